@@ -1,0 +1,379 @@
+"""MI355X-native detect -> crop -> embed -> match hot path of nghiapq77/face-recognition-cpp-tensorrt.
+
+The product is ``libfrt.so`` (hand-written HIP for gfx950 behind the C ABI of ``include/frt.h``).  This package is the
+Python-side mirror of the reference's class surface - ``RetinaFace`` (``/root/reference/src/retinaface.h:18-23``),
+``ArcFaceIR50`` (``src/arcface.h:19-39``), ``MatMul`` (``src/matmul.h:6-21``), ``getCroppedFaces`` (``src/arcface.h:17``)
+- used by the tests and by ``bench.py``; the C++ drop-in shells live in ``include/frt/*.h``.  Every call goes through the
+C ABI; there is no Python/CPU fallback: if ``libfrt.so`` is missing the import fails.
+
+The directory name is not an importable identifier; load it with::
+
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location("frt_amd", ".../face-recognition-cpp-tensorrt_amd/__init__.py",
+                                                  submodule_search_locations=[".../face-recognition-cpp-tensorrt_amd"])
+    frt_amd = importlib.util.module_from_spec(spec); sys.modules["frt_amd"] = frt_amd; spec.loader.exec_module(frt_amd)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import synth, weights_io  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrt.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("libfrt.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(or `make -C face-recognition-cpp-tensorrt_amd/csrc`).  There is no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+# ----------------------------------------------------------------------------------------------------------------------
+# C ABI declarations (include/frt.h)
+# ----------------------------------------------------------------------------------------------------------------------
+FRT_OK, FRT_ERR_INVALID, FRT_ERR_NOT_FOUND, FRT_ERR_FORMAT, FRT_ERR_DEVICE, FRT_ERR_EMPTY, FRT_ERR_EMPTY_ROI, FRT_ERR_CAPACITY = range(8)
+
+BBOX_DTYPE = np.dtype([("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"), ("score", "<f4")])  # == struct Bbox, common.h:13-16
+RESULT_DTYPE = np.dtype([("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"), ("score", "<f4"), ("frame", "<i4"),
+                         ("match_idx", "<i4"), ("match_sim", "<f4"), ("valid", "<i4")])
+assert BBOX_DTYPE.itemsize == 20 and RESULT_DTYPE.itemsize == 36
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+ABI = {
+    "frt_last_error": (ctypes.c_char_p, []),
+    "frt_version": (ctypes.c_char_p, []),
+    "frt_device_count": (_i, []),
+    "frt_detector_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, ctypes.POINTER(_vp)]),
+    "frt_detector_destroy": (None, [_vp]),
+    "frt_detector_num_anchors": (_i, [_vp]),
+    "frt_detector_find_faces": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp]),
+    "frt_detector_find_faces_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _vp]),
+    "frt_detector_preprocess": (_i, [_vp, _vp, _i, _i, _sz, _vp]),
+    "frt_detector_infer": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "frt_detector_postprocess": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "frt_crop_faces": (_i, [_vp, _i, _i, _sz, _vp, _i, _i, _i, _vp, _i]),
+    "frt_embedder_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
+    "frt_embedder_destroy": (None, [_vp]),
+    "frt_embedder_preprocess_face": (_i, [_vp, _vp, _vp]),
+    "frt_embedder_infer": (_i, [_vp, _vp, _i, _vp]),
+    "frt_embedder_forward": (_i, [_vp, _vp, _i, _i, _sz, _vp, _i, _vp, _vp]),
+    "frt_matcher_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "frt_matcher_destroy": (None, [_vp]),
+    "frt_matcher_init": (_i, [_vp, _vp, _i, _i]),
+    "frt_matcher_calculate": (_i, [_vp, _vp, _i, _vp]),
+    "frt_matcher_top1": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "frt_merge_top1": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frt_pipeline_create": (_i, [_vp, _vp, _vp, _i, ctypes.POINTER(_vp)]),
+    "frt_pipeline_destroy": (None, [_vp]),
+    "frt_pipeline_run": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "frt_pipeline_run_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "frt_pipeline_sync": (_i, [_vp]),
+    "frt_profile_enable": (_i, [_i]),
+    "frt_profile_collect": (_i, [_vp, _sz, _vp, _vp, _i]),
+}
+for _name, (_res, _args) in ABI.items():
+    _fn = getattr(lib, _name)  # AttributeError here == a symbol declared in frt.h is not exported
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class FrtError(RuntimeError):
+    """Raised on a non-zero frt_status; mirrors the reference's ``std::logic_error`` / ``throw const char*``."""
+
+    def __init__(self, code, msg):
+        super().__init__("frt status %d: %s" % (code, msg))
+        self.code = code
+
+
+def _check(rc):
+    if rc != FRT_OK:
+        raise FrtError(rc, lib.frt_last_error().decode(errors="replace"))
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def device_count():
+    return lib.frt_device_count()
+
+
+def write_weights(path, state, kind):
+    return weights_io.write_blob(path, state, kind)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# class MatMul (src/matmul.h)
+# ----------------------------------------------------------------------------------------------------------------------
+class MatMul:
+    def __init__(self, device=0):
+        self._h = _vp()
+        _check(lib.frt_matcher_create(device, ctypes.byref(self._h)))
+        self.m = self.k = 0
+
+    def init(self, knownEmbeds, numRow=None, numCol=None):
+        g = np.ascontiguousarray(knownEmbeds, np.float32)
+        numRow = g.shape[0] if numRow is None else numRow
+        numCol = g.shape[1] if numCol is None else numCol
+        _check(lib.frt_matcher_init(self._h, _ptr(g), int(numRow), int(numCol)))
+        self.m, self.k = int(numRow), int(numCol)
+
+    def calculate(self, embeds, embedCount=None):
+        e = np.ascontiguousarray(embeds, np.float32).reshape(-1, self.k)
+        n = e.shape[0] if embedCount is None else embedCount
+        out = np.empty((n, self.m), np.float32)
+        _check(lib.frt_matcher_calculate(self._h, _ptr(e), int(n), _ptr(out)))
+        return out
+
+    def top1(self, embeds):
+        e = np.ascontiguousarray(embeds, np.float32).reshape(-1, self.k)
+        idx = np.empty(e.shape[0], np.int32)
+        sim = np.empty(e.shape[0], np.float32)
+        _check(lib.frt_matcher_top1(self._h, _ptr(e), e.shape[0], _ptr(idx), _ptr(sim)))
+        return idx, sim
+
+    def close(self):
+        if self._h:
+            lib.frt_matcher_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_top1(idx_a, sim_a, idx_b, sim_b):
+    n = len(idx_a)
+    ia, ib = np.ascontiguousarray(idx_a, np.int32), np.ascontiguousarray(idx_b, np.int32)
+    sa, sb = np.ascontiguousarray(sim_a, np.float32), np.ascontiguousarray(sim_b, np.float32)
+    io, so = np.empty(n, np.int32), np.empty(n, np.float32)
+    _check(lib.frt_merge_top1(n, _ptr(ia), _ptr(sa), _ptr(ib), _ptr(sb), _ptr(io), _ptr(so)))
+    return io, so
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# class RetinaFace (src/retinaface.h)
+# ----------------------------------------------------------------------------------------------------------------------
+class RetinaFace:
+    def __init__(self, engineFile, frameWidth, frameHeight, inputShape=(3, 640, 640), maxBatchSize=1, maxFacesPerScene=4,
+                 nms_threshold=0.4, bbox_threshold=0.6, inputName="input_det", outputNames=("output_det0", "output_det1"), device=0):
+        assert len(inputShape) == 3 and len(outputNames) == 2  # retinaface.cpp:8,86 (binding names are accepted and ignored)
+        self._h = _vp()
+        self.frameWidth, self.frameHeight = int(frameWidth), int(frameHeight)
+        self.inputShape = tuple(int(x) for x in inputShape)
+        self.maxBatchSize, self.maxFacesPerScene = int(maxBatchSize), int(maxFacesPerScene)
+        _check(lib.frt_detector_create(os.fsencode(engineFile), self.frameWidth, self.frameHeight, *self.inputShape, self.maxBatchSize,
+                                       self.maxFacesPerScene, nms_threshold, bbox_threshold, device, ctypes.byref(self._h)))
+        self.numAnchors = lib.frt_detector_num_anchors(self._h)
+
+    def findFace(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros(self.maxFacesPerScene, BBOX_DTYPE)
+        n = ctypes.c_int(0)
+        _check(lib.frt_detector_find_faces(self._h, _ptr(img), img.shape[0], img.shape[1], img.strides[0], _ptr(out), ctypes.byref(n)))
+        return out[:n.value].copy()
+
+    def findFaceBatch(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        nf = frames.shape[0]
+        out = np.zeros((nf, self.maxFacesPerScene), BBOX_DTYPE)
+        n = np.zeros(nf, np.int32)
+        _check(lib.frt_detector_find_faces_batch(self._h, _ptr(frames), nf, frames.shape[1], frames.shape[2], frames.strides[1],
+                                                 frames.strides[0], _ptr(out), _ptr(n)))
+        return [out[i, :n[i]].copy() for i in range(nf)]
+
+    def preprocess(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.empty(self.inputShape, np.float32)
+        _check(lib.frt_detector_preprocess(self._h, _ptr(img), img.shape[0], img.shape[1], img.strides[0], _ptr(out)))
+        return out
+
+    def doInference(self, chw):
+        x = np.ascontiguousarray(chw, np.float32).reshape((-1,) + self.inputShape)
+        b = x.shape[0]
+        loc = np.empty((b, self.numAnchors, 4), np.float32)
+        conf = np.empty((b, self.numAnchors, 2), np.float32)
+        _check(lib.frt_detector_infer(self._h, _ptr(x), b, _ptr(loc), _ptr(conf)))
+        return loc, conf
+
+    def postprocessing(self, loc, conf):
+        loc = np.ascontiguousarray(loc, np.float32).reshape(self.numAnchors, 4)
+        conf = np.ascontiguousarray(conf, np.float32).reshape(self.numAnchors, 2)
+        out = np.zeros(self.maxFacesPerScene, BBOX_DTYPE)
+        n = ctypes.c_int(0)
+        _check(lib.frt_detector_postprocess(self._h, _ptr(loc), _ptr(conf), _ptr(out), ctypes.byref(n)))
+        return out[:n.value].copy()
+
+    def close(self):
+        if self._h:
+            lib.frt_detector_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def getCroppedFaces(frame, outputBbox, resize_w=112, resize_h=112, device=0):
+    """``getCroppedFaces`` (src/arcface.cpp:3-17) -> u8 BGR [n][resize_h][resize_w][3]."""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    boxes = np.ascontiguousarray(outputBbox, BBOX_DTYPE)
+    out = np.zeros((len(boxes), resize_h, resize_w, 3), np.uint8)
+    _check(lib.frt_crop_faces(_ptr(frame), frame.shape[0], frame.shape[1], frame.strides[0], _ptr(boxes), len(boxes), resize_w, resize_h,
+                              _ptr(out), device))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# class ArcFaceIR50 (src/arcface.h)
+# ----------------------------------------------------------------------------------------------------------------------
+class ArcFaceIR50:
+    classCount = 0  # the reference keeps this as a process-wide static (arcface.cpp:19); per-instance here
+
+    def __init__(self, engineFile, frameWidth=640, frameHeight=480, inputShape=(3, 112, 112), outputDim=512, maxBatchSize=1,
+                 maxFacesPerScene=4, knownPersonThreshold=0.65, inputName="input", outputName="output", device=0):
+        assert len(inputShape) == 3
+        self._h = _vp()
+        self.outputDim, self.maxBatchSize, self.maxFacesPerScene = int(outputDim), int(maxBatchSize), int(maxFacesPerScene)
+        self.knownPersonThresh = knownPersonThreshold
+        _check(lib.frt_embedder_create(os.fsencode(engineFile), *[int(x) for x in inputShape], self.outputDim, self.maxBatchSize, device,
+                                       ctypes.byref(self._h)))
+        self.matmul = MatMul(device)
+        self.croppedFaces = []  # list of dicts: face (u8 BGR crop), x1, y1, x2, y2  (struct CroppedFace, arcface.h:11-15)
+        self.classNames = []
+        self.classCount = 0
+        self._known = None
+        self._embeds = np.zeros((0, self.outputDim), np.float32)
+
+    def preprocessFace(self, face):
+        face = np.ascontiguousarray(face, np.uint8)
+        out = np.empty((3, 112, 112), np.float32)
+        _check(lib.frt_embedder_preprocess_face(self._h, _ptr(face), _ptr(out)))
+        return out
+
+    def doInference(self, chw, batchSize=None):
+        x = np.ascontiguousarray(chw, np.float32).reshape(-1, 3, 112, 112)
+        b = x.shape[0] if batchSize is None else batchSize
+        out = np.empty((b, self.outputDim), np.float32)
+        _check(lib.frt_embedder_infer(self._h, _ptr(x), b, _ptr(out)))
+        return out
+
+    def initKnownEmbeds(self, num):
+        self._known = np.zeros((int(num), self.outputDim), np.float32)
+
+    def addEmbedding(self, className, embedding):
+        self.classNames.append(className)
+        self._known[self.classCount] = np.asarray(embedding, np.float32)
+        self.classCount += 1
+
+    def addEmbeddings(self, classNames, embeddings):
+        """Bulk variant."""
+        e = np.asarray(embeddings, np.float32)
+        self._known[self.classCount:self.classCount + len(e)] = e
+        self.classNames.extend(classNames)
+        self.classCount += len(e)
+
+    def resetEmbeddings(self):
+        self.classCount = 0
+        self.classNames = []
+
+    def initMatMul(self):
+        self.matmul.init(self._known[:self.classCount], self.classCount, self.outputDim)
+
+    def forward(self, image, outputBbox):
+        image = np.ascontiguousarray(image, np.uint8)
+        boxes = np.ascontiguousarray(outputBbox, BBOX_DTYPE)
+        n = len(boxes)
+        embeds = np.zeros((n, self.outputDim), np.float32)
+        crops = np.zeros((n, 112, 112, 3), np.uint8)
+        if n:
+            _check(lib.frt_embedder_forward(self._h, _ptr(image), image.shape[0], image.shape[1], image.strides[0], _ptr(boxes), n,
+                                            _ptr(embeds), _ptr(crops)))
+        self._embeds = embeds
+        self.croppedFaces = [dict(face=crops[i], x1=int(b["x1"]), y1=int(b["y1"]), x2=int(b["x2"]), y2=int(b["y2"])) for i, b in enumerate(boxes)]
+        return embeds
+
+    def featureMatching(self):
+        if not self.classNames or not self.croppedFaces:
+            raise FrtError(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found")  # arcface.cpp:198
+        return self.matmul.calculate(self._embeds, len(self.croppedFaces))
+
+    def getOutputs(self, output_sims):
+        sims = np.asarray(output_sims, np.float32).reshape(len(self.croppedFaces), self.classCount)
+        arg = sims.argmax(1)  # first maximum == std::max_element (arcface.cpp:210)
+        return [self.classNames[a] for a in arg], [float(sims[i, a]) for i, a in enumerate(arg)]
+
+    def matchTop1(self):
+        """Fused featureMatching + getOutputs on the device (never materialises the F x N matrix)."""
+        if not self.classNames or not self.croppedFaces:
+            raise FrtError(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found")
+        idx, sim = self.matmul.top1(self._embeds)
+        return [self.classNames[a] for a in idx], [float(s) for s in sim]
+
+    def close(self):
+        if self._h:
+            lib.frt_embedder_destroy(self._h)
+            self._h = _vp()
+        self.matmul.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# batched device-resident pipeline (new surface)
+# ----------------------------------------------------------------------------------------------------------------------
+class Pipeline:
+    def __init__(self, detector, recognizer, max_frames):
+        self._h = _vp()
+        self.det, self.rec = detector, recognizer
+        self.max_frames = int(max_frames)
+        self.max_faces = detector.maxFacesPerScene
+        _check(lib.frt_pipeline_create(detector._h, recognizer._h, recognizer.matmul._h, self.max_frames, ctypes.byref(self._h)))
+
+    def run(self, frames, want_embeds=True):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n = frames.shape[0]
+        res = np.zeros(n * self.max_faces, RESULT_DTYPE)
+        emb = np.zeros((n * self.max_faces, 512), np.float32) if want_embeds else None
+        _check(lib.frt_pipeline_run(self._h, _ptr(frames), n, _ptr(res), _ptr(emb)))
+        return res, emb
+
+    def run_dev(self, frames_ptr, n_frames, results_ptr, embeds_ptr=None):
+        """Asynchronous; arguments are raw device addresses (e.g. ``torch.Tensor.data_ptr()``)."""
+        _check(lib.frt_pipeline_run_dev(self._h, _vp(frames_ptr), int(n_frames), _vp(results_ptr), _vp(embeds_ptr) if embeds_ptr else None))
+
+    def sync(self):
+        _check(lib.frt_pipeline_sync(self._h))
+
+    def close(self):
+        if self._h:
+            lib.frt_pipeline_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def profile_enable(kind):
+    _check(lib.frt_profile_enable(int(kind)))
+
+
+def profile_collect(cap=65536):
+    names = ctypes.create_string_buffer(cap * 24)
+    ms = np.zeros(cap, np.float64)
+    work = np.zeros(cap, np.float64)
+    n = lib.frt_profile_collect(names, len(names), _ptr(ms), _ptr(work), cap)
+    labels = names.value.decode().split("\n")[:n]
+    return labels, ms[:n].copy(), work[:n].copy()

@@ -1,0 +1,1124 @@
+// libfrt.so host side: weight loading/folding, the three objects behind the C ABI (include/frt.h) and the batched pipeline.
+// All device work is hand-written HIP (kernels_*.hip); there is no CPU fallback anywhere in this file: without a HIP
+// device every entry point that needs one fails with FRT_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "frt_kernels.h"
+#include "frt_weights.hpp"
+
+void launch_pack_results(const frt_bbox *boxes, const int *n_boxes, const int *valid, const int32_t *idx, const float *sim, int max_faces,
+                         int F, frt_face_result *out, hipStream_t s);
+
+namespace {
+
+thread_local std::string g_err;
+
+struct FrtError {
+    int code;
+    std::string msg;
+};
+
+[[noreturn]] void raise(int code, const std::string &m) { throw FrtError{code, m}; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) raise(FRT_ERR_DEVICE, std::string("HIP API failed: ") + #expr + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename Fn>
+int guarded(Fn &&fn) {
+    try {
+        fn();
+        g_err.clear();
+        return FRT_OK;
+    } catch (const FrtError &e) {
+        g_err = e.msg;
+        return e.code;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return FRT_ERR_FORMAT;
+    }
+}
+
+void use_device(int dev) { HIPCHK(hipSetDevice(dev)); }
+
+// ------------------------------------------------------------------------------------------------ device memory helpers
+struct Arena {
+    std::vector<void *> ptrs;
+    template <typename T>
+    T *alloc(size_t n) {
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+        ptrs.push_back(p);
+        return reinterpret_cast<T *>(p);
+    }
+    template <typename T>
+    T *upload(const std::vector<T> &v) {
+        T *d = alloc<T>(v.size());
+        HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return d;
+    }
+    void release() {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ profiling (HIP events)
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+    double work;
+};
+std::mutex g_prof_mu;
+int g_prof_kind = 0;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    bool on = false;
+    ProfRec rec;
+    hipStream_t s;
+    ProfScope(int level, const char *name, double work, hipStream_t st) : s(st) {
+        if (g_prof_kind != level) return;
+        on = true;
+        rec.name = name;
+        rec.work = work;
+        (void)hipEventCreate(&rec.a);
+        (void)hipEventCreate(&rec.b);
+        (void)hipEventRecord(rec.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(rec.b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+    }
+};
+
+}  // namespace
+
+// =====================================================================================================================
+// Detector
+// =====================================================================================================================
+struct frt_detector {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    Arena arena;
+    DetGeom g{};
+    int max_batch = 1;
+    struct Op {
+        int type;  // 0 dwpw, 1 conv3x3, 2 heads
+        DwPwArgs dw;
+        Conv3Args c3;
+        HeadArgs hd;
+    };
+    std::vector<Op> ops;
+    double flops_per_frame = 0;
+    uint8_t *d_frames = nullptr;
+    float *d_input = nullptr, *d_loc = nullptr, *d_conf = nullptr;
+    Candidate *d_cand = nullptr;
+    int *d_cand_count = nullptr, *d_nout = nullptr;
+    uint8_t *d_dead = nullptr;
+    frt_bbox *d_boxes = nullptr;
+
+    void build(const frt::Blob &b);
+    void forward(int n, hipStream_t s);          // d_input -> d_loc/d_conf
+    void postprocess(int n, hipStream_t s);      // d_loc/d_conf -> d_boxes/d_nout
+    void preprocess(const uint8_t *frames_dev, int n, size_t row_stride, size_t frame_stride, hipStream_t s);
+};
+
+namespace {
+
+// conv weight [Cout][Cin][3][3] (+BN) -> transposed [Cin][9][Cout] fp32 with the BN scale folded, bias [Cout]
+void fold_conv3(const frt::Blob &b, const std::string &conv, const std::string &bn, int cout, int cin, std::vector<float> &w, std::vector<float> &bias) {
+    const float *src = b.get(conv + ".weight", (size_t)cout * cin * 9).data;
+    std::vector<float> sc, bi;
+    frt::bn_fold(b, bn, cout, sc, bi);
+    w.assign((size_t)cin * 9 * cout, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 9; ++t) w[((size_t)ci * 9 + t) * cout + co] = src[((size_t)co * cin + ci) * 9 + t] * sc[co];
+    bias = bi;
+}
+void fold_dw(const frt::Blob &b, const std::string &conv, const std::string &bn, int c, std::vector<float> &w, std::vector<float> &bias) {
+    const float *src = b.get(conv + ".weight", (size_t)c * 9).data;
+    std::vector<float> sc, bi;
+    frt::bn_fold(b, bn, c, sc, bi);
+    w.resize((size_t)c * 9);
+    for (int i = 0; i < c; ++i)
+        for (int t = 0; t < 9; ++t) w[(size_t)i * 9 + t] = src[(size_t)i * 9 + t] * sc[i];
+    bias = bi;
+}
+void fold_pw(const frt::Blob &b, const std::string &conv, const std::string &bn, int cout, int cin, std::vector<float> &w, std::vector<float> &bias) {
+    const float *src = b.get(conv + ".weight", (size_t)cout * cin).data;
+    std::vector<float> sc, bi;
+    frt::bn_fold(b, bn, cout, sc, bi);
+    w.resize((size_t)cin * cout);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) w[(size_t)ci * cout + co] = src[(size_t)co * cin + ci] * sc[co];
+    bias = bi;
+}
+inline int conv_out(int x, int stride) { return (x + 2 - 3) / stride + 1; }
+
+}  // namespace
+
+void frt_detector::build(const frt::Blob &b) {
+    const int B = max_batch, H = g.in_h, W = g.in_w;
+    std::vector<float> w, bias, w2, bias2;
+    auto act = [&](int c, int h, int w_) { return arena.alloc<float>((size_t)B * c * h * w_); };
+    auto add_c3 = [&](const float *in, float *out, const std::string &conv, const std::string &bn, int cin, int cout, int h, int w_, int stride,
+                      int ctotal, int coff) {
+        fold_conv3(b, conv, bn, cout, cin, w, bias);
+        Op o{};
+        o.type = 1;
+        o.c3 = Conv3Args{in, out, arena.upload(w), arena.upload(bias), B, cin, h, w_, cout, conv_out(h, stride), conv_out(w_, stride), stride, 1, ctotal, coff};
+        ops.push_back(o);
+        flops_per_frame += 2.0 * cin * 9 * cout * o.c3.Ho * o.c3.Wo;
+    };
+    // ---- body (net.py:102-124); return layers stage1/2/3 (config.py:17)
+    struct L {
+        int cin, cout, stride;
+    };
+    const std::vector<std::pair<std::string, std::vector<L>>> stages = {
+        {"stage1", {{3, 8, 2}, {8, 16, 1}, {16, 32, 2}, {32, 32, 1}, {32, 64, 2}, {64, 64, 1}}},
+        {"stage2", {{64, 128, 2}, {128, 128, 1}, {128, 128, 1}, {128, 128, 1}, {128, 128, 1}, {128, 128, 1}}},
+        {"stage3", {{128, 256, 2}, {256, 256, 1}}}};
+    const float *cur = d_input;
+    int ch = H, cw = W;
+    const float *feat[3];
+    int fh[3], fw[3];
+    int si = 0;
+    for (auto &st : stages) {
+        for (size_t i = 0; i < st.second.size(); ++i) {
+            const L l = st.second[i];
+            const std::string p = "body." + st.first + "." + std::to_string(i);
+            const int oh = conv_out(ch, l.stride), ow = conv_out(cw, l.stride);
+            float *out = act(l.cout, oh, ow);
+            if (l.cin == 3) {
+                add_c3(cur, out, p + ".0", p + ".1", 3, l.cout, ch, cw, l.stride, l.cout, 0);
+            } else {
+                fold_dw(b, p + ".0", p + ".1", l.cin, w, bias);
+                fold_pw(b, p + ".3", p + ".4", l.cout, l.cin, w2, bias2);
+                Op o{};
+                o.type = 0;
+                o.dw = DwPwArgs{cur, out, arena.upload(w), arena.upload(bias), arena.upload(w2), arena.upload(bias2), nullptr, 0, 0,
+                                B, l.cin, ch, cw, l.cout, oh, ow, l.stride, 1};
+                ops.push_back(o);
+                flops_per_frame += 2.0 * oh * ow * (9.0 * l.cin + (double)l.cin * l.cout);
+            }
+            cur = out;
+            ch = oh;
+            cw = ow;
+        }
+        feat[si] = cur;
+        fh[si] = ch;
+        fw[si] = cw;
+        ++si;
+    }
+    for (int k = 0; k < 3; ++k)
+        if (fh[k] != g.fh[k] || fw[k] != g.fw[k]) raise(FRT_ERR_INVALID, "detector: feature-map size mismatch");
+    // ---- FPN (net.py:81-98): laterals 1x1+BN+ReLU, nearest-upsample-add top-down (fused), 3x3 merges
+    const int cins[3] = {64, 128, 256};
+    float *lat[3];
+    auto add_lat = [&](int k, const float *addsrc, int ah, int aw) {
+        const std::string p = "fpn.output" + std::to_string(k + 1);
+        fold_pw(b, p + ".0", p + ".1", 64, cins[k], w2, bias2);
+        lat[k] = act(64, fh[k], fw[k]);
+        Op o{};
+        o.type = 0;
+        o.dw = DwPwArgs{feat[k], lat[k], nullptr, nullptr, arena.upload(w2), arena.upload(bias2), addsrc, ah, aw,
+                        B, cins[k], fh[k], fw[k], 64, fh[k], fw[k], 1, 1};
+        ops.push_back(o);
+        flops_per_frame += 2.0 * fh[k] * fw[k] * cins[k] * 64;
+    };
+    add_lat(2, nullptr, 0, 0);
+    add_lat(1, lat[2], fh[2], fw[2]);
+    float *p4 = act(64, fh[1], fw[1]);
+    add_c3(lat[1], p4, "fpn.merge2.0", "fpn.merge2.1", 64, 64, fh[1], fw[1], 1, 64, 0);
+    add_lat(0, p4, fh[1], fw[1]);
+    float *p3 = act(64, fh[0], fw[0]);
+    add_c3(lat[0], p3, "fpn.merge1.0", "fpn.merge1.1", 64, 64, fh[0], fw[0], 1, 64, 0);
+    const float *pyr[3] = {p3, p4, lat[2]};
+    // ---- SSH (net.py:55-66) + heads (retinaface_trim.py:14-35).  Every SSH conv ends in a ReLU: either its own or the
+    //      ReLU applied to the concat it feeds exclusively.
+    for (int k = 0; k < 3; ++k) {
+        const std::string s = "ssh" + std::to_string(k + 1);
+        float *cat = act(64, fh[k], fw[k]);
+        float *t1 = act(16, fh[k], fw[k]);
+        float *t2 = act(16, fh[k], fw[k]);
+        add_c3(pyr[k], cat, s + ".conv3X3.0", s + ".conv3X3.1", 64, 32, fh[k], fw[k], 1, 64, 0);
+        add_c3(pyr[k], t1, s + ".conv5X5_1.0", s + ".conv5X5_1.1", 64, 16, fh[k], fw[k], 1, 16, 0);
+        add_c3(t1, cat, s + ".conv5X5_2.0", s + ".conv5X5_2.1", 16, 16, fh[k], fw[k], 1, 64, 32);
+        add_c3(t1, t2, s + ".conv7X7_2.0", s + ".conv7X7_2.1", 16, 16, fh[k], fw[k], 1, 16, 0);
+        add_c3(t2, cat, s + ".conv7x7_3.0", s + ".conv7x7_3.1", 16, 16, fh[k], fw[k], 1, 64, 48);
+        const std::string hb = "BboxHead." + std::to_string(k) + ".conv1x1", hc = "ClassHead." + std::to_string(k) + ".conv1x1";
+        const float *wb = b.get(hb + ".weight", 8 * 64).data, *wc = b.get(hc + ".weight", 4 * 64).data;
+        std::vector<float> tb(64 * 8), tc(64 * 4);
+        for (int co = 0; co < 8; ++co)
+            for (int ci = 0; ci < 64; ++ci) tb[ci * 8 + co] = wb[co * 64 + ci];
+        for (int co = 0; co < 4; ++co)
+            for (int ci = 0; ci < 64; ++ci) tc[ci * 4 + co] = wc[co * 64 + ci];
+        std::vector<float> bb(b.get(hb + ".bias", 8).data, b.get(hb + ".bias", 8).data + 8);
+        std::vector<float> bc(b.get(hc + ".bias", 4).data, b.get(hc + ".bias", 4).data + 4);
+        Op o{};
+        o.type = 2;
+        o.hd = HeadArgs{cat, arena.upload(tb), arena.upload(bb), arena.upload(tc), arena.upload(bc), d_loc, d_conf, B, 64, fh[k], fw[k], g.A, g.base[k]};
+        ops.push_back(o);
+        flops_per_frame += 2.0 * fh[k] * fw[k] * 64 * 12;
+    }
+}
+
+void frt_detector::preprocess(const uint8_t *frames_dev, int n, size_t row_stride, size_t frame_stride, hipStream_t s) {
+    ProfScope ps(2, "det_preprocess", (double)n * g.frame_h * g.frame_w * 3, s);
+    launch_det_preprocess(frames_dev, n, g.frame_h, g.frame_w, row_stride, frame_stride, g.in_h, g.in_w, d_input, s);
+}
+
+void frt_detector::forward(int n, hipStream_t s) {
+    ProfScope ps(2, "det_network", flops_per_frame * n, s);
+    for (Op &o : ops) {
+        if (o.type == 0) {
+            o.dw.B = n;
+            launch_dwpw(o.dw, s);
+        } else if (o.type == 1) {
+            o.c3.B = n;
+            launch_conv3x3(o.c3, s);
+        } else {
+            o.hd.B = n;
+            launch_heads(o.hd, s);
+        }
+    }
+}
+
+void frt_detector::postprocess(int n, hipStream_t s) {
+    ProfScope ps(2, "det_postprocess", (double)n * g.A, s);
+    launch_decode(d_loc, d_conf, n, g, d_cand, d_cand_count, s);
+    launch_nms(d_cand, d_cand_count, n, g, d_dead, d_boxes, d_nout, s);
+}
+
+// =====================================================================================================================
+// Embedder
+// =====================================================================================================================
+struct ArcUnit {
+    int cin, depth, stride, h_in;  // input spatial size (square)
+    half_t *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;
+    float *prelu = nullptr, *s2 = nullptr, *b2 = nullptr, *ssc = nullptr, *bsc = nullptr;
+    float *sn = nullptr, *bn = nullptr;  // BatchNorm that consumes this unit's output (next unit's leading BN / output_layer.0)
+    float *se_w1 = nullptr, *se_w2 = nullptr;
+};
+
+struct frt_embedder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    Arena arena;
+    int max_batch = 1;
+    bool se = false;
+    std::vector<ArcUnit> units;
+    float *in_w, *in_s0, *in_b0, *in_slope, *in_s1, *in_b1;
+    half_t *wfc;
+    float *fc_bias, *bn_s, *bn_b;
+    // activations
+    float *d_in = nullptr;  // [max_batch][3][112][112]
+    half_t *Y[2], *Z[2], *T, *SC, *RES = nullptr;
+    float *fc_partial, *d_out, *se_pool = nullptr, *se_gate = nullptr;
+    uint8_t *d_crops = nullptr;
+    int *d_valid = nullptr;
+    frt_bbox *d_boxes = nullptr;
+    uint8_t *d_frame = nullptr;
+    size_t frame_cap = 0;
+    static constexpr int FC_SPLITS = 49;
+    double flops_per_face = 0;
+
+    void build(const frt::Blob &b);
+    // chw_dev [F][3][112][112] -> out_dev [F][512]; F <= max_batch
+    void forward(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s);
+};
+
+namespace {
+
+std::vector<uint16_t> conv_w_f16(const frt::Blob &b, const std::string &name, int cout, int cin, int ks) {
+    // [Cout][Cin][kh][kw] fp32 -> [Cout][kh][kw][Cin] fp16 (K index = tap*Cin + ci)
+    const float *src = b.get(name, (size_t)cout * cin * ks * ks).data;
+    std::vector<uint16_t> w((size_t)cout * cin * ks * ks);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < ks * ks; ++t) w[((size_t)co * ks * ks + t) * cin + ci] = frt::f32_to_f16(src[((size_t)co * cin + ci) * ks * ks + t]);
+    return w;
+}
+std::vector<float> vec_of(const frt::Blob &b, const std::string &name, size_t n) {
+    const float *p = b.get(name, n).data;
+    return std::vector<float>(p, p + n);
+}
+
+}  // namespace
+
+void frt_embedder::build(const frt::Blob &b) {
+    std::vector<float> sc, bi;
+    // input layer (model_irse.py:139-141)
+    {
+        const float *src = b.get("input_layer.0.weight", 64 * 27).data;
+        std::vector<float> w(27 * 64);
+        for (int co = 0; co < 64; ++co)
+            for (int k = 0; k < 27; ++k) w[k * 64 + co] = src[co * 27 + k];
+        in_w = arena.upload(w);
+        frt::bn_fold(b, "input_layer.1", 64, sc, bi);
+        in_s0 = arena.upload(sc);
+        in_b0 = arena.upload(bi);
+        in_slope = arena.upload(vec_of(b, "input_layer.2.weight", 64));
+        frt::bn_fold(b, "body.0.res_layer.0", 64, sc, bi);
+        in_s1 = arena.upload(sc);
+        in_b1 = arena.upload(bi);
+        flops_per_face += 2.0 * 27 * 64 * 112 * 112;
+    }
+    // units (model_irse.py:97-109 for IR-50)
+    const int cfg[4][3] = {{64, 64, 3}, {64, 128, 4}, {128, 256, 14}, {256, 512, 3}};
+    int h = 112, idx = 0;
+    for (int st = 0; st < 4; ++st)
+        for (int u = 0; u < cfg[st][2]; ++u) {
+            ArcUnit a;
+            a.cin = u == 0 ? cfg[st][0] : cfg[st][1];
+            a.depth = cfg[st][1];
+            a.stride = u == 0 ? 2 : 1;
+            a.h_in = h;
+            const std::string p = "body." + std::to_string(idx);
+            a.w1 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".res_layer.1.weight", a.depth, a.cin, 3)));
+            a.prelu = arena.upload(vec_of(b, p + ".res_layer.2.weight", a.depth));
+            a.w2 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".res_layer.3.weight", a.depth, a.depth, 3)));
+            frt::bn_fold(b, p + ".res_layer.4", a.depth, sc, bi);
+            a.s2 = arena.upload(sc);
+            a.b2 = arena.upload(bi);
+            if (a.cin != a.depth) {
+                a.wsc = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".shortcut_layer.0.weight", a.depth, a.cin, 1)));
+                frt::bn_fold(b, p + ".shortcut_layer.1", a.depth, sc, bi);
+                a.ssc = arena.upload(sc);
+                a.bsc = arena.upload(bi);
+            }
+            if (se) {
+                a.se_w1 = arena.upload(vec_of(b, p + ".res_layer.5.fc1.weight", (size_t)a.depth / 16 * a.depth));
+                a.se_w2 = arena.upload(vec_of(b, p + ".res_layer.5.fc2.weight", (size_t)a.depth * (a.depth / 16)));
+            }
+            const bool last = st == 3 && u == cfg[st][2] - 1;
+            frt::bn_fold(b, last ? std::string("output_layer.0") : "body." + std::to_string(idx + 1) + ".res_layer.0", a.depth, sc, bi);
+            a.sn = arena.upload(sc);
+            a.bn = arena.upload(bi);
+            const int ho = h / a.stride;
+            flops_per_face += 2.0 * 9 * a.cin * a.depth * h * h + 2.0 * 9 * a.depth * a.depth * ho * ho;
+            if (a.wsc) flops_per_face += 2.0 * a.cin * a.depth * ho * ho;
+            units.push_back(a);
+            h = ho;
+            ++idx;
+        }
+    // output layer (model_irse.py:143-147): Linear over the NCHW flatten (index c*49 + hw) re-ordered to NHWC (hw*512 + c)
+    {
+        const float *src = b.get("output_layer.3.weight", (size_t)512 * 25088).data;
+        std::vector<uint16_t> w((size_t)512 * 25088);
+        for (int o = 0; o < 512; ++o)
+            for (int c = 0; c < 512; ++c)
+                for (int hw = 0; hw < 49; ++hw) w[(size_t)o * 25088 + (size_t)hw * 512 + c] = frt::f32_to_f16(src[(size_t)o * 25088 + (size_t)c * 49 + hw]);
+        wfc = reinterpret_cast<half_t *>(arena.upload(w));
+        fc_bias = arena.upload(vec_of(b, "output_layer.3.bias", 512));
+        frt::bn_fold(b, "output_layer.4", 512, sc, bi);
+        bn_s = arena.upload(sc);
+        bn_b = arena.upload(bi);
+        flops_per_face += 2.0 * 25088 * 512;
+    }
+    const size_t F = (size_t)max_batch;
+    const size_t big = F * 112 * 112 * 64;
+    d_in = arena.alloc<float>(F * 3 * 112 * 112);
+    for (int i = 0; i < 2; ++i) {
+        Y[i] = arena.alloc<half_t>(big);
+        Z[i] = arena.alloc<half_t>(big);
+    }
+    T = arena.alloc<half_t>(big);
+    SC = arena.alloc<half_t>(F * 28 * 28 * 128);  // largest conv-shortcut output (56->28, 128 ch)
+    if (se) {
+        RES = arena.alloc<half_t>(F * 56 * 56 * 64);
+        se_pool = arena.alloc<float>(F * 512);
+        se_gate = arena.alloc<float>(F * 512);
+    }
+    fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);
+    d_out = arena.alloc<float>(F * 512);
+    d_crops = arena.alloc<uint8_t>(F * 112 * 112 * 3);
+    d_valid = arena.alloc<int>(F);
+    d_boxes = arena.alloc<frt_bbox>(F);
+}
+
+void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s) {
+    ProfScope ps(2, "embed_network", flops_per_face * F, s);
+    ArcInputArgs ia{chw_dev, in_w, in_s0, in_b0, in_slope, in_s1, in_b1, Y[0], Z[0], F, 112, 112};
+    launch_arc_input(ia, s);
+    int cur = 0;
+    for (const ArcUnit &u : units) {
+        const int h = u.h_in, ho = h / u.stride;
+        {  // conv1: BN(x) [already applied -> Z] -> conv3x3 s1 -> PReLU
+            ConvMfmaArgs a{};
+            a.x = Z[cur];
+            a.w = u.w1;
+            a.B = F; a.H = h; a.W = h; a.Cin = u.cin; a.Ho = h; a.Wo = h; a.Cout = u.depth; a.ks = 3; a.stride = 1; a.pad = 1;
+            a.mode = EPI_PRELU;
+            a.p0 = u.prelu;
+            a.out0 = T;
+            a.splits = 1;
+            ProfScope pk(1, "conv3x3_mfma", 2.0 * 9 * u.cin * u.depth * (double)F * h * h, s);
+            launch_conv_mfma(a, s);
+        }
+        const half_t *sc_t = Y[cur];
+        int sc_h = h, sc_stride = u.stride;
+        if (u.wsc) {  // conv1x1 stride s + BN on the raw input
+            ConvMfmaArgs a{};
+            a.x = Y[cur];
+            a.w = u.wsc;
+            a.B = F; a.H = h; a.W = h; a.Cin = u.cin; a.Ho = ho; a.Wo = ho; a.Cout = u.depth; a.ks = 1; a.stride = u.stride; a.pad = 0;
+            a.mode = EPI_BN;
+            a.p0 = u.ssc;
+            a.p1 = u.bsc;
+            a.out0 = SC;
+            a.splits = 1;
+            launch_conv_mfma(a, s);
+            sc_t = SC;
+            sc_h = ho;
+            sc_stride = 1;
+        }
+        {  // conv2: conv3x3 stride s -> BN -> (+SE) -> + shortcut ; also emit BN_next(y)
+            ConvMfmaArgs a{};
+            a.x = T;
+            a.w = u.w2;
+            a.B = F; a.H = h; a.W = h; a.Cin = u.depth; a.Ho = ho; a.Wo = ho; a.Cout = u.depth; a.ks = 3; a.stride = u.stride; a.pad = 1;
+            a.p0 = u.s2;
+            a.p1 = u.b2;
+            a.splits = 1;
+            if (!se) {
+                a.mode = EPI_BN_ADD_BN;
+                a.p2 = u.sn;
+                a.p3 = u.bn;
+                a.sc = sc_t;
+                a.sc_h = sc_h; a.sc_w = sc_h; a.sc_stride = sc_stride;
+                a.out0 = Y[cur ^ 1];
+                a.out1 = Z[cur ^ 1];
+            } else {
+                a.mode = EPI_BN;
+                a.out0 = RES;
+            }
+            {
+                ProfScope pk(1, "conv3x3_mfma", 2.0 * 9 * u.depth * u.depth * (double)F * ho * ho, s);
+                launch_conv_mfma(a, s);
+            }
+            if (se) {
+                SeArgs sa{RES, u.se_w1, u.se_w2, sc_t, sc_h, sc_h, sc_stride, u.sn, u.bn, Y[cur ^ 1], Z[cur ^ 1], se_pool, se_gate, F, ho, ho, u.depth};
+                launch_se(sa, s);
+            }
+        }
+        cur ^= 1;
+    }
+    {  // Linear 25088 -> 512 as a split-K GEMM over the NHWC-flattened BN2d output (Z), then bias + BN1d + L2 norm
+        ConvMfmaArgs a{};
+        a.x = Z[cur];
+        a.w = wfc;
+        a.B = F; a.H = 1; a.W = 1; a.Cin = 25088; a.Ho = 1; a.Wo = 1; a.Cout = 512; a.ks = 1; a.stride = 1; a.pad = 0;
+        a.mode = EPI_PARTIAL;
+        a.outf = fc_partial;
+        a.splits = FC_SPLITS;
+        launch_conv_mfma(a, s);
+        launch_fc_finalize(fc_partial, FC_SPLITS, F, fc_bias, bn_s, bn_b, valid_dev, out_dev, s);
+    }
+}
+
+// =====================================================================================================================
+// Matcher
+// =====================================================================================================================
+struct frt_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    float *d_gallery = nullptr;
+    int N = 0, D = 0;
+    // scratch (grown on demand)
+    float *d_q = nullptr, *d_sim = nullptr, *d_full = nullptr;
+    int32_t *d_idx = nullptr;
+    MatchPartial *d_partial = nullptr;
+    int q_cap = 0;
+    size_t full_cap = 0;
+    int blocks = 0;
+
+    void ensure_queries(int F) {
+        if (F <= q_cap && d_partial) return;
+        const int cap = std::max(F, 128);
+        if (d_q) (void)hipFree(d_q);
+        if (d_sim) (void)hipFree(d_sim);
+        if (d_idx) (void)hipFree(d_idx);
+        if (d_partial) (void)hipFree(d_partial);
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_q), (size_t)cap * D * sizeof(float)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_sim), (size_t)cap * sizeof(float)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_idx), (size_t)cap * sizeof(int32_t)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_partial), (size_t)blocks * cap * sizeof(MatchPartial)));
+        q_cap = cap;
+    }
+    // queries_dev [F][D] -> idx_dev, sim_dev (device pointers)
+    void top1_dev(const float *queries_dev, int F, int32_t *idx_dev, float *sim_dev, hipStream_t s) {
+        ProfScope ps(2, "match_top1", 2.0 * D * (double)N * F, s);
+        // the partial scratch is [blocks][F]
+        launch_match_top1(d_gallery, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, 0, s);
+    }
+};
+
+// =====================================================================================================================
+// Pipeline
+// =====================================================================================================================
+struct frt_pipeline {
+    frt_detector *det;
+    frt_embedder *emb;
+    frt_matcher *mat;
+    int max_frames, max_faces, F_cap;
+    hipStream_t stream = nullptr;
+    Arena arena;
+    uint8_t *d_frames;
+    float *d_chw, *d_embeds, *d_sim;
+    int *d_valid;
+    int32_t *d_idx;
+    frt_face_result *d_results;
+
+    void run(const uint8_t *frames_dev, int n, frt_face_result *results_dev, float *embeds_dev) {
+        hipStream_t s = stream;
+        const DetGeom &g = det->g;
+        const int F = n * max_faces;
+        det->preprocess(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, s);
+        det->forward(n, s);
+        det->postprocess(n, s);
+        {
+            ProfScope ps(2, "crop_faces", (double)F * 112 * 112 * 3, s);
+            launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, det->d_boxes, det->d_nout,
+                              max_faces, F, 0, 112, 112, nullptr, d_chw, d_valid, s);
+        }
+        float *emb_out = embeds_dev ? embeds_dev : d_embeds;
+        for (int f0 = 0; f0 < F; f0 += emb->max_batch) {
+            const int nf = std::min(emb->max_batch, F - f0);
+            emb->forward(d_chw + (size_t)f0 * 3 * 112 * 112, nf, d_valid + f0, emb_out + (size_t)f0 * 512, s);
+        }
+        const bool have_gallery = mat && mat->N > 0;
+        if (have_gallery) mat->top1_dev(emb_out, F, d_idx, d_sim, s);
+        ProfScope ps(2, "pack_results", (double)F, s);
+        launch_pack_results(det->d_boxes, det->d_nout, d_valid, have_gallery ? d_idx : nullptr, have_gallery ? d_sim : nullptr, max_faces, F,
+                            results_dev, s);
+    }
+};
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" {
+
+const char *frt_last_error(void) { return g_err.c_str(); }
+const char *frt_version(void) { return "libfrt 0.1 (gfx950)"; }
+int frt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int in_c, int in_h, int in_w, int max_batch, int max_faces,
+                        float nms_threshold, float bbox_threshold, int device, frt_detector **out) {
+    return guarded([&] {
+        if (!out || !weights_path) raise(FRT_ERR_INVALID, "null argument");
+        *out = nullptr;
+        if (in_c != 3 || in_h < 32 || in_w < 32 || frame_w < 1 || frame_h < 1 || max_batch < 1 || max_faces < 1)
+            raise(FRT_ERR_INVALID, "detector: invalid shape arguments");
+        frt::Blob blob;
+        std::string err;
+        const int rc = blob.load(weights_path, err);
+        if (rc) raise(rc, err);
+        if (blob.kind != 1) raise(FRT_ERR_FORMAT, "detector: weight blob is not a RetinaFace-mobilenet0.25 blob");
+        use_device(device);
+        std::unique_ptr<frt_detector> d(new frt_detector);
+        d->device = device;
+        d->max_batch = max_batch;
+        DetGeom &g = d->g;
+        g.in_w = in_w; g.in_h = in_h; g.frame_w = frame_w; g.frame_h = frame_h;
+        const float steps[3] = {8.f, 16.f, 32.f};
+        int base = 0;
+        for (int k = 0; k < 3; ++k) {
+            g.fh[k] = (int)std::ceil(in_h / steps[k]);
+            g.fw[k] = (int)std::ceil(in_w / steps[k]);
+            g.base[k] = base;
+            base += g.fh[k] * g.fw[k] * 2;
+        }
+        g.A = base;
+        g.scale_h = (float)in_h / frame_h;  // retinaface.cpp:21-22
+        g.scale_w = (float)in_w / frame_w;
+        g.nms_thr = nms_threshold;
+        g.bbox_thr = bbox_threshold;
+        g.max_faces = max_faces;
+        HIPCHK(hipStreamCreate(&d->stream));
+        const size_t B = (size_t)max_batch;
+        d->d_frames = d->arena.alloc<uint8_t>(B * frame_h * frame_w * 3);
+        d->d_input = d->arena.alloc<float>(B * 3 * in_h * in_w);
+        d->d_loc = d->arena.alloc<float>(B * g.A * 4);
+        d->d_conf = d->arena.alloc<float>(B * g.A * 2);
+        d->d_cand = d->arena.alloc<Candidate>(B * g.A);
+        d->d_cand_count = d->arena.alloc<int>(B);
+        d->d_nout = d->arena.alloc<int>(B);
+        d->d_dead = d->arena.alloc<uint8_t>(B * g.A);
+        d->d_boxes = d->arena.alloc<frt_bbox>(B * max_faces);
+        d->build(blob);
+        HIPCHK(hipDeviceSynchronize());
+        *out = d.release();
+    });
+}
+
+void frt_detector_destroy(frt_detector *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->stream) {
+        (void)hipStreamSynchronize(d->stream);
+        (void)hipStreamDestroy(d->stream);
+    }
+    d->arena.release();
+    delete d;
+}
+
+int frt_detector_num_anchors(const frt_detector *d) { return d ? d->g.A : 0; }
+
+int frt_detector_find_faces_batch(frt_detector *d, const uint8_t *bgr, int n_frames, int rows, int cols, size_t row_stride,
+                                  size_t frame_stride, frt_bbox *out, int *n_out) {
+    return guarded([&] {
+        if (!d || !bgr || !out || !n_out) raise(FRT_ERR_INVALID, "null argument");
+        if (rows != d->g.frame_h || cols != d->g.frame_w) raise(FRT_ERR_INVALID, "findFace: frame must be frameWidth x frameHeight");
+        if (n_frames < 1 || n_frames > d->max_batch) raise(FRT_ERR_CAPACITY, "findFace: more frames than det_maxBatchSize");
+        std::lock_guard<std::mutex> lk(d->mu);
+        use_device(d->device);
+        hipStream_t s = d->stream;
+        const size_t tight = (size_t)cols * 3;
+        for (int f = 0; f < n_frames; ++f)
+            HIPCHK(hipMemcpy2DAsync(d->d_frames + (size_t)f * rows * tight, tight, bgr + (size_t)f * frame_stride, row_stride, tight, rows,
+                                    hipMemcpyHostToDevice, s));
+        d->preprocess(d->d_frames, n_frames, tight, (size_t)rows * tight, s);
+        d->forward(n_frames, s);
+        d->postprocess(n_frames, s);
+        HIPCHK(hipMemcpyAsync(out, d->d_boxes, sizeof(frt_bbox) * n_frames * d->g.max_faces, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(n_out, d->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_detector_find_faces(frt_detector *d, const uint8_t *bgr, int rows, int cols, size_t row_stride, frt_bbox *out, int *n_out) {
+    return frt_detector_find_faces_batch(d, bgr, 1, rows, cols, row_stride, row_stride * (size_t)rows, out, n_out);
+}
+
+int frt_detector_preprocess(frt_detector *d, const uint8_t *bgr, int rows, int cols, size_t row_stride, float *chw_out) {
+    return guarded([&] {
+        if (!d || !bgr || !chw_out) raise(FRT_ERR_INVALID, "null argument");
+        if (rows != d->g.frame_h || cols != d->g.frame_w) raise(FRT_ERR_INVALID, "preprocess: frame must be frameWidth x frameHeight");
+        std::lock_guard<std::mutex> lk(d->mu);
+        use_device(d->device);
+        hipStream_t s = d->stream;
+        const size_t tight = (size_t)cols * 3;
+        HIPCHK(hipMemcpy2DAsync(d->d_frames, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice, s));
+        d->preprocess(d->d_frames, 1, tight, (size_t)rows * tight, s);
+        HIPCHK(hipMemcpyAsync(chw_out, d->d_input, sizeof(float) * 3 * d->g.in_h * d->g.in_w, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_detector_infer(frt_detector *d, const float *chw, int batch, float *loc_out, float *conf_out) {
+    return guarded([&] {
+        if (!d || !chw || !loc_out || !conf_out) raise(FRT_ERR_INVALID, "null argument");
+        if (batch < 1 || batch > d->max_batch) raise(FRT_ERR_CAPACITY, "doInference: batch exceeds det_maxBatchSize");
+        std::lock_guard<std::mutex> lk(d->mu);
+        use_device(d->device);
+        hipStream_t s = d->stream;
+        const size_t in_elems = (size_t)3 * d->g.in_h * d->g.in_w;
+        HIPCHK(hipMemcpyAsync(d->d_input, chw, sizeof(float) * in_elems * batch, hipMemcpyHostToDevice, s));
+        d->forward(batch, s);
+        HIPCHK(hipMemcpyAsync(loc_out, d->d_loc, sizeof(float) * (size_t)batch * d->g.A * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(conf_out, d->d_conf, sizeof(float) * (size_t)batch * d->g.A * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_detector_postprocess(frt_detector *d, const float *loc, const float *conf, frt_bbox *out, int *n_out) {
+    return guarded([&] {
+        if (!d || !loc || !conf || !out || !n_out) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(d->mu);
+        use_device(d->device);
+        hipStream_t s = d->stream;
+        HIPCHK(hipMemcpyAsync(d->d_loc, loc, sizeof(float) * (size_t)d->g.A * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d->d_conf, conf, sizeof(float) * (size_t)d->g.A * 2, hipMemcpyHostToDevice, s));
+        d->postprocess(1, s);
+        HIPCHK(hipMemcpyAsync(out, d->d_boxes, sizeof(frt_bbox) * d->g.max_faces, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(n_out, d->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------- crop
+int frt_crop_faces(const uint8_t *bgr, int rows, int cols, size_t row_stride, const frt_bbox *boxes, int n, int out_w, int out_h,
+                   uint8_t *crops_out, int device) {
+    return guarded([&] {
+        if (!bgr || !boxes || !crops_out || n < 0 || out_w < 1 || out_h < 1) raise(FRT_ERR_INVALID, "getCroppedFaces: bad argument");
+        if (n == 0) return;
+        if (device >= 0) use_device(device);
+        Arena a;
+        struct Guard {
+            Arena &a;
+            ~Guard() { a.release(); }
+        } guard{a};
+        const size_t tight = (size_t)cols * 3;
+        uint8_t *d_frame = a.alloc<uint8_t>((size_t)rows * tight);
+        frt_bbox *d_boxes = a.alloc<frt_bbox>(n);
+        uint8_t *d_crops = a.alloc<uint8_t>((size_t)n * out_h * out_w * 3);
+        float *d_chw = a.alloc<float>((size_t)n * out_h * out_w * 3);
+        int *d_valid = a.alloc<int>(n);
+        HIPCHK(hipMemcpy2D(d_frame, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_boxes, boxes, sizeof(frt_bbox) * n, hipMemcpyHostToDevice));
+        launch_crop_faces(d_frame, rows, cols, tight, 0, d_boxes, nullptr, 1, n, 1, out_h, out_w, d_crops, d_chw, d_valid, nullptr);
+        std::vector<int> valid(n);
+        HIPCHK(hipMemcpy(valid.data(), d_valid, sizeof(int) * n, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> tmp((size_t)n * out_h * out_w * 3);
+        HIPCHK(hipMemcpy(tmp.data(), d_crops, tmp.size(), hipMemcpyDeviceToHost));
+        bool bad = false;
+        for (int i = 0; i < n; ++i) {
+            if (valid[i])
+                std::memcpy(crops_out + (size_t)i * out_h * out_w * 3, tmp.data() + (size_t)i * out_h * out_w * 3, (size_t)out_h * out_w * 3);
+            else
+                bad = true;
+        }
+        if (bad) raise(FRT_ERR_EMPTY_ROI, "getCroppedFaces: empty or out-of-frame ROI");
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------ embedder
+int frt_embedder_create(const char *weights_path, int in_c, int in_h, int in_w, int out_dim, int max_batch, int device, frt_embedder **out) {
+    return guarded([&] {
+        if (!out || !weights_path) raise(FRT_ERR_INVALID, "null argument");
+        *out = nullptr;
+        if (in_c != 3 || in_h != 112 || in_w != 112 || out_dim != 512 || max_batch < 1)
+            raise(FRT_ERR_INVALID, "embedder: only rec_inputShape [3,112,112] and rec_outputDim 512 are supported");
+        frt::Blob blob;
+        std::string err;
+        const int rc = blob.load(weights_path, err);
+        if (rc) raise(rc, err);
+        if (blob.kind != 2 && blob.kind != 3) raise(FRT_ERR_FORMAT, "embedder: weight blob is not an ArcFace IR-50 / IR-SE-50 blob");
+        use_device(device);
+        std::unique_ptr<frt_embedder> e(new frt_embedder);
+        e->device = device;
+        e->max_batch = max_batch;
+        e->se = blob.kind == 3;
+        HIPCHK(hipStreamCreate(&e->stream));
+        e->build(blob);
+        HIPCHK(hipDeviceSynchronize());
+        *out = e.release();
+    });
+}
+
+void frt_embedder_destroy(frt_embedder *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamDestroy(e->stream);
+    }
+    if (e->d_frame) (void)hipFree(e->d_frame);
+    e->arena.release();
+    delete e;
+}
+
+int frt_embedder_preprocess_face(frt_embedder *e, const uint8_t *bgr_crop, float *chw_out) {
+    return guarded([&] {
+        if (!e || !bgr_crop || !chw_out) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(e->mu);
+        use_device(e->device);
+        hipStream_t s = e->stream;
+        HIPCHK(hipMemcpyAsync(e->d_crops, bgr_crop, 112 * 112 * 3, hipMemcpyHostToDevice, s));
+        launch_face_normalize(e->d_crops, 1, 112, 112, e->d_in, s);
+        HIPCHK(hipMemcpyAsync(chw_out, e->d_in, sizeof(float) * 3 * 112 * 112, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_embedder_infer(frt_embedder *e, const float *chw, int batch, float *embeds_out) {
+    return guarded([&] {
+        if (!e || !chw || !embeds_out || batch < 1) raise(FRT_ERR_INVALID, "doInference: bad argument");
+        std::lock_guard<std::mutex> lk(e->mu);
+        use_device(e->device);
+        hipStream_t s = e->stream;
+        const size_t in_elems = (size_t)3 * 112 * 112;
+        for (int f0 = 0; f0 < batch; f0 += e->max_batch) {
+            const int nf = std::min(e->max_batch, batch - f0);
+            HIPCHK(hipMemcpyAsync(e->d_in, chw + (size_t)f0 * in_elems, sizeof(float) * in_elems * nf, hipMemcpyHostToDevice, s));
+            e->forward(e->d_in, nf, nullptr, e->d_out, s);
+            HIPCHK(hipMemcpyAsync(embeds_out + (size_t)f0 * 512, e->d_out, sizeof(float) * 512 * nf, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    });
+}
+
+int frt_embedder_forward(frt_embedder *e, const uint8_t *bgr, int rows, int cols, size_t row_stride, const frt_bbox *boxes, int n,
+                         float *embeds_out, uint8_t *crops_out) {
+    return guarded([&] {
+        if (!e || !bgr || !boxes || !embeds_out || n < 0 || rows < 1 || cols < 1) raise(FRT_ERR_INVALID, "forward: bad argument");
+        if (n == 0) return;
+        std::lock_guard<std::mutex> lk(e->mu);
+        use_device(e->device);
+        hipStream_t s = e->stream;
+        const size_t tight = (size_t)cols * 3, need = (size_t)rows * tight;
+        if (need > e->frame_cap) {
+            if (e->d_frame) (void)hipFree(e->d_frame);
+            e->d_frame = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&e->d_frame), need));
+            e->frame_cap = need;
+        }
+        HIPCHK(hipMemcpy2DAsync(e->d_frame, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice, s));
+        bool bad = false;
+        for (int f0 = 0; f0 < n; f0 += e->max_batch) {
+            const int nf = std::min(e->max_batch, n - f0);
+            HIPCHK(hipMemcpyAsync(e->d_boxes, boxes + f0, sizeof(frt_bbox) * nf, hipMemcpyHostToDevice, s));
+            launch_crop_faces(e->d_frame, rows, cols, tight, 0, e->d_boxes, nullptr, 1, nf, 1, 112, 112, e->d_crops, e->d_in, e->d_valid, s);
+            e->forward(e->d_in, nf, e->d_valid, e->d_out, s);
+            HIPCHK(hipMemcpyAsync(embeds_out + (size_t)f0 * 512, e->d_out, sizeof(float) * 512 * nf, hipMemcpyDeviceToHost, s));
+            if (crops_out) HIPCHK(hipMemcpyAsync(crops_out + (size_t)f0 * 112 * 112 * 3, e->d_crops, (size_t)nf * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
+            std::vector<int> valid(nf);
+            HIPCHK(hipMemcpyAsync(valid.data(), e->d_valid, sizeof(int) * nf, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (int v : valid) bad = bad || !v;
+        }
+        if (bad) raise(FRT_ERR_EMPTY_ROI, "forward: empty or out-of-frame ROI (embedding set to zeros)");
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------- matcher
+int frt_matcher_create(int device, frt_matcher **out) {
+    return guarded([&] {
+        if (!out) raise(FRT_ERR_INVALID, "null argument");
+        *out = nullptr;
+        use_device(device);
+        std::unique_ptr<frt_matcher> m(new frt_matcher);
+        m->device = device;
+        HIPCHK(hipStreamCreate(&m->stream));
+        *out = m.release();
+    });
+}
+
+void frt_matcher_destroy(frt_matcher *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) {
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipStreamDestroy(m->stream);
+    }
+    for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full})
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+int frt_matcher_init(frt_matcher *m, const float *gallery, int num_row, int num_col) {
+    return guarded([&] {
+        if (!m || (num_row > 0 && !gallery) || num_row < 0) raise(FRT_ERR_INVALID, "MatMul::init: bad argument");
+        if (num_col < 32 || num_col % 32) raise(FRT_ERR_INVALID, "MatMul::init: numCol must be a multiple of 32");
+        std::lock_guard<std::mutex> lk(m->mu);
+        use_device(m->device);
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (m->d_gallery) (void)hipFree(m->d_gallery);  // idempotent re-init (the reference leaks here on /reload)
+        m->d_gallery = nullptr;
+        m->N = num_row;
+        m->D = num_col;
+        if (num_row > 0) {
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_gallery), (size_t)num_row * num_col * sizeof(float)));
+            HIPCHK(hipMemcpy(m->d_gallery, gallery, (size_t)num_row * num_col * sizeof(float), hipMemcpyHostToDevice));
+        }
+        m->blocks = match_top1_blocks(num_row, 0);
+        m->q_cap = 0;  // partial scratch depends on `blocks`
+        if (m->d_partial) {
+            (void)hipFree(m->d_partial);
+            m->d_partial = nullptr;
+        }
+    });
+}
+
+int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, float *outputs) {
+    return guarded([&] {
+        if (!m || !embeds || !outputs) raise(FRT_ERR_INVALID, "MatMul::calculate: null argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (m->N <= 0 || embed_count <= 0) raise(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found");
+        use_device(m->device);
+        hipStream_t s = m->stream;
+        m->ensure_queries(embed_count);
+        const size_t need = (size_t)embed_count * m->N;
+        if (need > m->full_cap) {
+            if (m->d_full) (void)hipFree(m->d_full);
+            m->d_full = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_full), need * sizeof(float)));
+            m->full_cap = need;
+        }
+        HIPCHK(hipMemcpyAsync(m->d_q, embeds, sizeof(float) * (size_t)embed_count * m->D, hipMemcpyHostToDevice, s));
+        for (int f0 = 0; f0 < embed_count; f0 += 128) {
+            const int nf = std::min(128, embed_count - f0);
+            launch_match_full(m->d_gallery, m->N, m->D, m->d_q + (size_t)f0 * m->D, nf, m->d_full + (size_t)f0 * m->N, s);
+        }
+        HIPCHK(hipMemcpyAsync(outputs, m->d_full, need * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_matcher_top1(frt_matcher *m, const float *embeds, int embed_count, int32_t *idx_out, float *sim_out) {
+    return guarded([&] {
+        if (!m || !embeds || !idx_out || !sim_out) raise(FRT_ERR_INVALID, "top1: null argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (m->N <= 0 || embed_count <= 0) raise(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found");
+        use_device(m->device);
+        hipStream_t s = m->stream;
+        m->ensure_queries(embed_count);
+        HIPCHK(hipMemcpyAsync(m->d_q, embeds, sizeof(float) * (size_t)embed_count * m->D, hipMemcpyHostToDevice, s));
+        m->top1_dev(m->d_q, embed_count, m->d_idx, m->d_sim, s);
+        HIPCHK(hipMemcpyAsync(idx_out, m->d_idx, sizeof(int32_t) * embed_count, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(sim_out, m->d_sim, sizeof(float) * embed_count, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_merge_top1(int n, const int32_t *idx_a, const float *sim_a, const int32_t *idx_b, const float *sim_b, int32_t *idx_out, float *sim_out) {
+    return guarded([&] {
+        if (n < 0 || !idx_a || !sim_a || !idx_b || !sim_b || !idx_out || !sim_out) raise(FRT_ERR_INVALID, "merge: bad argument");
+        for (int i = 0; i < n; ++i) {
+            const bool a_ok = idx_a[i] >= 0, b_ok = idx_b[i] >= 0;
+            bool take_b = false;
+            if (!a_ok)
+                take_b = b_ok;
+            else if (b_ok)
+                take_b = (sim_b[i] > sim_a[i]) || (sim_b[i] == sim_a[i] && idx_b[i] < idx_a[i]);
+            idx_out[i] = take_b ? idx_b[i] : idx_a[i];
+            sim_out[i] = take_b ? sim_b[i] : sim_a[i];
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------ pipeline
+int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int max_frames, frt_pipeline **out) {
+    return guarded([&] {
+        if (!d || !e || !out) raise(FRT_ERR_INVALID, "null argument");
+        *out = nullptr;
+        if (max_frames < 1 || max_frames > d->max_batch) raise(FRT_ERR_CAPACITY, "pipeline: max_frames exceeds det_maxBatchSize");
+        if (d->device != e->device || (m && m->device != d->device)) raise(FRT_ERR_INVALID, "pipeline: objects live on different devices");
+        use_device(d->device);
+        std::unique_ptr<frt_pipeline> p(new frt_pipeline);
+        p->det = d; p->emb = e; p->mat = m;
+        p->max_frames = max_frames;
+        p->max_faces = d->g.max_faces;
+        p->F_cap = max_frames * p->max_faces;
+        HIPCHK(hipStreamCreate(&p->stream));
+        const size_t F = (size_t)p->F_cap;
+        p->d_frames = p->arena.alloc<uint8_t>((size_t)max_frames * d->g.frame_h * d->g.frame_w * 3);
+        p->d_chw = p->arena.alloc<float>(F * 3 * 112 * 112);
+        p->d_embeds = p->arena.alloc<float>(F * 512);
+        p->d_sim = p->arena.alloc<float>(F);
+        p->d_idx = p->arena.alloc<int32_t>(F);
+        p->d_valid = p->arena.alloc<int>(F);
+        p->d_results = p->arena.alloc<frt_face_result>(F);
+        *out = p.release();
+    });
+}
+
+void frt_pipeline_destroy(frt_pipeline *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->det->device);
+    if (p->stream) {
+        (void)hipStreamSynchronize(p->stream);
+        (void)hipStreamDestroy(p->stream);
+    }
+    p->arena.release();
+    delete p;
+}
+
+static void pipeline_lock_run(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev) {
+    if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
+    std::lock_guard<std::mutex> l1(p->det->mu);
+    std::lock_guard<std::mutex> l2(p->emb->mu);
+    std::unique_lock<std::mutex> l3;
+    if (p->mat) {
+        l3 = std::unique_lock<std::mutex>(p->mat->mu);
+        if (p->mat->N > 0) p->mat->ensure_queries(p->F_cap);
+    }
+    p->run(reinterpret_cast<const uint8_t *>(frames_dev), n_frames, reinterpret_cast<frt_face_result *>(results_dev),
+           reinterpret_cast<float *>(embeds_dev));
+}
+
+int frt_pipeline_run_dev(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev) {
+    return guarded([&] {
+        if (!p || !frames_dev || !results_dev) raise(FRT_ERR_INVALID, "null argument");
+        use_device(p->det->device);
+        pipeline_lock_run(p, frames_dev, n_frames, results_dev, embeds_dev);
+    });
+}
+
+int frt_pipeline_sync(frt_pipeline *p) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        use_device(p->det->device);
+        HIPCHK(hipStreamSynchronize(p->stream));
+    });
+}
+
+int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out) {
+    return guarded([&] {
+        if (!p || !frames || !results) raise(FRT_ERR_INVALID, "null argument");
+        if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
+        use_device(p->det->device);
+        hipStream_t s = p->stream;
+        const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
+        HIPCHK(hipMemcpyAsync(p->d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, s));
+        pipeline_lock_run(p, p->d_frames, n_frames, p->d_results, p->d_embeds);
+        const int F = n_frames * p->max_faces;
+        HIPCHK(hipMemcpyAsync(results, p->d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
+        if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, p->d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+// ----------------------------------------------------------------------------------------------------------- profiling
+int frt_profile_enable(int kind) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_kind = kind;
+    for (ProfRec &r : g_prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return FRT_OK;
+}
+
+int frt_profile_collect(char *names_out, size_t names_cap, double *ms_out, double *work_out, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    std::string names;
+    for (ProfRec &r : g_prof) {
+        if (n < cap) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(r.b);
+            if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = -1.f;
+            if (ms_out) ms_out[n] = ms;
+            if (work_out) work_out[n] = r.work;
+            names += r.name;
+            names += '\n';
+            ++n;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    if (names_out && names_cap) {
+        const size_t k = std::min(names_cap - 1, names.size());
+        std::memcpy(names_out, names.data(), k);
+        names_out[k] = 0;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Internal declarations shared by the HIP translation units of libfrt.so (gfx950 only; no other targets, no shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/frt.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- match (kernels_match.hip)
+struct MatchPartial {  // one per (workgroup, query)
+    float sim;
+    int32_t idx;
+};
+// top-1: gallery [N][512] fp32, queries [F][512] fp32 -> idx[F], sim[F].  partial: scratch [grid][F].
+void launch_match_top1(const float *gallery, int N, int D, const float *queries, int F, MatchPartial *partial, int partial_blocks,
+                       int32_t *idx_out, float *sim_out, int row_offset, hipStream_t s);
+int match_top1_blocks(int N, int F);
+// full matrix: out[F][N]
+void launch_match_full(const float *gallery, int N, int D, const float *queries, int F, float *out, hipStream_t s);
+
+// ---------------------------------------------------------------- post-processing (kernels_post.hip)
+struct DetGeom {
+    int in_w, in_h, frame_w, frame_h;
+    int fw[3], fh[3];      // feature-map sizes per level (ceil(dim/step))
+    int base[3];           // first anchor index per level
+    int A;                 // anchors per frame
+    float scale_w, scale_h;
+    float nms_thr, bbox_thr;
+    int max_faces;
+};
+struct Candidate {
+    frt_bbox box;
+    int32_t anchor;
+};
+void launch_decode(const float *loc, const float *conf, int n_frames, const DetGeom &g, Candidate *cand, int *cand_count, hipStream_t s);
+void launch_nms(const Candidate *cand, const int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
+                hipStream_t s);
+
+// ---------------------------------------------------------------- image ops (kernels_image.hip)
+// u8 BGR frames [n][frame_h][frame_w][3] (row_stride / frame_stride in bytes) -> fp32 planar [n][3][in_h][in_w]
+void launch_det_preprocess(const uint8_t *frames, int n, int frame_h, int frame_w, size_t row_stride, size_t frame_stride, int in_h,
+                           int in_w, float *out, hipStream_t s);
+// per face slot f: box = boxes[f]; valid iff f%max_faces < n_boxes[f/max_faces] (n_boxes == nullptr: all valid) and ROI non-empty.
+// writes u8 BGR crops [F][oh][ow][3] (may be null), fp32 planar RGB normalised [F][3][oh][ow], valid flags [F].
+void launch_crop_faces(const uint8_t *frames, int frame_h, int frame_w, size_t row_stride, size_t frame_stride, const frt_bbox *boxes,
+                       const int *n_boxes, int max_faces, int F, int frames_shared, int oh, int ow, uint8_t *crops, float *chw, int *valid,
+                       hipStream_t s);
+void launch_face_normalize(const uint8_t *crops, int F, int oh, int ow, float *chw, hipStream_t s);
+
+// ---------------------------------------------------------------- detector network (kernels_det.hip), fp32 NCHW
+struct DwPwArgs {
+    const float *in; float *out;
+    const float *wd, *bd;   // depthwise [Cin][9], bias [Cin] (BN folded); null wd -> plain 1x1 conv
+    const float *wp, *bp;   // pointwise, TRANSPOSED [Cin][Cout], bias [Cout]
+    const float *add;       // optional tensor to add after ReLU, nearest-upsampled from [B][Cout][add_h][add_w]
+    int add_h, add_w;
+    int B, Cin, H, W, Cout, Ho, Wo, stride, relu;
+};
+void launch_dwpw(const DwPwArgs &a, hipStream_t s);
+struct Conv3Args {
+    const float *in; float *out;
+    const float *w, *b;     // [Cin][9][Cout] (transposed), bias [Cout]
+    int B, Cin, H, W, Cout, Ho, Wo, stride, relu;
+    int out_ctotal, out_coff;  // write into channels [coff, coff+Cout) of a [B][ctotal][Ho][Wo] tensor
+};
+void launch_conv3x3(const Conv3Args &a, hipStream_t s);
+struct HeadArgs {
+    const float *in;        // [B][64][H][W]
+    const float *wb, *bb;   // bbox head [64][8], [8]
+    const float *wc, *bc;   // class head [64][4], [4]
+    float *loc, *conf;      // [B][A][4], [B][A][2]
+    int B, C, H, W, A, base;
+};
+void launch_heads(const HeadArgs &a, hipStream_t s);
+
+// ---------------------------------------------------------------- recogniser network (kernels_arc.hip), fp16 NHWC + MFMA
+enum { EPI_PRELU = 0, EPI_BN = 1, EPI_BN_ADD_BN = 2, EPI_PARTIAL = 3 };
+struct ConvMfmaArgs {
+    const half_t *x;   // [B][H][W][Cin]
+    const half_t *w;   // [Cout][ks*ks*Cin]
+    int B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad;
+    int mode;
+    const float *p0, *p1, *p2, *p3;
+    const half_t *sc;  // shortcut tensor [B][sc_h][sc_w][Cout], sampled at (oh*sc_stride, ow*sc_stride)
+    int sc_h, sc_w, sc_stride;
+    half_t *out0, *out1;
+    float *outf;       // EPI_PARTIAL: [splits][M][Cout]
+    int splits;
+};
+void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
+struct ArcInputArgs {
+    const float *x;       // [F][3][112][112] planar RGB
+    const float *w;       // [27][64]  (k = ci*9 + kh*3 + kw)
+    const float *s0, *b0; // folded BN after the conv
+    const float *slope;   // PReLU
+    const float *s1, *b1; // next unit's leading BN
+    half_t *y, *z;        // [F][112][112][64]
+    int F, H, W;
+};
+void launch_arc_input(const ArcInputArgs &a, hipStream_t s);
+// partial [splits][F][512] -> +bias -> BN1d -> L2 normalise -> out [F][512] fp32; rows with valid[f]==0 become zeros.
+void launch_fc_finalize(const float *partial, int splits, int F, const float *bias, const float *s, const float *b, const int *valid,
+                        float *out, hipStream_t s_);
+// SE tail (IR-SE): pool -> fc1 -> relu -> fc2 -> sigmoid -> scale, + shortcut, + next BN
+struct SeArgs {
+    const half_t *res;   // [F][H][W][C] = BN2(conv2)
+    const float *w1;     // [C/16][C]
+    const float *w2;     // [C][C/16]
+    const half_t *sc; int sc_h, sc_w, sc_stride;
+    const float *s1, *b1;
+    half_t *y, *z;
+    float *pool;         // scratch [F][C]
+    float *gate;         // scratch [F][C]
+    int F, H, W, C;
+};
+void launch_se(const SeArgs &a, hipStream_t s);

@@ -1,0 +1,216 @@
+// Detector post-processing on the device: analytic anchors + decode + threshold + compaction, then greedy NMS.
+//
+// Replaces RetinaFace::postprocessing / create_anchor_retinaface / nms (/root/reference/src/retinaface.cpp:154-271), which
+// the reference runs on the host after a blocking D2H copy and which rebuilds all 16 800 anchors with push_back per frame.
+//
+// Exactness contract: box coordinates are ints obtained by truncating float expressions twice, so
+// the arithmetic below reproduces the reference's precision mix operation by operation: priors and decode in double
+// narrowed to float per field, corner / un-letterbox expressions in float with int operands promoted, IEEE division, no
+// FMA contraction (this translation unit is compiled with -ffp-contract=off).  Strict '>' score test, '>=' suppression,
+// '+1' areas, cap to max_faces AFTER the NMS.  std::sort is unstable on equal scores; here ties are defined as "lower
+// anchor index first" (same rule as oracle/postproc.c).
+//
+// Greedy NMS followed by "keep the first K survivors" is computed as K rounds of {arg-max over the live candidates,
+// suppress everything overlapping the winner}: identical output, no sort, O(K * n / 256) per frame.
+#include "frt_kernels.h"
+
+#include <limits.h>
+
+namespace {
+
+__constant__ int c_min_sizes[3][2] = {{10, 20}, {32, 64}, {128, 256}};
+__constant__ float c_steps[3] = {8.f, 16.f, 32.f};
+
+__device__ __forceinline__ int clipi(int v, int lo, int hi) {
+    const int t = v < hi ? v : hi;
+    return t > lo ? t : lo;
+}
+
+__global__ void decode_kernel(const float *__restrict__ loc, const float *__restrict__ conf, DetGeom g, Candidate *__restrict__ cand,
+                              int *__restrict__ cand_count) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (a >= g.A) return;
+    const float score = conf[((long)f * g.A + a) * 2 + 1];
+    if (!(score > g.bbox_thr)) return;
+
+    const int k = a >= g.base[2] ? 2 : (a >= g.base[1] ? 1 : 0);
+    const int rel = a - g.base[k];
+    const int l = rel & 1, cell = rel >> 1;
+    const int i = cell / g.fw[k], j = cell - i * g.fw[k];
+    const int w = g.in_w, h = g.in_h;
+    const float step = c_steps[k];
+    const int ms = c_min_sizes[k][l];
+    // priors: double arithmetic narrowed to float (retinaface.cpp:230-233)
+    const float asx = (float)(ms * 1.0 / w);
+    const float asy = (float)(ms * 1.0 / h);
+    const float acx = (float)((j + 0.5) * step / w);
+    const float acy = (float)((i + 0.5) * step / h);
+
+    const float *bb = loc + ((long)f * g.A + a) * 4;
+    const float l0 = bb[0], l1 = bb[1], l2 = bb[2], l3 = bb[3];
+    // decode (retinaface.cpp:166-169): double intermediates, float fields
+    const float cx = (float)(acx + l0 * 0.1 * asx);
+    const float cy = (float)(acy + l1 * 0.1 * asy);
+    const float sx = (float)(asx * exp(l2 * 0.2));
+    const float sy = (float)(asy * exp(l3 * 0.2));
+
+    frt_bbox r;
+    r.y1 = (int)((cx - sx / 2) * w);
+    r.x1 = (int)((cy - sy / 2) * h);
+    r.y2 = (int)((cx + sx / 2) * w);
+    r.x2 = (int)((cy + sy / 2) * h);
+    if (g.scale_h > g.scale_w) {
+        r.y1 = (int)(r.y1 / g.scale_w);
+        r.y2 = (int)(r.y2 / g.scale_w);
+        r.x1 = (int)((r.x1 - (h - g.scale_w * g.frame_h) / 2) / g.scale_w);
+        r.x2 = (int)((r.x2 - (h - g.scale_w * g.frame_h) / 2) / g.scale_w);
+    } else {
+        r.y1 = (int)((r.y1 - (w - g.scale_h * g.frame_w) / 2) / g.scale_h);
+        r.y2 = (int)((r.y2 - (w - g.scale_h * g.frame_w) / 2) / g.scale_h);
+        r.x1 = (int)(r.x1 / g.scale_h);
+        r.x2 = (int)(r.x2 / g.scale_h);
+    }
+    r.y1 = clipi(r.y1, 0, g.frame_w - 1);
+    r.x1 = clipi(r.x1, 0, g.frame_h - 1);
+    r.y2 = clipi(r.y2, 0, g.frame_w - 1);
+    r.x2 = clipi(r.x2, 0, g.frame_h - 1);
+    r.score = score;
+
+    const int pos = atomicAdd(&cand_count[f], 1);
+    Candidate c;
+    c.box = r;
+    c.anchor = a;
+    cand[(long)f * g.A + pos] = c;
+}
+
+__device__ __forceinline__ bool cand_better(float s, int a, float bs, int ba) { return (s > bs) || (s == bs && a < ba); }
+
+__global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ cand_all, const int *__restrict__ cand_count, DetGeom g,
+                                                  uint8_t *__restrict__ dead_all, frt_bbox *__restrict__ out, int *__restrict__ n_out) {
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const Candidate *cand = cand_all + (long)f * g.A;
+    uint8_t *dead = dead_all + (long)f * g.A;
+    const int n = cand_count[f];
+    __shared__ float s_score[4];
+    __shared__ int s_anchor[4];
+    __shared__ int s_pos[4];
+    __shared__ Candidate s_win;
+    __shared__ int s_has;
+
+    for (int i = tid; i < n; i += 256) dead[i] = 0;
+    __syncthreads();
+
+    int kept = 0;
+    for (; kept < g.max_faces; ++kept) {
+        float bs = -INFINITY;
+        int ba = INT_MAX, bp = -1;
+        for (int i = tid; i < n; i += 256) {
+            if (dead[i]) continue;
+            const float s = cand[i].box.score;
+            const int a = cand[i].anchor;
+            if (bp < 0 || cand_better(s, a, bs, ba)) {
+                bs = s;
+                ba = a;
+                bp = i;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off);
+            const int oa = __shfl_xor(ba, off);
+            const int op = __shfl_xor(bp, off);
+            if (op >= 0 && (bp < 0 || cand_better(os, oa, bs, ba))) {
+                bs = os;
+                ba = oa;
+                bp = op;
+            }
+        }
+        if ((tid & 63) == 0) {
+            s_score[tid >> 6] = bs;
+            s_anchor[tid >> 6] = ba;
+            s_pos[tid >> 6] = bp;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float ws = s_score[0];
+            int wa = s_anchor[0], wp = s_pos[0];
+            for (int w = 1; w < 4; ++w)
+                if (s_pos[w] >= 0 && (wp < 0 || cand_better(s_score[w], s_anchor[w], ws, wa))) {
+                    ws = s_score[w];
+                    wa = s_anchor[w];
+                    wp = s_pos[w];
+                }
+            s_has = wp >= 0;
+            if (wp >= 0) {
+                s_win = cand[wp];
+                dead[wp] = 1;
+                out[(long)f * g.max_faces + kept] = cand[wp].box;
+            }
+        }
+        __syncthreads();
+        if (!s_has) break;
+        const frt_bbox wb = s_win.box;
+        const float warea = (float)((wb.x2 - wb.x1 + 1) * (wb.y2 - wb.y1 + 1));
+        for (int i = tid; i < n; i += 256) {
+            if (dead[i]) continue;
+            const frt_bbox b = cand[i].box;
+            const float area = (float)((b.x2 - b.x1 + 1) * (b.y2 - b.y1 + 1));
+            const float xx1 = (float)(wb.x1 > b.x1 ? wb.x1 : b.x1);
+            const float yy1 = (float)(wb.y1 > b.y1 ? wb.y1 : b.y1);
+            const float xx2 = (float)(wb.x2 < b.x2 ? wb.x2 : b.x2);
+            const float yy2 = (float)(wb.y2 < b.y2 ? wb.y2 : b.y2);
+            float w = xx2 - xx1 + 1;
+            float h = yy2 - yy1 + 1;
+            if (w < 0.f) w = 0.f;
+            if (h < 0.f) h = 0.f;
+            const float inter = w * h;
+            const float ovr = inter / (warea + area - inter);
+            if (ovr >= g.nms_thr) dead[i] = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) n_out[f] = kept;
+    // zero the unused slots so the results buffer is deterministic
+    for (int i = kept + tid; i < g.max_faces; i += 256) {
+        frt_bbox z;
+        z.x1 = z.y1 = z.x2 = z.y2 = 0;
+        z.score = 0.f;
+        out[(long)f * g.max_faces + i] = z;
+    }
+}
+
+}  // namespace
+
+void launch_decode(const float *loc, const float *conf, int n_frames, const DetGeom &g, Candidate *cand, int *cand_count, hipStream_t s) {
+    (void)hipMemsetAsync(cand_count, 0, sizeof(int) * n_frames, s);
+    dim3 grid((g.A + 255) / 256, n_frames);
+    hipLaunchKernelGGL(decode_kernel, grid, dim3(256), 0, s, loc, conf, g, cand, cand_count);
+}
+
+void launch_nms(const Candidate *cand, const int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
+                hipStream_t s) {
+    hipLaunchKernelGGL(nms_kernel, dim3(n_frames), dim3(256), 0, s, cand, cand_count, g, dead, out, n_out);
+}
+
+// ---------------------------------------------------------------- per-face result records of the batched pipeline
+namespace {
+__global__ void pack_results_kernel(const frt_bbox *__restrict__ boxes, const int *__restrict__ n_boxes, const int *__restrict__ valid,
+                                    const int32_t *__restrict__ idx, const float *__restrict__ sim, int max_faces, int F,
+                                    frt_face_result *__restrict__ out) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    frt_face_result r;
+    r.box = boxes[f];
+    r.frame = f / max_faces;
+    const bool ok = (f % max_faces) < n_boxes[r.frame] && valid[f] != 0;
+    r.valid = ok ? 1 : 0;
+    r.match_idx = (ok && idx) ? idx[f] : -1;
+    r.match_sim = (ok && sim) ? sim[f] : 0.f;
+    out[f] = r;
+}
+}  // namespace
+
+void launch_pack_results(const frt_bbox *boxes, const int *n_boxes, const int *valid, const int32_t *idx, const float *sim, int max_faces,
+                         int F, frt_face_result *out, hipStream_t s) {
+    hipLaunchKernelGGL(pack_results_kernel, dim3((F + 255) / 256), dim3(256), 0, s, boxes, n_boxes, valid, idx, sim, max_faces, F, out);
+}

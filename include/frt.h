@@ -1,0 +1,167 @@
+/*
+ * libfrt - MI355X-native (gfx950) detect -> crop -> embed -> match hot path; thin C ABI.
+ *
+ * This header is the drop-in boundary.  The reference has no C ABI: its boundary is three C++ classes
+ * (RetinaFace / ArcFaceIR50 / MatMul) that sit directly on TensorRT + cuBLASLt + the CUDA runtime.  Every entry point
+ * below names the reference member function (file:line under /root/reference) it replaces; the header-only C++ shells
+ * in include/frt/{common,retinaface,arcface,matmul}.h rebuild the reference class surfaces on top of these calls.
+ *
+ * Conventions: plain pointers and sizes only; opaque handles; every function returns an frt_status (0 = ok) and
+ * leaves a message retrievable with frt_last_error() (thread-local).  Host pointers unless the name ends in "_dev".
+ * Objects serialise their own device work with a per-object mutex (the reference objects are not thread-safe although
+ * the Crow server is multithreaded, src/app.cpp:367); distinct objects may be used concurrently.
+ *
+ * Axis naming follows the reference: Bbox.x* are ROWS, Bbox.y* are COLUMNS (src/retinaface.cpp:165).
+ */
+#ifndef FRT_H
+#define FRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum frt_status {
+    FRT_OK = 0,
+    FRT_ERR_INVALID = 1,     /* bad argument / shape                                   (reference: assert)            */
+    FRT_ERR_NOT_FOUND = 2,   /* weight blob missing   (reference: throw std::logic_error("Cant find engine file"))   */
+    FRT_ERR_FORMAT = 3,      /* weight blob malformed / wrong network kind                                           */
+    FRT_ERR_DEVICE = 4,      /* HIP runtime failure   (reference: checkCudaStatus -> std::logic_error, common.cpp:43) */
+    FRT_ERR_EMPTY = 5,       /* no faces / empty gallery (reference: throw const char*, src/arcface.cpp:198)          */
+    FRT_ERR_EMPTY_ROI = 6,   /* zero-area crop rectangle (reference: cv::Exception from Mat::operator())             */
+    FRT_ERR_CAPACITY = 7     /* more frames / faces than the object was created for                                  */
+} frt_status;
+
+/* Layout-identical to the reference's `struct Bbox` (src/common.h:13-16): 4 x int32 + float32 = 20 bytes. */
+typedef struct frt_bbox {
+    int32_t x1, y1, x2, y2; /* x = row, y = column */
+    float score;
+} frt_bbox;
+
+typedef struct frt_detector frt_detector;
+typedef struct frt_embedder frt_embedder;
+typedef struct frt_matcher frt_matcher;
+typedef struct frt_pipeline frt_pipeline;
+
+const char *frt_last_error(void);
+const char *frt_version(void);
+/* Number of visible HIP devices (0 when none). */
+int frt_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Detector  ==  class RetinaFace (src/retinaface.h:18-23)
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* RetinaFace::RetinaFace (src/retinaface.cpp:3-29) + loadEngine (:31-55) + preInference (:81-104).
+ * weights_path: FRTW blob (kind 1) instead of a TensorRT engine.  in_c must be 3.  max_batch = frames per call. */
+int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int in_c, int in_h, int in_w, int max_batch,
+                        int max_faces, float nms_threshold, float bbox_threshold, int device, frt_detector **out);
+/* RetinaFace::~RetinaFace (src/retinaface.cpp:273-280) */
+void frt_detector_destroy(frt_detector *d);
+/* m_OUTPUT_SIZE_BASE (src/retinaface.cpp:13): anchors per frame */
+int frt_detector_num_anchors(const frt_detector *d);
+
+/* RetinaFace::findFace (src/retinaface.cpp:147-152).  bgr: u8 HWC frame of exactly frame_h x frame_w, row_stride bytes
+ * per row.  out: capacity max_faces.  n_out: number of boxes written (score-descending, after NMS and cap). */
+int frt_detector_find_faces(frt_detector *d, const uint8_t *bgr, int rows, int cols, size_t row_stride, frt_bbox *out, int *n_out);
+/* New surface: n_frames <= max_batch contiguous frames; out[n_frames * max_faces], n_out[n_frames]. */
+int frt_detector_find_faces_batch(frt_detector *d, const uint8_t *bgr, int n_frames, int rows, int cols, size_t row_stride,
+                                  size_t frame_stride, frt_bbox *out, int *n_out);
+
+/* RetinaFace::preprocess (src/retinaface.cpp:106-136): frame -> float32 planar [3][in_h][in_w] on the host. */
+int frt_detector_preprocess(frt_detector *d, const uint8_t *bgr, int rows, int cols, size_t row_stride, float *chw_out);
+/* RetinaFace::doInference (src/retinaface.cpp:138-145): bindings input_det -> output_det0 [batch][A][4],
+ * output_det1 [batch][A][2] (softmaxed), conversion/retina/torch2trt.py:95-96. */
+int frt_detector_infer(frt_detector *d, const float *chw, int batch, float *loc_out, float *conf_out);
+/* RetinaFace::postprocessing (src/retinaface.cpp:154-208) for one frame of raw head outputs. */
+int frt_detector_postprocess(frt_detector *d, const float *loc, const float *conf, frt_bbox *out, int *n_out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Crop  ==  free function getCroppedFaces (src/arcface.h:17, src/arcface.cpp:3-17)
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* crops_out: u8 BGR [n][out_h][out_w][3].  device < 0 -> current device.  Returns FRT_ERR_EMPTY_ROI if any box has
+ * a zero-area or out-of-frame rectangle (nothing is written for that face; the others are still produced). */
+int frt_crop_faces(const uint8_t *bgr, int rows, int cols, size_t row_stride, const frt_bbox *boxes, int n, int out_w, int out_h,
+                   uint8_t *crops_out, int device);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Embedder  ==  class ArcFaceIR50 minus the gallery (src/arcface.h:19-39)
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* ArcFaceIR50::ArcFaceIR50 (src/arcface.cpp:21-43) + loadEngine (:45-69) + preInference (:88-103).
+ * weights_path: FRTW blob kind 2 (IR-50, the reference's network) or kind 3 (IR-SE-50).  in_c,in_h,in_w must be
+ * 3,112,112 and out_dim 512.  max_batch = faces per device launch (the reference default is 1, app/config.json:18). */
+int frt_embedder_create(const char *weights_path, int in_c, int in_h, int in_w, int out_dim, int max_batch, int device,
+                        frt_embedder **out);
+void frt_embedder_destroy(frt_embedder *e);
+
+/* ArcFaceIR50::preprocessFace (src/arcface.cpp:105-114): u8 BGR [in_h][in_w][3] -> float32 planar RGB. */
+int frt_embedder_preprocess_face(frt_embedder *e, const uint8_t *bgr_crop, float *chw_out);
+/* ArcFaceIR50::doInference, both overloads (src/arcface.cpp:131-148): float32 [batch][3][112][112] -> [batch][512]
+ * L2-normalised.  batch may exceed max_batch (processed in chunks). */
+int frt_embedder_infer(frt_embedder *e, const float *chw, int batch, float *embeds_out);
+/* ArcFaceIR50::forward (src/arcface.cpp:166-187) with the evident intent of the batched branch:
+ * getCroppedFaces + preprocessFaces + inference.  embeds_out [n][512]; crops_out (may be NULL) u8 BGR [n][112][112][3]
+ * (= CroppedFace.face, src/app.cpp:329). */
+int frt_embedder_forward(frt_embedder *e, const uint8_t *bgr, int rows, int cols, size_t row_stride, const frt_bbox *boxes, int n,
+                         float *embeds_out, uint8_t *crops_out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Matcher  ==  class MatMul (src/matmul.h:6-21) + ArcFaceIR50::getOutputs argmax (src/arcface.cpp:203-217)
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* MatMul::MatMul (src/matmul.cpp:3-7) */
+int frt_matcher_create(int device, frt_matcher **out);
+/* MatMul::~MatMul (src/matmul.cpp:79-91) */
+void frt_matcher_destroy(frt_matcher *m);
+/* MatMul::init (src/matmul.cpp:9-34): gallery A[num_row][num_col] row-major fp32, copied to the device.  Idempotent:
+ * a second call frees the previous device copy (the reference leaks it on every /reload). */
+int frt_matcher_init(frt_matcher *m, const float *gallery, int num_row, int num_col);
+/* MatMul::calculate (src/matmul.cpp:36-77): outputs[i*num_row + j] = sum_k embeds[i][k] * gallery[j][k], fp32. */
+int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, float *outputs);
+/* Fused calculate + getOutputs argmax: idx_out[i] = FIRST j maximising the similarity (std::max_element semantics),
+ * sim_out[i] = that similarity.  Never materialises the [n x num_row] matrix. */
+int frt_matcher_top1(frt_matcher *m, const float *embeds, int embed_count, int32_t *idx_out, float *sim_out);
+/* Sharded-gallery variant: rows of this matcher are global rows [row_offset, row_offset+num_row).
+ * Merges with an existing (idx, sim) pair per query, keeping the higher similarity and the LOWER global index on ties. */
+int frt_merge_top1(int n, const int32_t *idx_a, const float *sim_a, const int32_t *idx_b, const float *sim_b, int32_t *idx_out,
+                   float *sim_out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Batched device-resident pipeline (new surface; the /inference call stack of src/app.cpp:304-310 for B frames at once,
+ * without host round trips between the stages).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct frt_face_result {
+    frt_bbox box;
+    int32_t frame;     /* frame index inside the batch                          */
+    int32_t match_idx; /* gallery row of the best match (-1: no gallery)        */
+    float match_sim;   /* its cosine similarity                                 */
+    int32_t valid;     /* 0: slot unused (fewer than max_faces boxes) or empty ROI */
+} frt_face_result;
+
+/* Borrows the three objects (they must outlive the pipeline and live on the same device).  max_frames <= detector
+ * max_batch.  Face slots are [frame][max_faces]. */
+int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int max_frames, frt_pipeline **out);
+void frt_pipeline_destroy(frt_pipeline *p);
+/* frames: host u8 BGR, n_frames contiguous frames.  results[n_frames*max_faces]; embeds_out (may be NULL)
+ * [n_frames*max_faces][512]. */
+int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out);
+/* Same with everything resident in HBM: frames_dev u8 [n_frames][rows][cols][3]; results_dev / embeds_dev device
+ * buffers (embeds_dev may be NULL).  Asynchronous on the pipeline stream; frt_pipeline_sync() waits. */
+int frt_pipeline_run_dev(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev);
+int frt_pipeline_sync(frt_pipeline *p);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Profiling hooks (HIP events on the library's own stream; used by bench.py for the roofline object).
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* kinds: 0 = off, 1 = time every launch of the dominant kernel family (conv3x3 MFMA), 2 = time every stage. */
+int frt_profile_enable(int kind);
+/* Drains recorded events.  names_out: '\n'-separated labels; returns the number of records written (<= cap). */
+int frt_profile_collect(char *names_out, size_t names_cap, double *ms_out, double *work_out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRT_H */
