@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: faces/sec end-to-end (detect + crop + embed + match), 640x640, batch = 32 frames, 1M x 512 gallery.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the whole hot path over one batch of 32 synthetic 640x640 frames that are already resident in
+HBM: letterbox/normalise -> RetinaFace-mnet0.25 -> decode + NMS (K = 4 faces per frame) -> bicubic crop -> ArcFace IR-50
+(fp16 MFMA convs, fp32 accumulate) -> cosine top-1 against a 1M x 512 fp32 gallery (fp32 MFMA).  Nothing is cached
+between steps and no stage is skipped.  With N > 1 every rank (one process per GPU) owns a full gallery replica and its
+own 32 frames (weak scaling); after each step the per-face results are all-gathered with RCCL so every rank holds the
+whole batch's answer - the only collective on the path.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel family = the ArcFace 3x3 implicit-GEMM convs (conv_mfma_kernel); achieved = algorithmic
+                FLOPs of those launches / their HIP-event time, measured live on the pipeline's stream during the timed
+                steps; peak = 2.5 PFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle (reference-faithful CPU restatement, oracle/) timed on this box's host cores over a bounded
+                sample of the same workload, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense; /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def cpu_baseline(frt, det_sd, rec_sd, gallery, frames, K, budget_s=20.0):
+    """Reference-faithful CPU pipeline (oracle) on a bounded sample: frames are processed one at a time, like the reference."""
+    import torch
+
+    import oracle
+    from oracle import match, nets
+    H, W = frames.shape[1:3]
+    faces = 0
+    t0 = time.perf_counter()
+    n = 0
+    for fr in frames:
+        x = oracle.det_preprocess(fr, H, W)
+        loc, conf = nets.retinaface_forward(det_sd, x[None])
+        boxes = oracle.postprocess(loc[0], conf[0], W, H, W, H, 0.4, 0.6, K)
+        crops = oracle.crop_faces(fr, boxes)
+        emb = nets.arcface_forward(rec_sd, oracle.face_normalize(crops))
+        match.top1(emb, gallery)
+        faces += len(boxes)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(faces / dt, 3), "unit": "faces/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d frame(s) of the same 640x640 workload, %d faces, full CPU pipeline (oracle nets fp32 on torch-CPU, "
+                      "C post-processing/crop, NumPy %dx512 match), %.1f s" % (n, faces, gallery.shape[0], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--faces", type=int, default=4, help="det_maxFacesPerScene (K)")
+    ap.add_argument("--gallery", type=int, default=1_000_000)
+    ap.add_argument("--mode", default="ir", choices=["ir", "ir_se"], help="IR-50 (the reference's network) or IR-SE-50")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as entry
+    frt = entry.load_pkg()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if frt.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (libfrt has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    s = frt.synth
+    B, K, H, W = args.batch, args.faces, 640, 640
+    tmp = tempfile.mkdtemp(prefix="frt_bench_%d_" % rank)
+    det_sd = s.retinaface_state(1)
+    rec_sd = s.arcface_state(2, args.mode, calib=s.load_calibration(args.mode))
+    det_path = frt.write_weights(os.path.join(tmp, "det.frtw"), det_sd, 1)
+    rec_path = frt.write_weights(os.path.join(tmp, "rec.frtw"), rec_sd, 2 if args.mode == "ir" else 3)
+    det = frt.RetinaFace(det_path, W, H, (3, H, W), B, K, 0.4, 0.6, device=local_rank)
+    rec = frt.ArcFaceIR50(rec_path, W, H, (3, 112, 112), 512, B * K, K, 0.65, device=local_rank)
+    gallery = s.make_gallery(args.gallery)
+    rec.setGallery(gallery)  # bulk initKnownEmbeds + addEmbedding x N (2 GB: no per-row copies)
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+
+    frames = s.make_frames(B, H, W, start=rank * B)  # weak scaling: every rank has its own 32 frames
+    d_frames = torch.from_numpy(frames).cuda()
+    F = B * K
+    d_res = torch.zeros(F * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    d_all = torch.zeros(world * F * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream()
+    pipe.set_stream(stream.cuda_stream)
+
+    def step():
+        pipe.run_dev(d_frames.data_ptr(), B, d_res.data_ptr(), None)
+        if world > 1:  # every rank ends up with the whole batch's answer; ordered after the pipeline on the same stream
+            dist.all_gather_into_tensor(d_all, d_res)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), frt.RESULT_DTYPE)
+    faces_per_step = int(res["valid"].sum())
+
+    profile = not args.no_profile
+    if profile:
+        frt.profile_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        nf = torch.tensor([faces_per_step], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nf, op=dist.ReduceOp.SUM)
+        total_faces_per_step = int(nf.item())
+    else:
+        total_faces_per_step = faces_per_step
+
+    roofline = None
+    if profile:
+        labels, ms, work = frt.profile_collect()
+        frt.profile_enable(0)
+        sel = [i for i, l in enumerate(labels) if l == "conv3x3_mfma" and ms[i] > 0]
+        if sel:
+            tot_ms, tot_flop = float(ms[sel].sum()), float(work[sel].sum())
+            ach = tot_flop / (tot_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP16_MFMA_TFLOPS, 4), "traffic": None,
+                        "kernel": "conv_mfma_kernel (ArcFace 3x3 implicit GEMM, fp16 in / fp32 acc)",
+                        "launches": len(sel), "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
+                        "flop_per_launch_avg": round(tot_flop / len(sel), 1), "share_of_step_time": round(tot_ms / (1e3 * dt), 4)}
+
+    if rank == 0:
+        out = {
+            "metric": "faces/sec end-to-end (detect+embed+match), 640x640 batch=32, 1M gallery",
+            "value": round(total_faces_per_step * args.steps / dt, 2),
+            "unit": "faces/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16 MFMA convs (fp32 accumulate) + f32 detector + f32 MFMA match",
+            "data": "synthetic",
+            "config": {"workload": "640x640 batch=%d frames/GPU, K=%d faces/frame, %dx512 fp32 gallery replicated per GPU, "
+                                   "RetinaFace-mnet0.25 + ArcFace %s" % (B, K, args.gallery, "IR-50" if args.mode == "ir" else "IR-SE-50"),
+                       "frames_per_step_per_gpu": B, "faces_per_frame": K, "faces_per_step": total_faces_per_step,
+                       "gallery_rows": args.gallery, "parallelism": "frames sharded dp%d, RCCL all-gather of results" % world},
+            "roofline": roofline,
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frt, det_sd, rec_sd, gallery, frames, K)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,7 @@ ABI = {
     "frt_pipeline_run": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_pipeline_run_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_pipeline_sync": (_i, [_vp]),
+    "frt_pipeline_set_stream": (_i, [_vp, _vp]),
     "frt_profile_enable": (_i, [_i]),
     "frt_profile_collect": (_i, [_vp, _sz, _vp, _vp, _i]),
 }
@@ -278,6 +279,12 @@ class ArcFaceIR50:
         self.classNames.extend(classNames)
         self.classCount += len(e)
 
+    def setGallery(self, embeddings, classNames=None):
+        """initKnownEmbeds + N x addEmbedding without per-row copies; ``classNames`` defaults to the row indices."""
+        self._known = np.ascontiguousarray(embeddings, np.float32)
+        self.classCount = len(self._known)
+        self.classNames = classNames if classNames is not None else range(self.classCount)
+
     def resetEmbeddings(self):
         self.classCount = 0
         self.classNames = []
@@ -299,7 +306,7 @@ class ArcFaceIR50:
         return embeds
 
     def featureMatching(self):
-        if not self.classNames or not self.croppedFaces:
+        if not len(self.classNames) or not self.croppedFaces:
             raise FrtError(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found")  # arcface.cpp:198
         return self.matmul.calculate(self._embeds, len(self.croppedFaces))
 
@@ -310,7 +317,7 @@ class ArcFaceIR50:
 
     def matchTop1(self):
         """Fused featureMatching + getOutputs on the device (never materialises the F x N matrix)."""
-        if not self.classNames or not self.croppedFaces:
+        if not len(self.classNames) or not self.croppedFaces:
             raise FrtError(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found")
         idx, sim = self.matmul.top1(self._embeds)
         return [self.classNames[a] for a in idx], [float(s) for s in sim]
@@ -353,6 +360,10 @@ class Pipeline:
 
     def sync(self):
         _check(lib.frt_pipeline_sync(self._h))
+
+    def set_stream(self, hip_stream):
+        """``hip_stream``: raw hipStream_t value (e.g. ``torch.cuda.current_stream().cuda_stream``) or None."""
+        _check(lib.frt_pipeline_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
 
     def close(self):
         if self._h:

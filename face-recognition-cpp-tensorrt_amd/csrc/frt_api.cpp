@@ -579,7 +579,7 @@ struct frt_pipeline {
     frt_embedder *emb;
     frt_matcher *mat;
     int max_frames, max_faces, F_cap;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, own_stream = nullptr;
     Arena arena;
     uint8_t *d_frames;
     float *d_chw, *d_embeds, *d_sim;
@@ -1013,7 +1013,8 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         p->max_frames = max_frames;
         p->max_faces = d->g.max_faces;
         p->F_cap = max_frames * p->max_faces;
-        HIPCHK(hipStreamCreate(&p->stream));
+        HIPCHK(hipStreamCreate(&p->own_stream));
+        p->stream = p->own_stream;
         const size_t F = (size_t)p->F_cap;
         p->d_frames = p->arena.alloc<uint8_t>((size_t)max_frames * d->g.frame_h * d->g.frame_w * 3);
         p->d_chw = p->arena.alloc<float>(F * 3 * 112 * 112);
@@ -1029,10 +1030,8 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
 void frt_pipeline_destroy(frt_pipeline *p) {
     if (!p) return;
     (void)hipSetDevice(p->det->device);
-    if (p->stream) {
-        (void)hipStreamSynchronize(p->stream);
-        (void)hipStreamDestroy(p->stream);
-    }
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     p->arena.release();
     delete p;
 }
@@ -1063,6 +1062,15 @@ int frt_pipeline_sync(frt_pipeline *p) {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->stream));
+    });
+}
+
+int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        use_device(p->det->device);
+        HIPCHK(hipStreamSynchronize(p->stream));
+        p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : p->own_stream;
     });
 }
 

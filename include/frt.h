@@ -152,6 +152,9 @@ int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_f
  * buffers (embeds_dev may be NULL).  Asynchronous on the pipeline stream; frt_pipeline_sync() waits. */
 int frt_pipeline_run_dev(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev);
 int frt_pipeline_sync(frt_pipeline *p);
+/* Run on a caller-owned HIP stream (a hipStream_t passed as void*, e.g. PyTorch's current stream, so that RCCL collectives
+ * issued by the caller are ordered after the pipeline without a host synchronisation).  NULL restores the private stream. */
+int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Profiling hooks (HIP events on the library's own stream; used by bench.py for the roofline object).

@@ -1,0 +1,181 @@
+// Drop-in for /root/reference/src/arcface.h: getCroppedFaces, struct CroppedFace and class ArcFaceIR50 with the reference's
+// public surface (src/arcface.h:11-39).  Differences, all deliberate:
+//   * featureMatching() returns an object-owned, reused buffer (the reference leaks new float[F*N] per call, arcface.cpp:194);
+//   * forward() with rec_maxBatchSize >= 2 implements the evident intent (the reference's batched branch overflows m_embed);
+//   * initKnownEmbeds() frees the previous gallery (the reference leaks it on every /reload);
+//   * crop + resize + normalise run in one HIP kernel; CroppedFace.face still holds the u8 BGR 112x112 crop (app.cpp:329)
+//     and CroppedFace.faceMat the fp32 planar RGB tensor, like after the reference's preprocessFaces().
+#ifndef FRT_ARCFACE_H
+#define FRT_ARCFACE_H
+
+#include <algorithm>
+#include <cassert>
+#include <tuple>
+
+#include "common.h"
+#include "cvlite.h"
+#include "matmul.h"
+
+struct CroppedFace {
+    cv::Mat face;     // u8 BGR crop
+    cv::Mat faceMat;  // getCroppedFaces: same u8 crop; after ArcFaceIR50::forward: CV_32FC1 [3*112 x 112] planar RGB
+    int x1, y1, x2, y2;
+};
+
+// src/arcface.cpp:3-17 (ROI = cols [y1,y2) x rows [x1,x2); INTER_CUBIC to resize_w x resize_h)
+inline void getCroppedFaces(cv::Mat frame, std::vector<struct Bbox> &outputBbox, int resize_w, int resize_h, std::vector<struct CroppedFace> &croppedFaces) {
+    croppedFaces.clear();
+    const int n = (int)outputBbox.size();
+    if (!n) return;
+    std::vector<unsigned char> crops((size_t)n * resize_h * resize_w * 3);
+    checkFrtStatus(frt_crop_faces(frame.data, frame.rows, frame.cols, (size_t)frame.step, reinterpret_cast<const frt_bbox *>(outputBbox.data()), n,
+                                  resize_w, resize_h, crops.data(), -1));
+    for (int i = 0; i < n; ++i) {
+        CroppedFace c;
+        c.faceMat = cv::Mat(resize_h, resize_w, CV_8UC3, &crops[(size_t)i * resize_h * resize_w * 3]).clone();
+        c.face = c.faceMat.clone();
+        c.x1 = outputBbox[i].x1;
+        c.y1 = outputBbox[i].y1;
+        c.x2 = outputBbox[i].x2;
+        c.y2 = outputBbox[i].y2;
+        croppedFaces.push_back(c);
+    }
+}
+
+class ArcFaceIR50 {
+  public:
+    ArcFaceIR50(TRTLogger gLogger, const std::string engineFile, int frameWidth, int frameHeight, std::string inputName, std::string outputName,
+                std::vector<int> inputShape, int outputDim, int maxBatchSize, int maxFacesPerScene, float knownPersonThreshold, int device = 0)
+        : h_(nullptr), m_frameWidth(frameWidth), m_frameHeight(frameHeight), m_OUTPUT_D(outputDim), m_maxBatchSize(maxBatchSize),
+          m_maxFacesPerScene(maxFacesPerScene), m_knownPersonThresh(knownPersonThreshold), matmul(device) {
+        (void)gLogger;
+        (void)inputName;
+        (void)outputName;
+        assert(inputShape.size() == 3);  // src/arcface.cpp:25
+        m_INPUT_C = inputShape[0];
+        m_INPUT_H = inputShape[1];
+        m_INPUT_W = inputShape[2];
+        checkFrtStatus(frt_embedder_create(engineFile.c_str(), m_INPUT_C, m_INPUT_H, m_INPUT_W, outputDim, maxBatchSize, device, &h_));
+        std::cout << "[INFO] Loading ArcFace Engine...\n";
+        croppedFaces.reserve((size_t)maxFacesPerScene);
+    }
+    ~ArcFaceIR50() { frt_embedder_destroy(h_); }
+    ArcFaceIR50(const ArcFaceIR50 &) = delete;
+    ArcFaceIR50 &operator=(const ArcFaceIR50 &) = delete;
+
+    // src/arcface.cpp:105-114: BGR->RGB, (x-127.5)*0.0078125, planar; output becomes CV_32FC1 [3*H x W]
+    void preprocessFace(cv::Mat &face, cv::Mat &output) {
+        cv::Mat tight = face.isContinuous() ? face : face.clone();
+        output = cv::Mat(3 * m_INPUT_H, m_INPUT_W, CV_32FC1);
+        checkFrtStatus(frt_embedder_preprocess_face(h_, tight.data, output.ptr<float>(0)));
+    }
+    void doInference(float *input, float *output) { checkFrtStatus(frt_embedder_infer(h_, input, 1, output)); }                          // arcface.cpp:131-137
+    void doInference(float *input, float *output, int batchSize) { checkFrtStatus(frt_embedder_infer(h_, input, batchSize, output)); }  // arcface.cpp:139-148
+
+    void addEmbedding(const std::string className, float embedding[]) {  // arcface.cpp:150-154 (copies immediately: db.cpp:339 passes a blob pointer)
+        classNames.push_back(className);
+        std::copy(embedding, embedding + m_OUTPUT_D, m_knownEmbeds.begin() + (size_t)classCount * m_OUTPUT_D);
+        classCount++;
+    }
+    void addEmbedding(const std::string className, std::vector<float> embedding) {  // arcface.cpp:156-160
+        classNames.push_back(className);
+        std::copy(embedding.begin(), embedding.end(), m_knownEmbeds.begin() + (size_t)classCount * m_OUTPUT_D);
+        classCount++;
+    }
+    void initKnownEmbeds(int num) { m_knownEmbeds.assign((size_t)num * m_OUTPUT_D, 0.f); }  // arcface.cpp:162
+    void initMatMul() { matmul.init(m_knownEmbeds.data(), classCount, m_OUTPUT_D); }       // arcface.cpp:164
+    void resetEmbeddings() {                                                                // arcface.cpp:233-236
+        classCount = 0;
+        classNames.clear();
+    }
+
+    // src/arcface.cpp:166-187
+    void forward(cv::Mat image, std::vector<struct Bbox> outputBbox) {
+        const int n = (int)outputBbox.size();
+        croppedFaces.clear();
+        m_embeds.assign((size_t)std::max(n, 1) * m_OUTPUT_D, 0.f);
+        if (!n) return;
+        std::vector<unsigned char> crops((size_t)n * m_INPUT_H * m_INPUT_W * 3);
+        checkFrtStatus(frt_embedder_forward(h_, image.data, image.rows, image.cols, (size_t)image.step, reinterpret_cast<const frt_bbox *>(outputBbox.data()), n,
+                                            m_embeds.data(), crops.data()));
+        for (int i = 0; i < n; ++i) {
+            CroppedFace c;
+            c.face = cv::Mat(m_INPUT_H, m_INPUT_W, CV_8UC3, &crops[(size_t)i * m_INPUT_H * m_INPUT_W * 3]).clone();
+            preprocessFace(c.face, c.faceMat);
+            c.x1 = outputBbox[i].x1;
+            c.y1 = outputBbox[i].y1;
+            c.x2 = outputBbox[i].x2;
+            c.y2 = outputBbox[i].y2;
+            croppedFaces.push_back(c);
+        }
+    }
+    // src/arcface.cpp:189-201.  Throws a const char* exactly like the reference (handlers catch const char*, app.cpp:276,341).
+    float *featureMatching() {
+        if (classNames.size() > 0 && croppedFaces.size() > 0) {
+            m_outputs.resize(croppedFaces.size() * (size_t)classCount);
+            matmul.calculate(m_embeds.data(), (int)croppedFaces.size(), m_outputs.data());
+        } else {
+            throw "Feature matching: No faces in database or no faces found";
+        }
+        return m_outputs.data();
+    }
+    // src/arcface.cpp:203-217: first maximum per row (std::max_element), no threshold here
+    std::tuple<std::vector<std::string>, std::vector<float>> getOutputs(float *output_sims) {
+        std::vector<std::string> names;
+        std::vector<float> sims;
+        for (size_t i = 0; i < croppedFaces.size(); ++i) {
+            const float *row = output_sims + i * (size_t)classCount;
+            const int argmax = (int)std::distance(row, std::max_element(row, row + classCount));
+            names.push_back(classNames[(size_t)argmax]);
+            sims.push_back(row[argmax]);
+        }
+        return std::make_tuple(names, sims);
+    }
+    // Extension: featureMatching + getOutputs fused on the device (no F x N matrix, no host scan).
+    std::tuple<std::vector<std::string>, std::vector<float>> matchTop1() {
+        if (classNames.empty() || croppedFaces.empty()) throw "Feature matching: No faces in database or no faces found";
+        const int n = (int)croppedFaces.size();
+        std::vector<int> idx((size_t)n);
+        std::vector<float> sims((size_t)n);
+        matmul.top1(m_embeds.data(), n, idx.data(), sims.data());
+        std::vector<std::string> names;
+        for (int i = 0; i < n; ++i) names.push_back(classNames[(size_t)idx[(size_t)i]]);
+        return std::make_tuple(names, sims);
+    }
+    // src/arcface.cpp:219-231: drawing only, not on the hot path (not even called by app.cpp); real OpenCV required.
+    void visualize(cv::Mat &image, std::vector<std::string> names, std::vector<float> sims) {
+#ifdef FRT_HAVE_OPENCV
+        for (size_t i = 0; i < croppedFaces.size(); ++i) {
+            const CroppedFace &c = croppedFaces[i];
+            const float fontScaler = static_cast<float>(c.x2 - c.x1) / static_cast<float>(m_frameWidth);
+            const cv::Scalar color = sims[i] >= m_knownPersonThresh ? cv::Scalar(0, 255, 0) : cv::Scalar(0, 0, 255);
+            cv::rectangle(image, cv::Point(c.y1, c.x1), cv::Point(c.y2, c.x2), color, 2, 8, 0);
+            cv::putText(image, names[i] + " " + std::to_string(sims[i]), cv::Point(c.y1 + 2, c.x2 - 3), cv::FONT_HERSHEY_DUPLEX, 0.1 + 2 * fontScaler, color, 1);
+        }
+#else
+        (void)image;
+        (void)names;
+        (void)sims;
+#endif
+    }
+    const float *embeddings() const { return m_embeds.data(); }
+    frt_embedder *handle() { return h_; }
+    MatMul &matcher() { return matmul; }
+
+    std::vector<struct CroppedFace> croppedFaces;
+    static int classCount;  // process-wide, as in the reference (src/arcface.h:39, arcface.cpp:19)
+
+  private:
+    frt_embedder *h_;
+    int m_frameWidth, m_frameHeight, m_INPUT_C, m_INPUT_H, m_INPUT_W, m_OUTPUT_D, m_maxBatchSize, m_maxFacesPerScene;
+    float m_knownPersonThresh;
+    std::vector<float> m_embeds, m_knownEmbeds, m_outputs;
+    std::vector<std::string> classNames;
+    MatMul matmul;
+};
+
+#ifndef FRT_ARCFACE_NO_STATIC_DEFINITION
+int ArcFaceIR50::classCount = 0;  // define FRT_ARCFACE_NO_STATIC_DEFINITION in all but one translation unit
+#endif
+
+#endif  // FRT_ARCFACE_H

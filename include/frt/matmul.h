@@ -1,0 +1,45 @@
+// Drop-in for /root/reference/src/matmul.h: class MatMul with the same public surface (src/matmul.h:17-21).
+//   C = B x A^T : A = knownEmbeds [numRow x numCol] row-major (resident on the GPU), B = embeds [embedCount x numCol],
+//   outputs[i*numRow + j] = <B_i, A_j>   (src/matmul.h:7-16)
+#ifndef FRT_MATMUL_H
+#define FRT_MATMUL_H
+
+#include "common.h"
+
+class MatMul {
+  public:
+    MatMul() : h_(nullptr), device_(0) {}
+    explicit MatMul(int device) : h_(nullptr), device_(device) {}
+    ~MatMul() { frt_matcher_destroy(h_); }
+    MatMul(const MatMul &) = delete;
+    MatMul &operator=(const MatMul &) = delete;
+
+    void init(float *knownEmbeds, int numRow, int numCol) {
+        ensure();
+        checkFrtStatus(frt_matcher_init(h_, knownEmbeds, numRow, numCol));
+    }
+    void calculate(float *embeds, int embedCount, float *outputs) {
+        ensure();
+        checkFrtStatus(frt_matcher_calculate(h_, embeds, embedCount, outputs));
+    }
+    // Extension: fused argmax (what ArcFaceIR50::getOutputs computes from the full matrix), never materialises [n x numRow].
+    void top1(float *embeds, int embedCount, int *idx, float *sim) {
+        ensure();
+        checkFrtStatus(frt_matcher_top1(h_, embeds, embedCount, idx, sim));
+    }
+    frt_matcher *handle() {
+        ensure();
+        return h_;
+    }
+
+  private:
+    void ensure() {  // the reference constructs the cuBLASLt handle in the ctor; lazily here so a MatMul member costs nothing until used
+        if (!h_) checkFrtStatus(frt_matcher_create(device_, &h_));
+    }
+    frt_matcher *h_;
+    int device_;
+};
+
+using CosineSimilarityCalculator = MatMul;  // the name BASELINE.json:north_star uses for this class
+
+#endif  // FRT_MATMUL_H

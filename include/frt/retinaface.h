@@ -1,0 +1,72 @@
+// Drop-in for /root/reference/src/retinaface.h: class RetinaFace with the reference's constructor and findFace signatures
+// (src/retinaface.h:18-23).  engineFile is an FRTW weight blob instead of a TensorRT engine; inputName / outputNames are
+// accepted and ignored (the reference only uses them for getBindingIndex, src/retinaface.cpp:93-95).
+#ifndef FRT_RETINAFACE_H
+#define FRT_RETINAFACE_H
+
+#include <cassert>
+
+#include "common.h"
+#include "cvlite.h"
+
+#ifndef CLIP
+#define CLIP(a, min, max) (MAX(MIN(a, max), min))
+#endif
+
+struct anchorBox {
+    float cx, cy, sx, sy;
+};
+
+class RetinaFace {
+  public:
+    RetinaFace(TRTLogger gLogger, const std::string engineFile, int frameWidth, int frameHeight, std::string inputName,
+               std::vector<std::string> outputNames, std::vector<int> inputShape, int maxBatchSize, int maxFacesPerScene,
+               float nms_threshold, float bbox_threshold, int device = 0)
+        : h_(nullptr), m_maxFacesPerScene(maxFacesPerScene), m_maxBatchSize(maxBatchSize) {
+        (void)gLogger;
+        (void)inputName;
+        assert(inputShape.size() == 3);   // src/retinaface.cpp:8
+        assert(outputNames.size() == 2);  // src/retinaface.cpp:86
+        checkFrtStatus(frt_detector_create(engineFile.c_str(), frameWidth, frameHeight, inputShape[0], inputShape[1], inputShape[2],
+                                           maxBatchSize, maxFacesPerScene, nms_threshold, bbox_threshold, device, &h_));
+        std::cout << "[INFO] Loading RetinaFace Engine...\n";
+    }
+    ~RetinaFace() { frt_detector_destroy(h_); }
+    RetinaFace(const RetinaFace &) = delete;
+    RetinaFace &operator=(const RetinaFace &) = delete;
+
+    // src/retinaface.cpp:147-152.  img must be CV_8UC3 of frameWidth x frameHeight (the caller resizes, src/app.cpp:301).
+    std::vector<struct Bbox> findFace(cv::Mat &img) {
+        std::vector<struct Bbox> out((size_t)m_maxFacesPerScene);
+        int n = 0;
+        checkFrtStatus(frt_detector_find_faces(h_, img.data, img.rows, img.cols, (size_t)img.step, reinterpret_cast<frt_bbox *>(out.data()), &n));
+        out.resize((size_t)n);
+        return out;
+    }
+    // New surface: frames.size() <= maxBatchSize frames of identical size in one device pass.
+    std::vector<std::vector<struct Bbox>> findFaceBatch(std::vector<cv::Mat> &frames) {
+        const int nf = (int)frames.size();
+        std::vector<std::vector<struct Bbox>> res((size_t)nf);
+        if (!nf) return res;
+        const int rows = frames[0].rows, cols = frames[0].cols;
+        std::vector<unsigned char> packed((size_t)nf * rows * cols * 3);
+        for (int f = 0; f < nf; ++f)
+            for (int r = 0; r < rows; ++r)
+                std::memcpy(&packed[((size_t)f * rows + r) * cols * 3], frames[f].data + (size_t)r * frames[f].step, (size_t)cols * 3);
+        std::vector<frt_bbox> out((size_t)nf * m_maxFacesPerScene);
+        std::vector<int> n((size_t)nf);
+        checkFrtStatus(frt_detector_find_faces_batch(h_, packed.data(), nf, rows, cols, (size_t)cols * 3, (size_t)rows * cols * 3, out.data(), n.data()));
+        for (int f = 0; f < nf; ++f) {
+            const Bbox *b = reinterpret_cast<const Bbox *>(&out[(size_t)f * m_maxFacesPerScene]);
+            res[(size_t)f].assign(b, b + n[(size_t)f]);
+        }
+        return res;
+    }
+    frt_detector *handle() { return h_; }
+
+  private:
+    frt_detector *h_;
+    int m_maxFacesPerScene, m_maxBatchSize;
+};
+
+#endif  // FRT_RETINAFACE_H

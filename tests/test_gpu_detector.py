@@ -1,0 +1,72 @@
+"""RetinaFace-mnet0.25 HIP forward vs the fp32 oracle (and the reference-module goldens), then findFace end to end."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+LOC_TOL = 2e-4   # fp32 network, BN folded on the host, different summation order: observed ~1e-5
+CONF_TOL = 2e-5
+
+
+@pytest.mark.parametrize("tag,hw", [("96x160", (96, 160)), ("288x320", (288, 320)), ("640", (640, 640))])
+def test_network_matches_oracle_and_reference_goldens(frt, synth, blobs, tag, hw):
+    from oracle import nets
+    h, w = hw
+    path, sd = blobs("det")
+    det = frt.RetinaFace(path, w, h, (3, h, w), 2, 4)
+    fr = synth.make_frames(2, h, w)
+    x = np.ascontiguousarray((fr.astype(np.float32) - np.array([104, 117, 123], np.float32)).transpose(0, 3, 1, 2))
+    loc, conf = det.doInference(x)
+    oloc, oconf = nets.retinaface_forward(sd, x)
+    assert loc.shape == oloc.shape and conf.shape == oconf.shape
+    assert np.abs(loc - oloc).max() < LOC_TOL, np.abs(loc - oloc).max()
+    assert np.abs(conf - oconf).max() < CONF_TOL, np.abs(conf - oconf).max()
+    g = np.load(os.path.join(GOLDEN, "retinaface_mnet.npz"))
+    step = int(g["step_" + tag])
+    assert np.abs(loc[:, ::step] - g["loc_" + tag]).max() < LOC_TOL
+    assert np.abs(conf[:, ::step] - g["conf_" + tag]).max() < CONF_TOL
+    det.close()
+
+
+def test_non_multiple_of_32_input(frt, synth, blobs):
+    from oracle import nets
+    h, w = 100, 172  # ceil feature maps 13x22, 7x11, 4x6; nearest upsample 4->7->13 is not an exact 2x
+    path, sd = blobs("det")
+    det = frt.RetinaFace(path, w, h, (3, h, w), 1, 4)
+    x = np.ascontiguousarray((synth.make_frames(1, h, w).astype(np.float32) - 110).transpose(0, 3, 1, 2))
+    loc, conf = det.doInference(x)
+    oloc, oconf = nets.retinaface_forward(sd, x)
+    assert loc.shape == oloc.shape
+    assert np.abs(loc - oloc).max() < LOC_TOL and np.abs(conf - oconf).max() < CONF_TOL
+    det.close()
+
+
+@pytest.mark.parametrize("geom", [(640, 640, 640, 640), (320, 288, 640, 480)])
+def test_find_face_boxes_match_oracle_pipeline(frt, orc, synth, blobs, geom):
+    from oracle import nets
+    in_w, in_h, fw, fh = geom
+    path, sd = blobs("det")
+    det = frt.RetinaFace(path, fw, fh, (3, in_h, in_w), 4, 4, 0.4, 0.6)
+    frames = synth.make_frames(4, fh, fw)
+    got = det.findFaceBatch(frames)
+    exact = total = 0
+    for f in range(4):
+        x = orc.det_preprocess(frames[f], in_h, in_w)
+        oloc, oconf = nets.retinaface_forward(sd, x[None])
+        want = orc.postprocess(oloc[0], oconf[0], in_w, in_h, fw, fh, 0.4, 0.6, 4)
+        assert len(got[f]) == len(want) == 4
+        single = det.findFace(frames[f])
+        for k in ("x1", "y1", "x2", "y2", "score"):
+            assert np.array_equal(single[k], got[f][k])  # batch of 1 == batched path
+        for k in ("x1", "y1", "x2", "y2"):
+            d = np.abs(got[f][k] - want[k])
+            assert d.max() <= 1, (f, k, got[f], want)  # int truncation of a float that differs in the last bits
+            exact += int((d == 0).sum())
+            total += d.size
+        assert np.abs(got[f]["score"] - want["score"]).max() < CONF_TOL
+    assert exact >= total - 2, (exact, total)
+    det.close()

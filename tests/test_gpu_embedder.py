@@ -1,0 +1,76 @@
+"""ArcFace IR-50 / IR-SE-50 HIP forward (fp16 MFMA convs, fp32 accumulate) vs the fp32 oracle and the reference goldens.
+
+Tolerance from BASELINE.json north_star: embeddings cosine-equal within 1e-4."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, face_input
+
+pytestmark = pytest.mark.gpu
+COS_TOL = 1e-4
+
+
+@pytest.mark.parametrize("mode", ["ir", "ir_se"])
+def test_embeddings_match_oracle_and_goldens(frt, synth, blobs, mode):
+    from oracle import nets
+    path, sd = blobs(mode)
+    g = np.load(os.path.join(GOLDEN, "arcface_%s.npz" % mode))
+    nf = int(g["n_faces"])
+    rec = frt.ArcFaceIR50(path, maxBatchSize=8)
+    x = face_input(synth.make_faces(nf))
+    emb = rec.doInference(x)
+    assert emb.shape == (nf, 512)
+    assert np.allclose((emb.astype(np.float64) ** 2).sum(1), 1, atol=1e-5)
+    cos_gold = (emb * g["embeddings"]).sum(1)
+    assert cos_gold.min() > 1 - COS_TOL, cos_gold
+    oemb = nets.arcface_forward(sd, x)
+    assert (emb * oemb).sum(1).min() > 1 - COS_TOL
+    assert np.abs(emb - oemb).max() < 2e-3
+    # the pairwise cosine structure (what matching consumes) is preserved
+    assert np.abs(emb @ emb.T - g["cos"]).max() < 2e-3
+    rec.close()
+
+
+def test_batch_chunking_and_batch1_agree(frt, synth, blobs):
+    path, _ = blobs("ir")
+    x = face_input(synth.make_faces(5))
+    rec1 = frt.ArcFaceIR50(path, maxBatchSize=1)   # the reference default (config.json:18): one face per launch
+    rec4 = frt.ArcFaceIR50(path, maxBatchSize=4)   # 5 faces -> chunks of 4 + 1
+    e1, e4 = rec1.doInference(x), rec4.doInference(x)
+    assert (e1 * e4).sum(1).min() > 1 - 1e-6
+    assert np.abs(e1 - e4).max() < 1e-4
+    rec1.close()
+    rec4.close()
+
+
+def test_forward_crops_and_embeds_like_the_oracle(frt, orc, synth, blobs):
+    from oracle import nets
+    path, sd = blobs("ir")
+    rec = frt.ArcFaceIR50(path, maxBatchSize=4)
+    fr = synth.make_frame(3, 480, 640)
+    boxes = np.zeros(3, frt.BBOX_DTYPE)
+    boxes[0] = (30, 40, 200, 180, 0.9)
+    boxes[1] = (100, 300, 212, 412, 0.8)
+    boxes[2] = (250, 10, 479, 300, 0.7)
+    emb = rec.forward(fr, boxes)
+    ocrops = orc.crop_faces(fr, boxes)
+    assert np.array_equal(np.stack([c["face"] for c in rec.croppedFaces]), ocrops)  # CroppedFace.face (app.cpp:329)
+    assert [c["x1"] for c in rec.croppedFaces] == [30, 100, 250]
+    oemb = nets.arcface_forward(sd, orc.face_normalize(ocrops))
+    assert (emb * oemb).sum(1).min() > 1 - COS_TOL
+    # featureMatching / getOutputs vs the fused device path
+    gal = synth.make_gallery(777)
+    gal[[5, 700]] = oemb[[1, 2]]
+    rec.initKnownEmbeds(len(gal))
+    for i, e in enumerate(gal):
+        rec.addEmbedding("u%d" % i, e)
+    rec.initMatMul()
+    names, sims = rec.getOutputs(rec.featureMatching())
+    n2, s2 = rec.matchTop1()
+    assert names == n2 and names[1:] == ["u5", "u700"] and np.allclose(sims, s2, atol=1e-6) and min(sims[1:]) > 0.999
+    rec.resetEmbeddings()
+    with pytest.raises(frt.FrtError):
+        rec.featureMatching()
+    rec.close()

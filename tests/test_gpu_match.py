@@ -1,0 +1,76 @@
+"""HIP cosine-similarity GEMM + fused top-1 vs the NumPy oracle (MatMul::calculate / getOutputs semantics)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mm(frt):
+    m = frt.MatMul(0)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("N,F", [(2, 1), (10000, 1), (10000, 4), (10007, 33), (12345, 128), (300, 200)])
+def test_top1_and_full_matrix_match_oracle(frt, synth, mm, N, F):
+    from oracle import match
+    g = synth.make_gallery(N)
+    r = np.random.Generator(np.random.PCG64(N + F))
+    idx = r.integers(0, N, F)
+    q = synth.make_queries(g, idx, noise=0.02)
+    mm.init(g)
+    got_i, got_s = mm.top1(q)
+    want_i, want_s = match.top1(q, g)
+    assert np.array_equal(got_i, want_i) and np.array_equal(got_i, idx)
+    assert np.abs(got_s - want_s).max() < 1e-5  # fp32, different summation order only
+    full = mm.calculate(q)
+    assert full.shape == (F, N)
+    assert np.abs(full - match.similarity(q, g)).max() < 1e-5
+    # the fused epilogue and the materialised matrix are the same arithmetic: bit-identical maxima
+    assert np.array_equal(full.argmax(1), got_i) and np.array_equal(full.max(1), got_s)
+
+
+def test_duplicate_rows_tie_break_first_index_wins(frt, synth, mm):
+    g = synth.make_gallery(4096 + 37)
+    for dst, src in ((4000, 5), (131, 130), (4100, 129), (2048, 2047)):
+        g[dst] = g[src]
+    q = np.concatenate([g[[5, 130, 129, 2047]], synth.make_queries(g, [4000, 131, 4100, 2048])])
+    mm.init(g)
+    i, s = mm.top1(q)
+    assert i.tolist() == [5, 130, 129, 2047, 5, 130, 129, 2047]
+    full = mm.calculate(q)
+    assert np.array_equal(full[:, 4000], full[:, 5]) and np.array_equal(full[:, 2048], full[:, 2047])  # bit-identical duplicates
+
+
+def test_reinit_is_idempotent_and_empty_gallery_is_an_error(frt, synth, mm):
+    g1, g2 = synth.make_gallery(1000, seed=11), synth.make_gallery(2000, seed=12)
+    mm.init(g1)
+    mm.init(g2)  # /reload: the old device copy is released (the reference leaks it)
+    q = synth.make_queries(g2, [1999])
+    assert mm.top1(q)[0].tolist() == [1999]
+    mm.init(g2[:0], 0, 512)
+    with pytest.raises(frt.FrtError) as e:
+        mm.top1(q)
+    assert e.value.code == frt.FRT_ERR_EMPTY
+
+
+def test_one_million_gallery_properties(frt, synth, mm):
+    """BASELINE size (1M x 512 fp32 = 2.05 GB): planted answers, linearity, first-index rule; checked by properties."""
+    N = 1_000_000
+    g = synth.make_gallery(N)
+    plant = np.array([0, 1, 127, 128, 499_999, 500_000, 999_871, 999_999])
+    g[999_999] = g[127]  # duplicate at the far end: index 127 must win
+    mm.init(g)
+    q = synth.make_queries(g, plant, noise=0.01)
+    i, s = mm.top1(q)
+    want = plant.copy()
+    want[-1] = 127
+    assert np.array_equal(i, want) and s.min() > 0.97
+    # scaling a query scales its similarity, the argmax is unchanged
+    i2, s2 = mm.top1(2.0 * q)
+    assert np.array_equal(i2, i) and np.allclose(s2, 2 * s, rtol=1e-6)
+    # top-1 over the whole gallery == merge of top-1 over two halves (what the sharded multi-GPU path does)
+    from oracle import match
+    oi, osim = match.top1(q[:2], g)
+    assert np.array_equal(oi, i[:2]) and np.abs(osim - s[:2]).max() < 1e-5
