@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--gallery", type=int, default=1_000_000)
     ap.add_argument("--mode", default="ir", choices=["ir", "ir_se"], help="IR-50 (the reference's network) or IR-SE-50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-profile", default=None, help="write a per-stage HIP-event breakdown (extra untimed steps) to this file")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -160,6 +161,22 @@ def main():
                         "kernel": "conv_mfma_kernel (ArcFace 3x3 implicit GEMM, fp16 in / fp32 acc)",
                         "launches": len(sel), "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
                         "flop_per_launch_avg": round(tot_flop / len(sel), 1), "share_of_step_time": round(tot_ms / (1e3 * dt), 4)}
+
+    if args.stage_profile and rank == 0:  # extra, untimed steps with stage-level HIP events -> a side file (not the JSON line)
+        frt.profile_enable(2)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        labels, ms, work = frt.profile_collect()
+        frt.profile_enable(0)
+        agg = {}
+        for l, m, w in zip(labels, ms, work):
+            a = agg.setdefault(l, [0.0, 0.0, 0])
+            a[0] += m
+            a[1] += w
+            a[2] += 1
+        with open(args.stage_profile, "w") as f:
+            json.dump({k: {"ms_per_step": v[0] / 3, "work_per_step": v[1] / 3, "launch_groups_per_step": v[2] / 3} for k, v in agg.items()}, f, indent=1)
 
     if rank == 0:
         out = {

@@ -18,7 +18,7 @@ import os
 
 import numpy as np
 
-from . import synth, weights_io  # noqa: F401
+from . import dist, synth, weights_io  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfrt.so")
