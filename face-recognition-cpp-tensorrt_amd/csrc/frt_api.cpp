@@ -117,11 +117,13 @@ struct frt_detector {
     DetGeom g{};
     int max_batch = 1;
     struct Op {
-        int type;  // 0 dwpw, 1 conv3x3, 2 heads
+        int type;  // 0 dwpw, 1 conv3x3 (n same-shaped problems, one per pyramid level), 2 heads (n levels)
+        int n;
         DwPwArgs dw;
-        Conv3Args c3;
-        HeadArgs hd;
+        Conv3Args c3[3];
+        HeadArgs hd[3];
     };
+    float *d_tmp = nullptr;  // depthwise intermediate of the split conv_dw path
     std::vector<Op> ops;
     double flops_per_frame = 0;
     uint8_t *d_frames = nullptr;
@@ -181,9 +183,24 @@ void frt_detector::build(const frt::Blob &b) {
         fold_conv3(b, conv, bn, cout, cin, w, bias);
         Op o{};
         o.type = 1;
-        o.c3 = Conv3Args{in, out, arena.upload(w), arena.upload(bias), B, cin, h, w_, cout, conv_out(h, stride), conv_out(w_, stride), stride, 1, ctotal, coff};
+        o.n = 1;
+        o.c3[0] = Conv3Args{in, out, arena.upload(w), arena.upload(bias), B, cin, h, w_, cout, conv_out(h, stride), conv_out(w_, stride), stride, 1, ctotal, coff};
         ops.push_back(o);
-        flops_per_frame += 2.0 * cin * 9 * cout * o.c3.Ho * o.c3.Wo;
+        flops_per_frame += 2.0 * cin * 9 * cout * o.c3[0].Ho * o.c3[0].Wo;
+    };
+    // the same conv on every pyramid level -> ONE launch (blockIdx.z = level)
+    auto add_c3_levels = [&](const float *const in[3], float *const out[3], const std::string &name, int cin, int cout, const int *hs, const int *ws,
+                             int ctotal, int coff) {
+        Op o{};
+        o.type = 1;
+        o.n = 3;
+        for (int k = 0; k < 3; ++k) {
+            const std::string pfx = "ssh" + std::to_string(k + 1) + "." + name;
+            fold_conv3(b, pfx + ".0", pfx + ".1", cout, cin, w, bias);
+            o.c3[k] = Conv3Args{in[k], out[k], arena.upload(w), arena.upload(bias), B, cin, hs[k], ws[k], cout, hs[k], ws[k], 1, 1, ctotal, coff};
+            flops_per_frame += 2.0 * cin * 9 * cout * hs[k] * ws[k];
+        }
+        ops.push_back(o);
     };
     // ---- body (net.py:102-124); return layers stage1/2/3 (config.py:17)
     struct L {
@@ -212,7 +229,7 @@ void frt_detector::build(const frt::Blob &b) {
                 Op o{};
                 o.type = 0;
                 o.dw = DwPwArgs{cur, out, arena.upload(w), arena.upload(bias), arena.upload(w2), arena.upload(bias2), nullptr, 0, 0,
-                                B, l.cin, ch, cw, l.cout, oh, ow, l.stride, 1};
+                                B, l.cin, ch, cw, l.cout, oh, ow, l.stride, 1, d_tmp};
                 ops.push_back(o);
                 flops_per_frame += 2.0 * oh * ow * (9.0 * l.cin + (double)l.cin * l.cout);
             }
@@ -237,7 +254,7 @@ void frt_detector::build(const frt::Blob &b) {
         Op o{};
         o.type = 0;
         o.dw = DwPwArgs{feat[k], lat[k], nullptr, nullptr, arena.upload(w2), arena.upload(bias2), addsrc, ah, aw,
-                        B, cins[k], fh[k], fw[k], 64, fh[k], fw[k], 1, 1};
+                        B, cins[k], fh[k], fw[k], 64, fh[k], fw[k], 1, 1, nullptr};
         ops.push_back(o);
         flops_per_frame += 2.0 * fh[k] * fw[k] * cins[k] * 64;
     };
@@ -248,19 +265,26 @@ void frt_detector::build(const frt::Blob &b) {
     add_lat(0, p4, fh[1], fw[1]);
     float *p3 = act(64, fh[0], fw[0]);
     add_c3(lat[0], p3, "fpn.merge1.0", "fpn.merge1.1", 64, 64, fh[0], fw[0], 1, 64, 0);
-    const float *pyr[3] = {p3, p4, lat[2]};
+    float *const pyr_m[3] = {p3, p4, lat[2]};
+    const float *const pyr[3] = {p3, p4, lat[2]};
+    (void)pyr_m;
     // ---- SSH (net.py:55-66) + heads (retinaface_trim.py:14-35).  Every SSH conv ends in a ReLU: either its own or the
     //      ReLU applied to the concat it feeds exclusively.
+    float *cat[3], *t1[3], *t2[3];
     for (int k = 0; k < 3; ++k) {
-        const std::string s = "ssh" + std::to_string(k + 1);
-        float *cat = act(64, fh[k], fw[k]);
-        float *t1 = act(16, fh[k], fw[k]);
-        float *t2 = act(16, fh[k], fw[k]);
-        add_c3(pyr[k], cat, s + ".conv3X3.0", s + ".conv3X3.1", 64, 32, fh[k], fw[k], 1, 64, 0);
-        add_c3(pyr[k], t1, s + ".conv5X5_1.0", s + ".conv5X5_1.1", 64, 16, fh[k], fw[k], 1, 16, 0);
-        add_c3(t1, cat, s + ".conv5X5_2.0", s + ".conv5X5_2.1", 16, 16, fh[k], fw[k], 1, 64, 32);
-        add_c3(t1, t2, s + ".conv7X7_2.0", s + ".conv7X7_2.1", 16, 16, fh[k], fw[k], 1, 16, 0);
-        add_c3(t2, cat, s + ".conv7x7_3.0", s + ".conv7x7_3.1", 16, 16, fh[k], fw[k], 1, 64, 48);
+        cat[k] = act(64, fh[k], fw[k]);
+        t1[k] = act(16, fh[k], fw[k]);
+        t2[k] = act(16, fh[k], fw[k]);
+    }
+    add_c3_levels(pyr, cat, "conv3X3", 64, 32, fh, fw, 64, 0);
+    add_c3_levels(pyr, t1, "conv5X5_1", 64, 16, fh, fw, 16, 0);
+    add_c3_levels(t1, cat, "conv5X5_2", 16, 16, fh, fw, 64, 32);
+    add_c3_levels(t1, t2, "conv7X7_2", 16, 16, fh, fw, 16, 0);
+    add_c3_levels(t2, cat, "conv7x7_3", 16, 16, fh, fw, 64, 48);
+    Op ho{};
+    ho.type = 2;
+    ho.n = 3;
+    for (int k = 0; k < 3; ++k) {
         const std::string hb = "BboxHead." + std::to_string(k) + ".conv1x1", hc = "ClassHead." + std::to_string(k) + ".conv1x1";
         const float *wb = b.get(hb + ".weight", 8 * 64).data, *wc = b.get(hc + ".weight", 4 * 64).data;
         std::vector<float> tb(64 * 8), tc(64 * 4);
@@ -270,12 +294,10 @@ void frt_detector::build(const frt::Blob &b) {
             for (int ci = 0; ci < 64; ++ci) tc[ci * 4 + co] = wc[co * 64 + ci];
         std::vector<float> bb(b.get(hb + ".bias", 8).data, b.get(hb + ".bias", 8).data + 8);
         std::vector<float> bc(b.get(hc + ".bias", 4).data, b.get(hc + ".bias", 4).data + 4);
-        Op o{};
-        o.type = 2;
-        o.hd = HeadArgs{cat, arena.upload(tb), arena.upload(bb), arena.upload(tc), arena.upload(bc), d_loc, d_conf, B, 64, fh[k], fw[k], g.A, g.base[k]};
-        ops.push_back(o);
+        ho.hd[k] = HeadArgs{cat[k], arena.upload(tb), arena.upload(bb), arena.upload(tc), arena.upload(bc), d_loc, d_conf, B, 64, fh[k], fw[k], g.A, g.base[k]};
         flops_per_frame += 2.0 * fh[k] * fw[k] * 64 * 12;
     }
+    ops.push_back(ho);
 }
 
 void frt_detector::preprocess(const uint8_t *frames_dev, int n, size_t row_stride, size_t frame_stride, hipStream_t s) {
@@ -290,11 +312,11 @@ void frt_detector::forward(int n, hipStream_t s) {
             o.dw.B = n;
             launch_dwpw(o.dw, s);
         } else if (o.type == 1) {
-            o.c3.B = n;
-            launch_conv3x3(o.c3, s);
+            for (int k = 0; k < o.n; ++k) o.c3[k].B = n;
+            launch_conv3x3_multi(o.c3, o.n, s);
         } else {
-            o.hd.B = n;
-            launch_heads(o.hd, s);
+            for (int k = 0; k < o.n; ++k) o.hd[k].B = n;
+            launch_heads_multi(o.hd, o.n, s);
         }
     }
 }
@@ -329,7 +351,7 @@ struct frt_embedder {
     float *fc_bias, *bn_s, *bn_b;
     // activations
     float *d_in = nullptr;  // [max_batch][3][112][112]
-    half_t *Y[2], *Z[2], *T, *SC, *RES = nullptr;
+    half_t *Y[2], *Z[2], *T, *SC, *RES = nullptr, *zeros = nullptr;
     float *fc_partial, *d_out, *se_pool = nullptr, *se_gate = nullptr;
     uint8_t *d_crops = nullptr;
     int *d_valid = nullptr;
@@ -451,6 +473,8 @@ void frt_embedder::build(const frt::Blob &b) {
     d_crops = arena.alloc<uint8_t>(F * 112 * 112 * 3);
     d_valid = arena.alloc<int>(F);
     d_boxes = arena.alloc<frt_bbox>(F);
+    zeros = arena.alloc<half_t>(256);
+    HIPCHK(hipMemset(zeros, 0, 256 * sizeof(half_t)));
 }
 
 void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s) {
@@ -469,6 +493,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             a.p0 = u.prelu;
             a.out0 = T;
             a.splits = 1;
+            a.zeros = zeros;
             ProfScope pk(1, "conv3x3_mfma", 2.0 * 9 * u.cin * u.depth * (double)F * h * h, s);
             launch_conv_mfma(a, s);
         }
@@ -484,6 +509,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             a.p1 = u.bsc;
             a.out0 = SC;
             a.splits = 1;
+            a.zeros = zeros;
             launch_conv_mfma(a, s);
             sc_t = SC;
             sc_h = ho;
@@ -497,6 +523,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             a.p0 = u.s2;
             a.p1 = u.b2;
             a.splits = 1;
+            a.zeros = zeros;
             if (!se) {
                 a.mode = EPI_BN_ADD_BN;
                 a.p2 = u.sn;
@@ -528,6 +555,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
         a.mode = EPI_PARTIAL;
         a.outf = fc_partial;
         a.splits = FC_SPLITS;
+        a.zeros = zeros;
         launch_conv_mfma(a, s);
         launch_fc_finalize(fc_partial, FC_SPLITS, F, fc_bias, bn_s, bn_b, valid_dev, out_dev, s);
     }
@@ -668,6 +696,7 @@ int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int 
         d->d_nout = d->arena.alloc<int>(B);
         d->d_dead = d->arena.alloc<uint8_t>(B * g.A);
         d->d_boxes = d->arena.alloc<frt_bbox>(B * max_faces);
+        d->d_tmp = d->arena.alloc<float>(B * 64 * (size_t)g.fh[0] * g.fw[0]);  // largest depthwise intermediate of a split conv_dw block
         d->build(blob);
         HIPCHK(hipDeviceSynchronize());
         *out = d.release();

@@ -60,6 +60,7 @@ struct DwPwArgs {
     const float *add;       // optional tensor to add after ReLU, nearest-upsampled from [B][Cout][add_h][add_w]
     int add_h, add_w;
     int B, Cin, H, W, Cout, Ho, Wo, stride, relu;
+    float *tmp;             // scratch [B][Cin][Ho][Wo] for the split depthwise -> pointwise path (null: always fused)
 };
 void launch_dwpw(const DwPwArgs &a, hipStream_t s);
 struct Conv3Args {
@@ -69,6 +70,7 @@ struct Conv3Args {
     int out_ctotal, out_coff;  // write into channels [coff, coff+Cout) of a [B][ctotal][Ho][Wo] tensor
 };
 void launch_conv3x3(const Conv3Args &a, hipStream_t s);
+void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s);  // up to 3 same-Cout problems in one launch
 struct HeadArgs {
     const float *in;        // [B][64][H][W]
     const float *wb, *bb;   // bbox head [64][8], [8]
@@ -77,6 +79,7 @@ struct HeadArgs {
     int B, C, H, W, A, base;
 };
 void launch_heads(const HeadArgs &a, hipStream_t s);
+void launch_heads_multi(const HeadArgs *a, int n, hipStream_t s);
 
 // ---------------------------------------------------------------- recogniser network (kernels_arc.hip), fp16 NHWC + MFMA
 enum { EPI_PRELU = 0, EPI_BN = 1, EPI_BN_ADD_BN = 2, EPI_PARTIAL = 3 };
@@ -91,6 +94,7 @@ struct ConvMfmaArgs {
     half_t *out0, *out1;
     float *outf;       // EPI_PARTIAL: [splits][M][Cout]
     int splits;
+    const half_t *zeros;  // >= 16 bytes of zeros (source of padded taps for the LDS-DMA path)
 };
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
 struct ArcInputArgs {

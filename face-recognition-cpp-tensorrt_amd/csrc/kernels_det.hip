@@ -1,100 +1,179 @@
-// RetinaFace-mobilenet0.25 forward (fp32, NCHW) as hand-written bandwidth-oriented HIP kernels for gfx950.
+// RetinaFace-mobilenet0.25 forward (fp32, NCHW) as hand-written HIP kernels for gfx950.
 //
 // Arithmetic spec: /root/reference/conversion/retina/models/net.py:9-38 (conv_bn / conv_dw blocks), :40-66 (SSH), :68-98
 // (FPN), :102-124 (MobileNetV1 stages) and retinaface_trim.py:14-35,107-127 (heads, concat, softmax).  In the reference
 // this network runs inside a TensorRT engine (src/retinaface.cpp:141).
 //
-// The whole detector is ~35 flop/byte - far below the machine balance - so no matrix cores (north_star agrees); what matters
-// is (i) every activation is read and written once, (ii) loads/stores are coalesced, (iii) weights never cost HBM traffic.
-//   * layout is planar NCHW with one thread per output pixel: for every input channel the 64 lanes of a wave read 64
-//     consecutive pixels (256 contiguous bytes), and write 64 consecutive pixels per output channel;
-//   * weights are indexed by wave-uniform values only, so the compiler keeps them on the scalar path (s_load -> SGPR
-//     operand of v_fma_f32): zero vector-memory traffic and zero VGPRs for weights;
+// The detector is ~35 flop/byte - below the machine balance - so no matrix cores (north_star agrees).  What matters:
+//   * planar NCHW, one thread per output pixel (or 2-4 pixels): for every input channel the 64 lanes of a wave read 64
+//     consecutive pixels (256 contiguous bytes) and write 64 consecutive pixels per output channel;
+//   * weights never touch the vector memory path in the inner loop: they are staged once per workgroup into LDS as one
+//     record per input channel and read back as wave-uniform (broadcast, conflict-free) ds_read_b128, or - in the dense 3x3
+//     kernel - fetched on the scalar path (s_load -> SGPR operand of v_fma_f32);
 //   * BatchNorm is folded into the preceding conv on the host (all detector BNs follow their conv); ReLU, the FPN
 //     nearest-upsample+add, the SSH concat (+ its ReLU) and the head permute/softmax are fused into the producing kernel;
-//   * a conv_dw block (depthwise 3x3 + BN + ReLU + pointwise 1x1 + BN + ReLU) is ONE kernel: the depthwise result lives
-//     in a register and feeds CT pointwise accumulators, the intermediate tensor never exists.
+//   * early conv_dw blocks (few channels, memory-bound) are ONE fused kernel: the depthwise value lives in a register and
+//     feeds CT pointwise accumulators.  Late blocks (Cout > one channel tile) would recompute the depthwise part once per
+//     output-channel tile, so they run as depthwise kernel + register-blocked pointwise kernel (PPT pixels x 32 couts per
+//     thread: 4*PPT..8*PPT FMAs per LDS/global read) - the round trip of the small intermediate is cheaper than the recompute;
+//   * the three pyramid levels of every SSH / head op are launched together (blockIdx.z = level): the 40x40 and 20x20 levels
+//     are pure latency on their own and hide inside the 80x80 level's launch.
 #include "frt_kernels.h"
 
 namespace {
 
 // ---------------------------------------------------------------- fused depthwise3x3(+ReLU) -> pointwise1x1 (+ReLU) (+upsample-add)
-template <int CT, bool HAS_DW>
+// LDS record per input channel: [9 dw taps, dw bias, 2 pad][CT pointwise weights].  HAS_DW=false: plain 1x1 conv.
+template <int CT, bool HAS_DW, int PPT>
 __global__ __launch_bounds__(256) void dwpw_kernel(DwPwArgs a) {
-    const long gp = (long)blockIdx.x * 256 + threadIdx.x;
-    const int HoWo = a.Ho * a.Wo;
-    if (gp >= (long)a.B * HoWo) return;
-    const int b = (int)(gp / HoWo), p = (int)(gp - (long)b * HoWo);
-    const int oh = p / a.Wo, ow = p - oh * a.Wo;
+    constexpr int REC = (HAS_DW ? 12 : 0) + CT;  // floats per input-channel record (16-byte multiple)
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int co0 = blockIdx.y * CT;
+    for (int i = threadIdx.x; i < a.Cin * REC; i += 256) {
+        const int ci = i / REC, r = i - ci * REC;
+        float v = 0.f;
+        if (HAS_DW && r < 9) v = a.wd[ci * 9 + r];
+        else if (HAS_DW && r == 9) v = a.bd[ci];
+        else if (r >= (HAS_DW ? 12 : 0)) v = a.wp[(long)ci * a.Cout + co0 + (r - (HAS_DW ? 12 : 0))];
+        wsm[i] = v;
+    }
+    __syncthreads();
+
+    const int HoWo = a.Ho * a.Wo;
+    const long total = (long)a.B * HoWo;
+    const long span = (total + PPT - 1) / PPT;
+    const long g0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int HW = a.H * a.W;
 
-    float acc[CT];
+    float acc[PPT][CT];
+    const float *inb[PPT];
+    int off[PPT][HAS_DW ? 9 : 1];
+    bool ok[PPT][HAS_DW ? 9 : 1];
+    bool live[PPT];
+    int pb[PPT], pp[PPT], poh[PPT], pow_[PPT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
-
-    const float *inb = a.in + (long)b * a.Cin * HW;
-    if (HAS_DW) {
-        const int ih0 = oh * a.stride - 1, iw0 = ow * a.stride - 1;
-        int off[9];
-        bool ok[9];
+    for (int q = 0; q < PPT; ++q) {
+        const long gp = g0 + q * span;
+        live[q] = g0 < span && gp < total;
+        const long gq = live[q] ? gp : 0;
+        pb[q] = (int)(gq / HoWo);
+        pp[q] = (int)(gq - (long)pb[q] * HoWo);
+        poh[q] = pp[q] / a.Wo;
+        pow_[q] = pp[q] - poh[q] * a.Wo;
+        inb[q] = a.in + (long)pb[q] * a.Cin * HW;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int c = 0; c < CT; ++c) acc[q][c] = 0.f;
+        if (HAS_DW) {
+            const int ih0 = poh[q] * a.stride - 1, iw0 = pow_[q] * a.stride - 1;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ih = ih0 + kh, iw = iw0 + kw;
-                ok[kh * 3 + kw] = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                off[kh * 3 + kw] = ih * a.W + iw;
-            }
-        for (int ci = 0; ci < a.Cin; ++ci) {
-            const float *x = inb + (long)ci * HW;
-            const float *wd = a.wd + ci * 9;
-            float d = a.bd[ci];
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float v = ok[t] ? x[off[t]] : 0.f;
-                d = fmaf(v, wd[t], d);
-            }
-            d = fmaxf(d, 0.f);
-            const float *wp = a.wp + (long)ci * a.Cout + co0;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = fmaf(d, wp[c], acc[c]);
-        }
-    } else {
-        const int ip = (oh * a.stride) * a.W + ow * a.stride;
-        for (int ci = 0; ci < a.Cin; ++ci) {
-            const float d = inb[(long)ci * HW + ip];
-            const float *wp = a.wp + (long)ci * a.Cout + co0;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = fmaf(d, wp[c], acc[c]);
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = ih0 + kh, iw = iw0 + kw;
+                    ok[q][kh * 3 + kw] = live[q] && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                    off[q][kh * 3 + kw] = ok[q][kh * 3 + kw] ? ih * a.W + iw : 0;
+                }
+        } else {
+            ok[q][0] = live[q];
+            off[q][0] = (poh[q] * a.stride) * a.W + pow_[q] * a.stride;
         }
     }
 
-    float *ob = a.out + ((long)b * a.Cout + co0) * HoWo + p;
-    const float *addb = nullptr;
-    if (a.add) {
-        // F.interpolate(mode="nearest") to (Ho,Wo): src = min(floor(dst * (float)in/out), in-1)   (net.py:89,93)
-        const float sh = (float)a.add_h / (float)a.Ho, sw = (float)a.add_w / (float)a.Wo;
-        int ah = (int)floorf(oh * sh), aw = (int)floorf(ow * sw);
-        ah = ah < a.add_h - 1 ? ah : a.add_h - 1;
-        aw = aw < a.add_w - 1 ? aw : a.add_w - 1;
-        addb = a.add + ((long)b * a.Cout + co0) * a.add_h * a.add_w + ah * a.add_w + aw;
-    }
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float *rec = wsm + ci * REC;
+        float d[PPT];
+        if (HAS_DW) {
+            const floatx4 w0 = *reinterpret_cast<const floatx4 *>(rec);
+            const floatx4 w1 = *reinterpret_cast<const floatx4 *>(rec + 4);
+            const floatx4 w2 = *reinterpret_cast<const floatx4 *>(rec + 8);
+            const float wt[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0]};
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        float v = acc[c] + a.bp[co0 + c];
-        if (a.relu) v = fmaxf(v, 0.f);
-        if (addb) v += addb[(long)c * a.add_h * a.add_w];
-        ob[(long)c * HoWo] = v;
+            for (int q = 0; q < PPT; ++q) {
+                const float *x = inb[q] + (long)ci * HW;
+                float v[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) v[t] = ok[q][t] ? x[off[q][t]] : 0.f;
+                float s = w2[1];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) s = fmaf(v[t], wt[t], s);
+                d[q] = fmaxf(s, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) d[q] = inb[q][(long)ci * HW + off[q][0]];
+        }
+        const float *wp = rec + (HAS_DW ? 12 : 0);
+#pragma unroll
+        for (int c4 = 0; c4 < CT; c4 += 4) {
+            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + c4);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                acc[q][c4] = fmaf(d[q], w[0], acc[q][c4]);
+                acc[q][c4 + 1] = fmaf(d[q], w[1], acc[q][c4 + 1]);
+                acc[q][c4 + 2] = fmaf(d[q], w[2], acc[q][c4 + 2]);
+                acc[q][c4 + 3] = fmaf(d[q], w[3], acc[q][c4 + 3]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        if (!live[q]) continue;
+        float *ob = a.out + ((long)pb[q] * a.Cout + co0) * HoWo + pp[q];
+        const float *addb = nullptr;
+        if (a.add) {
+            // F.interpolate(mode="nearest") to (Ho,Wo): src = min(floor(dst * (float)in/out), in-1)   (net.py:89,93)
+            const float sh = (float)a.add_h / (float)a.Ho, sw = (float)a.add_w / (float)a.Wo;
+            int ah = (int)floorf(poh[q] * sh), aw = (int)floorf(pow_[q] * sw);
+            ah = ah < a.add_h - 1 ? ah : a.add_h - 1;
+            aw = aw < a.add_w - 1 ? aw : a.add_w - 1;
+            addb = a.add + ((long)pb[q] * a.Cout + co0) * a.add_h * a.add_w + ah * a.add_w + aw;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            float v = acc[q][c] + a.bp[co0 + c];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (addb) v += addb[(long)c * a.add_h * a.add_w];
+            ob[(long)c * HoWo] = v;
+        }
     }
 }
 
+// ---------------------------------------------------------------- depthwise 3x3 + bias + ReLU (split path), thread = (b, c, pixel)
+__global__ __launch_bounds__(256) void dw_kernel(DwPwArgs a) {
+    const int HoWo = a.Ho * a.Wo;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (long)a.B * a.Cin * HoWo) return;
+    const int bc = (int)(g / HoWo), p = (int)(g - (long)bc * HoWo);
+    const int c = bc % a.Cin;
+    const int oh = p / a.Wo, ow = p - oh * a.Wo;
+    const float *x = a.in + (long)bc * a.H * a.W;
+    const float *w = a.wd + c * 9;  // NOT wave-uniform (a wave may straddle channels): ordinary cached loads
+    float s = a.bd[c];
+    const int ih0 = oh * a.stride - 1, iw0 = ow * a.stride - 1;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ih = ih0 + kh, iw = iw0 + kw;
+            const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            const float v = ok ? x[ih * a.W + iw] : 0.f;
+            s = fmaf(v, w[kh * 3 + kw], s);
+        }
+    a.tmp[g] = fmaxf(s, 0.f);
+}
+
 // ---------------------------------------------------------------- dense 3x3 (pad 1) + bias (+ReLU), writes a channel slice
+// Up to 3 independent problems per launch (blockIdx.z): the pyramid levels of one SSH op.
+struct Conv3Multi {
+    Conv3Args p[3];
+};
 template <int CT>
-__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
+__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Multi mm) {
+    const Conv3Args &a = mm.p[blockIdx.z];
     const long gp = (long)blockIdx.x * 256 + threadIdx.x;
     const int HoWo = a.Ho * a.Wo;
-    if (gp >= (long)a.B * HoWo) return;
+    if (gp >= (long)a.B * HoWo || (int)blockIdx.y * CT >= a.Cout) return;
     const int b = (int)(gp / HoWo), p = (int)(gp - (long)b * HoWo);
     const int oh = p / a.Wo, ow = p - oh * a.Wo;
     const int co0 = blockIdx.y * CT;
@@ -112,7 +191,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
         for (int kw = 0; kw < 3; ++kw) {
             const int ih = ih0 + kh, iw = iw0 + kw;
             ok[kh * 3 + kw] = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            off[kh * 3 + kw] = ih * a.W + iw;
+            off[kh * 3 + kw] = ok[kh * 3 + kw] ? ih * a.W + iw : 0;
         }
     const float *inb = a.in + (long)b * a.Cin * HW;
     for (int ci = 0; ci < a.Cin; ++ci) {
@@ -136,7 +215,11 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args a) {
 }
 
 // ---------------------------------------------------------------- heads: 1x1 64->8 (bbox) and 64->4 (class) + softmax, NHWC order
-__global__ __launch_bounds__(256) void heads_kernel(HeadArgs a) {
+struct HeadMulti {
+    HeadArgs p[3];
+};
+__global__ __launch_bounds__(256) void heads_kernel(HeadMulti mm) {
+    const HeadArgs &a = mm.p[blockIdx.z];
     const long gp = (long)blockIdx.x * 256 + threadIdx.x;
     const int HW = a.H * a.W;
     if (gp >= (long)a.B * HW) return;
@@ -173,43 +256,91 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs a) {
     *reinterpret_cast<floatx4 *>(a.conf + an * 2) = cf;
 }
 
-template <int CT>
+template <int CT, bool HAS_DW, int PPT>
 void launch_dwpw_t(const DwPwArgs &a, hipStream_t s) {
     const long total = (long)a.B * a.Ho * a.Wo;
-    dim3 grid((unsigned)((total + 255) / 256), a.Cout / CT);
-    if (a.wd)
-        hipLaunchKernelGGL((dwpw_kernel<CT, true>), grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((dwpw_kernel<CT, false>), grid, dim3(256), 0, s, a);
+    const long span = (total + PPT - 1) / PPT;
+    dim3 grid((unsigned)((span + 255) / 256), a.Cout / CT);
+    const size_t lds = (size_t)a.Cin * ((HAS_DW ? 12 : 0) + CT) * sizeof(float);
+    hipLaunchKernelGGL((dwpw_kernel<CT, HAS_DW, PPT>), grid, dim3(256), lds, s, a);
+}
+
+// 1x1 conv (no depthwise part): as many pixels per thread as keeps >= ~100k threads in flight
+void launch_pw(const DwPwArgs &a, hipStream_t s) {
+    const long total = (long)a.B * a.Ho * a.Wo;
+    if (a.Cout % 32 == 0) {
+        const long tiles = a.Cout / 32;
+        if (total / 4 * tiles >= 100000) launch_dwpw_t<32, false, 4>(a, s);
+        else if (total / 2 * tiles >= 100000) launch_dwpw_t<32, false, 2>(a, s);
+        else launch_dwpw_t<32, false, 1>(a, s);
+    } else if (a.Cout % 16 == 0) {
+        launch_dwpw_t<16, false, 1>(a, s);
+    } else {
+        launch_dwpw_t<8, false, 1>(a, s);
+    }
 }
 
 }  // namespace
 
 void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
-    // output-channel tile per thread: large enough to amortise the depthwise work, small enough to keep >= ~1000 waves in flight
+    if (!a.wd) return launch_pw(a, s);
     const long total = (long)a.B * a.Ho * a.Wo;
-    if (a.Cout % 64 == 0 && total >= 256L * 1024)
-        launch_dwpw_t<64>(a, s);
-    else if (a.Cout % 32 == 0 && total >= 256L * 64)
-        launch_dwpw_t<32>(a, s);
-    else if (a.Cout % 16 == 0)
-        launch_dwpw_t<16>(a, s);
-    else
-        launch_dwpw_t<8>(a, s);
+    const long blocks = (total + 255) / 256;
+    // fused while one channel tile covers every output channel (no depthwise recompute) ...
+    if (a.Cout <= 32 || !a.tmp) {
+        if (a.Cout % 32 == 0) {
+            if (blocks >= 2048) launch_dwpw_t<32, true, 2>(a, s);
+            else launch_dwpw_t<32, true, 1>(a, s);
+        } else if (a.Cout % 16 == 0) {
+            if (blocks >= 2048) launch_dwpw_t<16, true, 2>(a, s);
+            else launch_dwpw_t<16, true, 1>(a, s);
+        } else {
+            launch_dwpw_t<8, true, 1>(a, s);
+        }
+        return;
+    }
+    // ... otherwise depthwise -> tmp [B][Cin][Ho][Wo], then a register-blocked pointwise conv from tmp
+    const long n = (long)a.B * a.Cin * a.Ho * a.Wo;
+    hipLaunchKernelGGL(dw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    DwPwArgs b = a;
+    b.in = a.tmp;
+    b.wd = nullptr;
+    b.bd = nullptr;
+    b.H = a.Ho;
+    b.W = a.Wo;
+    b.stride = 1;
+    launch_pw(b, s);
 }
 
-void launch_conv3x3(const Conv3Args &a, hipStream_t s) {
-    const long total = (long)a.B * a.Ho * a.Wo;
-    const unsigned gx = (unsigned)((total + 255) / 256);
-    if (a.Cout % 32 == 0 && total >= 256L * 256)
-        hipLaunchKernelGGL((conv3x3_kernel<32>), dim3(gx, a.Cout / 32), dim3(256), 0, s, a);
-    else if (a.Cout % 16 == 0)
-        hipLaunchKernelGGL((conv3x3_kernel<16>), dim3(gx, a.Cout / 16), dim3(256), 0, s, a);
+void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s) {
+    Conv3Multi mm;
+    long max_total = 0;
+    int cout = a[0].Cout;
+    for (int i = 0; i < n; ++i) {
+        mm.p[i] = a[i];
+        max_total = max_total > (long)a[i].B * a[i].Ho * a[i].Wo ? max_total : (long)a[i].B * a[i].Ho * a[i].Wo;
+    }
+    for (int i = n; i < 3; ++i) mm.p[i] = a[0];
+    const unsigned gx = (unsigned)((max_total + 255) / 256);
+    if (cout % 32 == 0 && max_total >= 256L * 256)
+        hipLaunchKernelGGL((conv3x3_kernel<32>), dim3(gx, cout / 32, n), dim3(256), 0, s, mm);
+    else if (cout % 16 == 0)
+        hipLaunchKernelGGL((conv3x3_kernel<16>), dim3(gx, cout / 16, n), dim3(256), 0, s, mm);
     else
-        hipLaunchKernelGGL((conv3x3_kernel<8>), dim3(gx, a.Cout / 8), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv3x3_kernel<8>), dim3(gx, cout / 8, n), dim3(256), 0, s, mm);
 }
 
-void launch_heads(const HeadArgs &a, hipStream_t s) {
-    const long total = (long)a.B * a.H * a.W;
-    hipLaunchKernelGGL(heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+void launch_conv3x3(const Conv3Args &a, hipStream_t s) { launch_conv3x3_multi(&a, 1, s); }
+
+void launch_heads_multi(const HeadArgs *a, int n, hipStream_t s) {
+    HeadMulti mm;
+    long max_total = 0;
+    for (int i = 0; i < n; ++i) {
+        mm.p[i] = a[i];
+        max_total = max_total > (long)a[i].B * a[i].H * a[i].W ? max_total : (long)a[i].B * a[i].H * a[i].W;
+    }
+    for (int i = n; i < 3; ++i) mm.p[i] = a[0];
+    hipLaunchKernelGGL(heads_kernel, dim3((unsigned)((max_total + 255) / 256), 1, n), dim3(256), 0, s, mm);
 }
+
+void launch_heads(const HeadArgs &a, hipStream_t s) { launch_heads_multi(&a, 1, s); }

@@ -187,21 +187,31 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ G,
     }
 }
 
-__global__ void match_reduce_kernel(const MatchPartial *__restrict__ partial, int blocks, int F, int32_t *__restrict__ idx_out,
-                                    float *__restrict__ sim_out) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= F) return;
+// one wave per query: lanes stride over the workgroup partials, then a butterfly with the same first-maximum rule
+__global__ __launch_bounds__(64) void match_reduce_kernel(const MatchPartial *__restrict__ partial, int blocks, int F,
+                                                          int32_t *__restrict__ idx_out, float *__restrict__ sim_out) {
+    const int q = blockIdx.x;
     float v = -INFINITY;
     int i = INT_MAX;
-    for (int b = 0; b < blocks; ++b) {
+    for (int b = threadIdx.x; b < blocks; b += 64) {
         const MatchPartial p = partial[(long)b * F + q];
         if (p.idx >= 0 && better(p.sim, p.idx, v, i)) {
             v = p.sim;
             i = p.idx;
         }
     }
-    idx_out[q] = i == INT_MAX ? -1 : i;
-    sim_out[q] = v;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        if (better(ov, oi, v, i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+    if (threadIdx.x == 0) {
+        idx_out[q] = i == INT_MAX ? -1 : i;
+        sim_out[q] = v;
+    }
 }
 
 template <int NQ, bool FULL>
@@ -235,7 +245,7 @@ void launch_match_top1(const float *gallery, int N, int D, const float *queries,
         launch_t<2, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
     else
         launch_t<4, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
-    hipLaunchKernelGGL(match_reduce_kernel, dim3((F + 255) / 256), dim3(256), 0, s, partial, partial_blocks, F, idx_out, sim_out);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out);
 }
 
 void launch_match_full(const float *gallery, int N, int D, const float *queries, int F, float *out, hipStream_t s) {

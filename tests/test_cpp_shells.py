@@ -30,10 +30,13 @@ def test_inference_call_sequence_matches_python_binding(demo, frt, synth, blobs,
     dpath, _ = blobs("det")
     rpath, _ = blobs("ir")
     H, W, N = 160, 224, 300
-    frame = synth.make_frame(2, H, W)
     det = frt.RetinaFace(dpath, W, H, (3, H, W), 1, 4, 0.4, 0.6)
     rec = frt.ArcFaceIR50(rpath, W, H)
-    boxes = det.findFace(frame)
+    for seed in range(16):  # first synthetic frame of this size with at least one detection
+        frame = synth.make_frame(seed, H, W)
+        boxes = det.findFace(frame)
+        if len(boxes):
+            break
     emb = rec.forward(frame, boxes)
     gal = synth.make_gallery(N)
     gal[100:100 + len(emb)] = emb
