@@ -437,6 +437,269 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvMfmaArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- v3: LDS-resident halo patch ("strip") kernel, 3x3 / stride 1 / pad 1
+// The im2col kernels above move every input pixel through the L2->LDS path 9 times (once per tap); the v2 ablation showed that
+// path, not the matrix pipe, bounds them (DMA-only 45 us vs MFMA-only 37 us on the 14x14 layers).  Here a workgroup owns a
+// STRIP of output pixels - R image rows x W columns of one image (n_img whole images for 7x7) = up to 224 pixel slots = 7 MFMA
+// pixel tiles - and keeps the strip's halo'd input patch ((R+2) x (W+2) pixels x one 64-channel chunk, zero border) resident in
+// LDS for all 9 taps: a tap is just a row offset into the patch.  Only the [128 cout x 64] weight tile streams per (chunk, tap)
+// step through a 3-stage LDS-DMA ring; the next chunk's patch is prefetched in pieces during taps 0-5 of the current chunk.
+//   * DMA per MFMA drops ~3x (16 KB weights + 1/9 patch per 112 MFMAs  vs  32 KB per 64 MFMAs);
+//   * 4 waves x (1 cout fragment x 7 pixel fragments): 28 MFMAs per wave per barrier (was 16), A fragment reused 7x;
+//   * the patch uses 144-byte pixel rows (9 x 16 B, last slot is padding the DMA fills from the zero buffer): conflict-free
+//     ds_read_b128 without an XOR swizzle, so a tap costs ONE address add per pixel tile; kk offsets are immediates;
+//   * every step issues the same number of DMA instructions (dummy ones from the zero buffer at the tail), and the 9 taps are
+//     unrolled with compile-time (tap, ring stage = tap % 3): every s_waitcnt vmcnt(N) is an exact compile-time count;
+//   * grids fit the machine: 14x14x256 -> 128 images x 2 cout tiles = 256 workgroups on 256 CUs.
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0>  // PPS patch DMA pieces per thread per step during taps 0..PT-1; NW weight-ring depth
+__global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
+    // linear != 0: pixel slots are enumerated over the PADDED row width (slot == patch row of tap (0,0), slots in the two halo
+    // columns are dead).  The 32 lanes of a fragment read then touch 32 consecutive patch rows -> no LDS bank conflicts; the
+    // image-row wrap of the compact enumeration (a 2-row skip) costs ~40 % extra LDS cycles (measured SQ_LDS_BANK_CONFLICT).
+    constexpr int NSLOT = PT * PPS;
+    constexpr int PATCH_B = NSLOT * 256 * 16;    // bytes per patch buffer (whole DMA slots)
+    constexpr int PROW = 144;                    // bytes per patch pixel row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *patch = smem;  // LDS holds ONLY the patch (double-buffered); weights go L2 -> registers
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int H = p.H, W = p.W, Wp = W + 2;
+    const int NP = n_img * (R + 2) * Wp;
+    const int strips_per_img = H / R;
+    const int n_valid = n_img * R * W;
+
+    const int n_co_tiles = p.Cout >> 7;
+    const int nblk = gridDim.x, bq = nblk >> 3, brem = nblk & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int lid = (xcd < brem ? xcd * (bq + 1) : brem * (bq + 1) + (xcd - brem) * bq) + slot;
+    const int co_tile = lid % n_co_tiles, strip = lid / n_co_tiles;
+    const int co_base = co_tile * 128;
+    const int img0 = (strip / strips_per_img) * n_img;
+    const int row0 = (strip % strips_per_img) * R;
+
+    const int n_chunks = p.Cin >> 6;
+    const long Ktot = 9L * p.Cin;
+
+    // ---- patch DMA descriptors: slot q of this lane covers 16-byte chunk g = (q*4 + wave)*64 + lane of the patch image
+    int poff[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+        const int g = (q * 4 + wave) * 64 + lane;
+        const int prow = g / 9, pos = g - prow * 9;
+        poff[q] = -1;
+        if (pos < 8 && prow < NP) {
+            const int il = prow / ((R + 2) * Wp);
+            const int rem = prow - il * ((R + 2) * Wp);
+            const int pr = rem / Wp, pc = rem - pr * Wp;
+            const int iy = row0 + pr - 1, ix = pc - 1, b = img0 + il;
+            if (b < p.B && iy >= 0 && iy < H && ix >= 0 && ix < W) poff[q] = ((b * H + iy) * W + ix) * p.Cin + pos * 8;
+        }
+    }
+    // ---- weights: each wave consumes only its own 32 cout rows, so the A fragments never touch LDS: lane (r, hi) loads its
+    //      four 16-byte fragments (kk = 0..3) of W[co_base + wave*32 + r][tap][chunk*64 + (kk*2+hi)*8 ..] straight from L2 into
+    //      registers, two steps ahead (register ring of 3 steps, index = tap % 3 at compile time).  This removes the weight
+    //      tile from the LDS write AND read paths - LDS bandwidth (fragment reads + LDS-DMA writes) was the binding resource.
+    const half_t *wrow = p.w + (long)(co_base + wave * 32 + r) * Ktot + hi * 8;
+    // ---- B-fragment base addresses: pixel slot -> patch row of tap (0,0)
+    int pbase[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int sl = j * 32 + r;
+        int pidx = 0;
+        if (linear) {
+            pidx = sl < R * Wp ? sl : 0;
+        } else if (sl < n_valid) {
+            const int il = sl / (R * W);
+            const int rem = sl - il * (R * W);
+            const int rr = rem / W, cc = rem - rr * W;
+            pidx = (il * (R + 2) + rr) * Wp + cc;
+        }
+        pbase[j] = pidx * PROW + hi * 16;
+    }
+
+    half8 areg[3][4];
+    auto load_w = [&](int c, int tap, auto slot_c) {  // wave-uniform c, tap; clamped at the tail (values unused there)
+        constexpr int S = decltype(slot_c)::value;
+        const int woff = c < n_chunks ? tap * p.Cin + (c << 6) : 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) areg[S][kk] = *reinterpret_cast<const half8 *>(wrow + woff + kk * 16);
+    };
+    auto issue_patch = [&](int c, auto q0_c, auto nq_c) {
+        constexpr int Q0 = decltype(q0_c)::value, NQ = decltype(nq_c)::value;
+        const bool real = c < n_chunks;
+        char *pl = patch + (SINGLE ? 0 : (c & 1) * PATCH_B) + wave * 1024;
+#pragma unroll
+        for (int q = Q0; q < Q0 + NQ; ++q) {
+            const half_t *src = (real && poff[q] >= 0) ? p.x + (unsigned)(poff[q] + (c << 6)) : p.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(pl + q * 4096), 16, 0, 0);
+        }
+    };
+
+    floatx16 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // prologue: patch(0) completely, then the weight fragments of steps 0 and 1
+    issue_patch(0, std::integral_constant<int, 0>{}, std::integral_constant<int, NSLOT>{});
+    load_w(0, 0, std::integral_constant<int, 0>{});
+    load_w(0, 1, std::integral_constant<int, 1>{});
+
+    // B fragment registers: two kk-deep ring that runs CONTINUOUSLY across steps.  One wave per SIMD means only this wave's own
+    // instruction stream can hide LDS latency, so every MFMA is followed by exactly one ds_read that refills the register it
+    // just consumed with the fragment two kk-slots ahead - in the second half of a step that is the NEXT tap's fragment (the
+    // patch is resident).  sched_barrier(0) pins the order (left alone hipcc emits "2 reads, lgkmcnt(0), 1 MFMA").
+    half8 bf[2][7];
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's patch(0) pieces have landed (younger: the 8 fragment loads)
+    __builtin_amdgcn_s_barrier();                     // ... and everybody else's
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) bf[k2][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + k2 * 32);
+
+    auto step = [&](int c, auto tap_c) {
+        constexpr int TAP = decltype(tap_c)::value;
+        constexpr int NTAP = (TAP + 1) % 9;
+        constexpr int AS = TAP % 3;  // register-ring slot of this step's weight fragments (9 taps = 3 x 3: compile time)
+        const int pbuf = SINGLE ? 0 : (c & 1) * PATCH_B;
+        const int dp = ((TAP / 3) * Wp + (TAP % 3)) * PROW + pbuf;
+        const int dpn = ((NTAP / 3) * Wp + (NTAP % 3)) * PROW + (TAP == 8 ? (SINGLE ? 0 : ((c + 1) & 1) * PATCH_B) : pbuf);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = kk & 1;
+            if (kk == 2 && !SINGLE && TAP == 8) {
+                // chunk boundary: from here on the refills read the NEXT chunk's patch buffer.  This wave's pieces (last issued
+                // at tap PT-1; younger: the 4 fragment loads of each later step) have landed, every wave's reads of the buffer
+                // about to be recycled have returned, then everybody meets.
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (8 - (PT - 1))) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                if (ABL == 2) asm volatile("" ::"v"(areg[AS][kk]), "v"(bf[cur][j]));
+                else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[AS][kk], bf[cur][j], acc[j], 0, 0, 0);
+                if (kk < 2) bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dp + (kk + 2) * 32);
+                else bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dpn + (kk - 2) * 32);
+                if (ABL != 1 && ABL != 7 && kk == 0 && j == 1) {  // weight fragments of step t+2 into the slot step t-1 used
+                    constexpr int T2 = TAP + 2;
+                    load_w(T2 < 9 ? c : c + 1, T2 % 9, std::integral_constant<int, T2 % 3>{});
+                }
+                if (ABL != 1 && ABL != 6 && kk == 1 && j == 1 && !SINGLE && TAP < PT)
+                    issue_patch(c + 1, std::integral_constant<int, (TAP < PT ? TAP : 0) * PPS>{}, std::integral_constant<int, PPS>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int c = 0; c < (ABL == 4 ? 0 : n_chunks); ++c) {
+        step(c, std::integral_constant<int, 0>{});
+        step(c, std::integral_constant<int, 1>{});
+        step(c, std::integral_constant<int, 2>{});
+        step(c, std::integral_constant<int, 3>{});
+        step(c, std::integral_constant<int, 4>{});
+        step(c, std::integral_constant<int, 5>{});
+        step(c, std::integral_constant<int, 6>{});
+        step(c, std::integral_constant<int, 7>{});
+        step(c, std::integral_constant<int, 8>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's dummy DMAs still target LDS
+    __syncthreads();
+    if (ABL == 5) {  // timing ablation: keep the accumulators alive, skip the epilogue
+        float sacc = 0.f;
+        for (int j = 0; j < 7; ++j) sacc += acc[j][0];
+        if (sacc == 123.456f) p.out0[0] = (half_t)sacc;
+        return;
+    }
+
+    // ------------------------------------------------------------------ epilogue (per wave: 32 couts x 7 pixel tiles) through LDS
+    constexpr int EROW = 36;  // floats per pixel row (32 + 4 pad)
+    float *ep = reinterpret_cast<float *>(smem) + wave * (32 * EROW);
+    const int chunk = lane & 3;
+    const int cch = co_base + wave * 32 + chunk * 8;
+    floatx4 q0[2], q1[2], q2[2], q3[2];
+    q0[0] = *reinterpret_cast<const floatx4 *>(p.p0 + cch);
+    q0[1] = *reinterpret_cast<const floatx4 *>(p.p0 + cch + 4);
+    if (p.mode != EPI_PRELU) {
+        q1[0] = *reinterpret_cast<const floatx4 *>(p.p1 + cch);
+        q1[1] = *reinterpret_cast<const floatx4 *>(p.p1 + cch + 4);
+    }
+    if (p.mode == EPI_BN_ADD_BN && p.out1) {
+        q2[0] = *reinterpret_cast<const floatx4 *>(p.p2 + cch);
+        q2[1] = *reinterpret_cast<const floatx4 *>(p.p2 + cch + 4);
+        q3[0] = *reinterpret_cast<const floatx4 *>(p.p3 + cch);
+        q3[1] = *reinterpret_cast<const floatx4 *>(p.p3 + cch + 4);
+    }
+    // pixel slots of a strip are CONTIGUOUS in the flattened (image, row, column) index: m = m0 + slot (no divisions)
+    const long m0 = ((long)img0 * H + row0) * W;
+    const long Mtot = (long)p.B * H * W;
+    const float inv_wp = 1.0f / (float)Wp;
+    auto slot_pixel = [&](int sl, long &m) -> bool {  // pixel slot -> flattened output pixel index; false for dead slots
+        if (linear) {
+            const int rr = (int)(((float)sl + 0.5f) * inv_wp);  // exact for sl < 2^20
+            const int cc = sl - rr * Wp;
+            m = m0 + rr * W + cc;
+            return rr < R && cc < W && m < Mtot;
+        }
+        m = m0 + sl;
+        return sl < n_valid && m < Mtot;
+    };
+    half8 sc8[7][2];
+    if (p.mode == EPI_BN_ADD_BN) {  // stride 1: the shortcut has the output's geometry; all 14 loads in flight before the transposes
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int sl = j * 32 + (lane >> 2) + 16 * it;
+                long m;
+                const bool ok = slot_pixel(sl, m);
+                sc8[j][it] = *reinterpret_cast<const half8 *>(p.sc + (ok ? m : 0) * p.Cout + cch);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+            *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int px = (lane >> 2) + 16 * it;
+            const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
+            const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
+            const int sl = j * 32 + px;
+            long m;
+            if (!slot_pixel(sl, m)) continue;
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (p.mode == EPI_PRELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * q0[e >> 2][e & 3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3];
+            }
+            if (p.mode == EPI_BN_ADD_BN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)sc8[j][it][e];
+            }
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+            *reinterpret_cast<half8 *>(p.out0 + m * p.Cout + cch) = o;
+            if (p.mode == EPI_BN_ADD_BN && p.out1) {
+                half8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (half_t)(v[e] * q2[e >> 2][e & 3] + q3[e >> 2][e & 3]);
+                *reinterpret_cast<half8 *>(p.out1 + m * p.Cout + cch) = z;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- input layer: conv3x3 3->64 + BN + PReLU (+ unit-0 leading BN)
 // 0.3 % of the FLOPs, K = 27: plain VALU.  8 lanes share one pixel, each lane owns 8 of the 64 output channels, so a pixel's
 // 128-byte NHWC row is written by 8 consecutive lanes (fully coalesced 16-byte stores); the 27 taps are the same address for
@@ -602,6 +865,46 @@ void launch_glds_t(const ConvMfmaArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((conv_glds_kernel<WCO, WPX, NSTAGE, ABL>), grid, dim3(256), lds, s, a);
 }
 
+// strip geometry for the patch kernel; returns false when the layer is not eligible
+bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &single) {
+    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.Cout % 128 || a.Cin % 64 || a.splits != 1 || a.H != a.W) return false;
+    if (a.mode == EPI_PARTIAL) return false;
+    if (a.mode == EPI_BN_ADD_BN && !(a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
+    if (a.H * a.W <= 56) {
+        n_img = 224 / (a.H * a.W);
+        R = a.H;
+    } else {
+        n_img = 1;
+        R = 0;
+        for (int d = 1; d <= a.H; ++d)
+            if (a.H % d == 0 && d * a.W <= 224) R = d;
+        if (!R) return false;
+    }
+    if (n_img * R * a.W < 160) return false;  // too many dead pixel slots
+    const int NP = n_img * (R + 2) * (a.W + 2);
+    const int slots = (NP * 9 + 255) / 256;
+    single = a.Cin == 64;
+    pps = slots;  // DMA slots (1 KB per wave each) the patch image needs
+    if (single ? slots > 15 : slots > 12) return false;  // LDS budget, see launch_patch_t instantiations
+    return true;
+}
+
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0>
+void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
+    const size_t lds = (size_t)(SINGLE ? 1 : 2) * PT * PPS * 4096;  // patch buffers only (NW is unused: weights live in registers)
+    static_assert((SINGLE ? 1 : 2) * PT * PPS * 4096 <= 160 * 1024 && PT * PPS * 4096 >= 4 * 32 * 36 * 4, "LDS budget / epilogue scratch");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    const int strips = ((a.B + n_img - 1) / n_img) * (a.H / R);
+    dim3 grid(strips * (a.Cout / 128));
+    const int linear = (n_img == 1 && R * (a.W + 2) <= 224) ? 1 : 0;
+    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL>), grid, dim3(256), lds, s, a, R, n_img, linear);
+}
+
 int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage (default: 64 KB ring, 2 workgroups per CU), 3 = LDS-DMA 3-stage
     static int impl = -1;
     if (impl < 0) {
@@ -616,6 +919,24 @@ int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage
 
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
     const int impl = conv_impl();
+    static const int use_patch = getenv("FRT_CONV_PATCH") ? atoi(getenv("FRT_CONV_PATCH")) : 1;
+    int R, n_img, pps;
+    bool single;
+    if (impl >= 2 && use_patch && patch_geometry(a, R, n_img, pps, single)) {
+        const int slots = pps;
+        static const int abl = getenv("FRT_CONV_ABLATE") ? atoi(getenv("FRT_CONV_ABLATE")) : 0;  // timing experiments only
+        if (single) return launch_patch_t<3, 5, 5, true>(a, R, n_img, s);            // 15 slots (60 KB) + 5 x 16 KB ring
+        if (slots <= 10) {                                                            // 2 x 40 KB patch + 5 x 16 KB ring = 160 KB
+            if (abl == 1) return launch_patch_t<2, 5, 5, false, 1>(a, R, n_img, s);
+            if (abl == 2) return launch_patch_t<2, 5, 5, false, 2>(a, R, n_img, s);
+            if (abl == 4) return launch_patch_t<2, 5, 5, false, 4>(a, R, n_img, s);
+            if (abl == 5) return launch_patch_t<2, 5, 5, false, 5>(a, R, n_img, s);
+            if (abl == 6) return launch_patch_t<2, 5, 5, false, 6>(a, R, n_img, s);
+            if (abl == 7) return launch_patch_t<2, 5, 5, false, 7>(a, R, n_img, s);
+            return launch_patch_t<2, 5, 5, false>(a, R, n_img, s);
+        }
+        return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);                       // 2 x 48 KB patch + 4 x 16 KB ring = 160 KB
+    }
     const bool wide = a.Cout % 128 == 0;
     if (impl == 1) {
         if (wide) launch_conv_t<2, 2>(a, s);
