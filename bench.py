@@ -162,6 +162,25 @@ def main():
                         "launches": len(sel), "avg_launch_us": round(1e3 * tot_ms / len(sel), 2),
                         "flop_per_launch_avg": round(tot_flop / len(sel), 1), "share_of_step_time": round(tot_ms / (1e3 * dt), 4)}
 
+    if roofline is not None:
+        # The timed region runs the two-stream pipeline: conv launches share the CUs with the next batch's detector, so their
+        # live durations include that contention.  Same measurement again, serially (extra untimed steps), for the record.
+        pipe.set_overlap(False)
+        frt.profile_enable(1)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        labels, ms, work = frt.profile_collect()
+        frt.profile_enable(0)
+        pipe.set_overlap(True)
+        sel = [i for i, l in enumerate(labels) if l == "conv3x3_mfma" and ms[i] > 0]
+        if sel:
+            ach = float(work[sel].sum()) / (float(ms[sel].sum()) * 1e-3) / 1e12
+            roofline["serial_achieved"] = round(ach, 2)
+            roofline["serial_frac"] = round(ach / PEAK_FP16_MFMA_TFLOPS, 4)
+            roofline["note"] = ("achieved/frac: live HIP-event durations inside the timed region (two-stream pipeline: the next batch's "
+                                "detector shares the CUs); serial_*: same launches with the overlap switched off (3 extra untimed steps)")
+
     if args.stage_profile and rank == 0:  # extra, untimed steps with stage-level HIP events -> a side file (not the JSON line)
         frt.profile_enable(2)
         for _ in range(3):

@@ -70,6 +70,7 @@ ABI = {
     "frt_pipeline_run_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_pipeline_sync": (_i, [_vp]),
     "frt_pipeline_set_stream": (_i, [_vp, _vp]),
+    "frt_pipeline_set_overlap": (_i, [_vp, _i]),
     "frt_profile_enable": (_i, [_i]),
     "frt_profile_collect": (_i, [_vp, _sz, _vp, _vp, _i]),
 }
@@ -360,6 +361,10 @@ class Pipeline:
 
     def sync(self):
         _check(lib.frt_pipeline_sync(self._h))
+
+    def set_overlap(self, enable):
+        """Two-stream software pipelining of consecutive calls (detector of call b+1 under embed/match of call b)."""
+        _check(lib.frt_pipeline_set_overlap(self._h, 1 if enable else 0))
 
     def set_stream(self, hip_stream):
         """``hip_stream``: raw hipStream_t value (e.g. ``torch.cuda.current_stream().cuda_stream``) or None."""

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -608,6 +609,15 @@ struct frt_pipeline {
     frt_matcher *mat;
     int max_frames, max_faces, F_cap;
     hipStream_t stream = nullptr, own_stream = nullptr;
+    // Two-stream software pipeline: the detector (fp32 VALU / latency bound) of call b+1 runs on det_stream while crop + embed
+    // (MFMA bound) + match of call b run on `stream`; the two leave each other's execution units idle, so they overlap on the
+    // same CUs.  Fork/join with events; the boxes of a call live in one of two slots so the next detect cannot clobber them.
+    hipStream_t det_stream = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_det[2] = {nullptr, nullptr};
+    frt_bbox *slot_boxes[2];
+    int *slot_nout[2];
+    unsigned seq = 0;
+    bool overlap = true;
     Arena arena;
     uint8_t *d_frames;
     float *d_chw, *d_embeds, *d_sim;
@@ -619,13 +629,28 @@ struct frt_pipeline {
         hipStream_t s = stream;
         const DetGeom &g = det->g;
         const int F = n * max_faces;
-        det->preprocess(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, s);
-        det->forward(n, s);
-        det->postprocess(n, s);
+        const int slot = (int)(seq++ & 1u);
+        hipStream_t ds = (overlap && g_prof_kind != 2) ? det_stream : s;  // the stage-profiling mode times stages serially on one stream
+        if (ds != s && seq > 2) {
+            // det_stream may overwrite this box slot once the crop/pack that read it two calls ago (on `s`) are done.  NB the
+            // frames must be valid when the call is made: waiting for all prior work on `s` here would serialise the two streams.
+            HIPCHK(hipStreamWaitEvent(ds, ev_in[slot], 0));
+        }
+        det->preprocess(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, ds);
+        det->forward(n, ds);
+        det->postprocess(n, ds);
+        HIPCHK(hipMemcpyAsync(slot_boxes[slot], det->d_boxes, sizeof(frt_bbox) * F, hipMemcpyDeviceToDevice, ds));
+        HIPCHK(hipMemcpyAsync(slot_nout[slot], det->d_nout, sizeof(int) * n, hipMemcpyDeviceToDevice, ds));
+        if (ds != s) {
+            HIPCHK(hipEventRecord(ev_det[slot], ds));
+            HIPCHK(hipStreamWaitEvent(s, ev_det[slot], 0));
+        }
+        const frt_bbox *boxes = slot_boxes[slot];
+        const int *nout = slot_nout[slot];
         {
             ProfScope ps(2, "crop_faces", (double)F * 112 * 112 * 3, s);
-            launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, det->d_boxes, det->d_nout,
-                              max_faces, F, 0, 112, 112, nullptr, d_chw, d_valid, s);
+            launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, boxes, nout, max_faces, F, 0,
+                              112, 112, nullptr, d_chw, d_valid, s);
         }
         float *emb_out = embeds_dev ? embeds_dev : d_embeds;
         for (int f0 = 0; f0 < F; f0 += emb->max_batch) {
@@ -634,9 +659,11 @@ struct frt_pipeline {
         }
         const bool have_gallery = mat && mat->N > 0;
         if (have_gallery) mat->top1_dev(emb_out, F, d_idx, d_sim, s);
-        ProfScope ps(2, "pack_results", (double)F, s);
-        launch_pack_results(det->d_boxes, det->d_nout, d_valid, have_gallery ? d_idx : nullptr, have_gallery ? d_sim : nullptr, max_faces, F,
-                            results_dev, s);
+        {
+            ProfScope ps(2, "pack_results", (double)F, s);
+            launch_pack_results(boxes, nout, d_valid, have_gallery ? d_idx : nullptr, have_gallery ? d_sim : nullptr, max_faces, F, results_dev, s);
+        }
+        if (ds != s) HIPCHK(hipEventRecord(ev_in[slot], s));  // this slot's boxes are free again after this point of `s`
     }
 };
 
@@ -1044,7 +1071,18 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         p->F_cap = max_frames * p->max_faces;
         HIPCHK(hipStreamCreate(&p->own_stream));
         p->stream = p->own_stream;
+        HIPCHK(hipStreamCreate(&p->det_stream));
         const size_t F = (size_t)p->F_cap;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipEventCreateWithFlags(&p->ev_in[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&p->ev_det[i], hipEventDisableTiming));
+            p->slot_boxes[i] = p->arena.alloc<frt_bbox>(F);
+            p->slot_nout[i] = p->arena.alloc<int>((size_t)max_frames);
+        }
+        {
+            const char *e = getenv("FRT_PIPELINE_OVERLAP");
+            p->overlap = !(e && e[0] == '0');
+        }
         p->d_frames = p->arena.alloc<uint8_t>((size_t)max_frames * d->g.frame_h * d->g.frame_w * 3);
         p->d_chw = p->arena.alloc<float>(F * 3 * 112 * 112);
         p->d_embeds = p->arena.alloc<float>(F * 512);
@@ -1059,8 +1097,14 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
 void frt_pipeline_destroy(frt_pipeline *p) {
     if (!p) return;
     (void)hipSetDevice(p->det->device);
+    if (p->det_stream) (void)hipStreamSynchronize(p->det_stream);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    if (p->det_stream) (void)hipStreamDestroy(p->det_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (p->ev_in[i]) (void)hipEventDestroy(p->ev_in[i]);
+        if (p->ev_det[i]) (void)hipEventDestroy(p->ev_det[i]);
+    }
     p->arena.release();
     delete p;
 }
@@ -1090,6 +1134,7 @@ int frt_pipeline_sync(frt_pipeline *p) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
+        HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
     });
 }
@@ -1098,8 +1143,20 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
+        HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : p->own_stream;
+    });
+}
+
+int frt_pipeline_set_overlap(frt_pipeline *p, int enable) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        use_device(p->det->device);
+        HIPCHK(hipStreamSynchronize(p->det_stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        p->overlap = enable != 0;
+        p->seq = 0;
     });
 }
 
@@ -1110,7 +1167,9 @@ int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_f
         use_device(p->det->device);
         hipStream_t s = p->stream;
         const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
-        HIPCHK(hipMemcpyAsync(p->d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, s));
+        // upload on the stream the detector will run on: the crop (pipeline stream) is ordered behind the detector's event
+        hipStream_t cs = (p->overlap && g_prof_kind != 2) ? p->det_stream : s;
+        HIPCHK(hipMemcpyAsync(p->d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, cs));
         pipeline_lock_run(p, p->d_frames, n_frames, p->d_results, p->d_embeds);
         const int F = n_frames * p->max_faces;
         HIPCHK(hipMemcpyAsync(results, p->d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));

@@ -155,6 +155,10 @@ int frt_pipeline_sync(frt_pipeline *p);
 /* Run on a caller-owned HIP stream (a hipStream_t passed as void*, e.g. PyTorch's current stream, so that RCCL collectives
  * issued by the caller are ordered after the pipeline without a host synchronisation).  NULL restores the private stream. */
 int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream);
+/* Two-stream software pipelining (default on; env FRT_PIPELINE_OVERLAP=0 disables): the detector of call b+1 runs on an
+ * internal stream concurrently with crop/embed/match of call b.  Results stay ordered on the pipeline stream.  With
+ * overlap on, the frames passed to frt_pipeline_run_dev must already be valid when the call is made. */
+int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Profiling hooks (HIP events on the library's own stream; used by bench.py for the roofline object).

@@ -56,3 +56,36 @@ def test_pipeline_end_to_end(frt, orc, synth, blobs):
     pipe.close()
     det.close()
     rec.close()
+
+
+def test_two_stream_overlap_keeps_batches_apart(frt, synth, blobs):
+    """Back-to-back asynchronous calls (detector of call b+1 overlaps embed/match of call b) == one call at a time."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 2, 4, 320, 320
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    rec.setGallery(synth.make_gallery(3000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    batches = [synth.make_frames(B, H, W, start=10 * i) for i in range(5)]
+    want = [pipe.run(b)[0].copy() for b in batches]          # serial reference (each call synchronises)
+    assert sum(int(w["valid"].sum()) for w in want) > 0
+    d_frames = [torch.from_numpy(b).cuda() for b in batches]
+    d_res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in batches]
+    pipe.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for rep in range(2):                                       # second round re-uses both box slots
+        for f, r in zip(d_frames, d_res):
+            pipe.run_dev(f.data_ptr(), B, r.data_ptr(), None)
+        torch.cuda.synchronize()
+        for r, w in zip(d_res, want):
+            got = np.frombuffer(r.cpu().numpy().tobytes(), frt.RESULT_DTYPE)
+            for k in ("x1", "y1", "x2", "y2", "frame", "match_idx", "valid"):
+                assert np.array_equal(got[k], w[k]), (rep, k)
+            assert np.abs(got["match_sim"] - w["match_sim"]).max() < 1e-6
+    pipe.set_stream(None)
+    pipe.close()
+    det.close()
+    rec.close()
