@@ -451,30 +451,36 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvMfmaArgs p) {
 //   * every step issues the same number of DMA instructions (dummy ones from the zero buffer at the tail), and the 9 taps are
 //     unrolled with compile-time (tap, ring stage = tap % 3): every s_waitcnt vmcnt(N) is an exact compile-time count;
 //   * grids fit the machine: 14x14x256 -> 128 images x 2 cout tiles = 256 workgroups on 256 CUs.
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0>  // PPS patch DMA pieces per thread per step during taps 0..PT-1; NW weight-ring depth
+// PAIR (Cout == 64, Cin == 64): one workgroup handles TWO strips; waves (0,1) own the first, waves (2,3) the second, each wave
+// one 32-cout fragment of its strip.  Each half stages its own patch (128 threads per patch image); the whole K loop (9 taps)
+// runs on that single resident patch.
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false>  // PPS patch DMA pieces per thread per step during taps 0..PT-1
 __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
     // linear != 0: pixel slots are enumerated over the PADDED row width (slot == patch row of tap (0,0), slots in the two halo
     // columns are dead).  The 32 lanes of a fragment read then touch 32 consecutive patch rows -> no LDS bank conflicts; the
     // image-row wrap of the compact enumeration (a 2-row skip) costs ~40 % extra LDS cycles (measured SQ_LDS_BANK_CONFLICT).
-    constexpr int NSLOT = PT * PPS;
-    constexpr int PATCH_B = NSLOT * 256 * 16;    // bytes per patch buffer (whole DMA slots)
+    static_assert(!PAIR || SINGLE, "pair mode needs the single-chunk path");
+    constexpr int NSLOT = PAIR ? 34 : PT * PPS;
+    constexpr int PATCH_B = NSLOT * (PAIR ? 128 : 256) * 16;  // bytes per patch buffer (whole DMA slots)
     constexpr int PROW = 144;                    // bytes per patch pixel row
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *patch = smem;  // LDS holds ONLY the patch (double-buffered); weights go L2 -> registers
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char *patch = smem + (PAIR ? (wave >> 1) * PATCH_B : 0);  // LDS holds ONLY patches; weights go L2 -> registers
     const int r = lane & 31, hi = lane >> 5;
     const int H = p.H, W = p.W, Wp = W + 2;
     const int NP = n_img * (R + 2) * Wp;
     const int strips_per_img = H / R;
     const int n_valid = n_img * R * W;
 
-    const int n_co_tiles = p.Cout >> 7;
+    const int n_co_tiles = PAIR ? 1 : p.Cout >> 7;
     const int nblk = gridDim.x, bq = nblk >> 3, brem = nblk & 7;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int lid = (xcd < brem ? xcd * (bq + 1) : brem * (bq + 1) + (xcd - brem) * bq) + slot;
-    const int co_tile = lid % n_co_tiles, strip = lid / n_co_tiles;
-    const int co_base = co_tile * 128;
+    const int co_tile = lid % n_co_tiles;
+    const int strip = PAIR ? (lid / n_co_tiles) * 2 + (wave >> 1) : lid / n_co_tiles;
+    const int co_base = PAIR ? 0 : co_tile * 128;
+    const int cow = PAIR ? (wave & 1) * 32 : wave * 32;  // this wave's cout rows inside the tile
+    const bool strip_ok = strip < ((p.B + n_img - 1) / n_img) * strips_per_img;
     const int img0 = (strip / strips_per_img) * n_img;
     const int row0 = (strip % strips_per_img) * R;
 
@@ -485,10 +491,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
     int poff[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) {
-        const int g = (q * 4 + wave) * 64 + lane;
+        const int g = PAIR ? (q * 2 + (wave & 1)) * 64 + lane : (q * 4 + wave) * 64 + lane;
         const int prow = g / 9, pos = g - prow * 9;
         poff[q] = -1;
-        if (pos < 8 && prow < NP) {
+        if (pos < 8 && prow < NP && strip_ok) {
             const int il = prow / ((R + 2) * Wp);
             const int rem = prow - il * ((R + 2) * Wp);
             const int pr = rem / Wp, pc = rem - pr * Wp;
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
     //      four 16-byte fragments (kk = 0..3) of W[co_base + wave*32 + r][tap][chunk*64 + (kk*2+hi)*8 ..] straight from L2 into
     //      registers, two steps ahead (register ring of 3 steps, index = tap % 3 at compile time).  This removes the weight
     //      tile from the LDS write AND read paths - LDS bandwidth (fragment reads + LDS-DMA writes) was the binding resource.
-    const half_t *wrow = p.w + (long)(co_base + wave * 32 + r) * Ktot + hi * 8;
+    const half_t *wrow = p.w + (long)(co_base + cow + r) * Ktot + hi * 8;
     // ---- B-fragment base addresses: pixel slot -> patch row of tap (0,0)
     int pbase[7];
 #pragma unroll
@@ -528,12 +534,12 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
     auto issue_patch = [&](int c, auto q0_c, auto nq_c) {
         constexpr int Q0 = decltype(q0_c)::value, NQ = decltype(nq_c)::value;
         const bool real = c < n_chunks;
-        char *pl = patch + (SINGLE ? 0 : (c & 1) * PATCH_B) + wave * 1024;
+        char *pl = patch + (SINGLE ? 0 : (c & 1) * PATCH_B) + (PAIR ? (wave & 1) : wave) * 1024;
 #pragma unroll
         for (int q = Q0; q < Q0 + NQ; ++q) {
             const half_t *src = (real && poff[q] >= 0) ? p.x + (unsigned)(poff[q] + (c << 6)) : p.zeros;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(pl + q * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(pl + q * (PAIR ? 2048 : 4096)), 16, 0, 0);
         }
     };
 
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
     constexpr int EROW = 36;  // floats per pixel row (32 + 4 pad)
     float *ep = reinterpret_cast<float *>(smem) + wave * (32 * EROW);
     const int chunk = lane & 3;
-    const int cch = co_base + wave * 32 + chunk * 8;
+    const int cch = co_base + cow + chunk * 8;
     floatx4 q0[2], q1[2], q2[2], q3[2];
     q0[0] = *reinterpret_cast<const floatx4 *>(p.p0 + cch);
     q0[1] = *reinterpret_cast<const floatx4 *>(p.p0 + cch + 4);
@@ -642,10 +648,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
             const int rr = (int)(((float)sl + 0.5f) * inv_wp);  // exact for sl < 2^20
             const int cc = sl - rr * Wp;
             m = m0 + rr * W + cc;
-            return rr < R && cc < W && m < Mtot;
+            return strip_ok && rr < R && cc < W && m < Mtot;
         }
         m = m0 + sl;
-        return sl < n_valid && m < Mtot;
+        return strip_ok && sl < n_valid && m < Mtot;
     };
     half8 sc8[7][2];
     if (p.mode == EPI_BN_ADD_BN) {  // stride 1: the shortcut has the output's geometry; all 14 loads in flight before the transposes
@@ -867,7 +873,10 @@ void launch_glds_t(const ConvMfmaArgs &a, hipStream_t s) {
 
 // strip geometry for the patch kernel; returns false when the layer is not eligible
 bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &single) {
-    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.Cout % 128 || a.Cin % 64 || a.splits != 1 || a.H != a.W) return false;
+    // pair mode measured: 56x56 layers 91-105 -> 87-95 us, but the 112x112 layer 306 -> 348 us (it is HBM-bound: 205 MB in, 205 MB
+    // out, and a 2-row strip re-reads its halo rows twice) - so the 112x112 layer stays on the im2col LDS-DMA kernel
+    const bool pair = a.Cout == 64 && a.Cin == 64 && a.H <= 56;
+    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || (a.Cout % 128 && !pair) || a.Cin % 64 || a.splits != 1 || a.H != a.W) return false;
     if (a.mode == EPI_PARTIAL) return false;
     if (a.mode == EPI_BN_ADD_BN && !(a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
     if (a.H * a.W <= 56) {
@@ -885,24 +894,25 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     const int slots = (NP * 9 + 255) / 256;
     single = a.Cin == 64;
     pps = slots;  // DMA slots (1 KB per wave each) the patch image needs
+    if (pair) return NP * 9 <= 34 * 128;
     if (single ? slots > 15 : slots > 12) return false;  // LDS budget, see launch_patch_t instantiations
     return true;
 }
 
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0>
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false>
 void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
-    const size_t lds = (size_t)(SINGLE ? 1 : 2) * PT * PPS * 4096;  // patch buffers only (NW is unused: weights live in registers)
-    static_assert((SINGLE ? 1 : 2) * PT * PPS * 4096 <= 160 * 1024 && PT * PPS * 4096 >= 4 * 32 * 36 * 4, "LDS budget / epilogue scratch");
+    const size_t lds = PAIR ? (size_t)2 * 34 * 2048 : (size_t)(SINGLE ? 1 : 2) * PT * PPS * 4096;  // patch buffers only (weights live in registers)
+    static_assert(PAIR || ((SINGLE ? 1 : 2) * PT * PPS * 4096 <= 160 * 1024 && PT * PPS * 4096 >= 4 * 32 * 36 * 4), "LDS budget / epilogue scratch");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     const int strips = ((a.B + n_img - 1) / n_img) * (a.H / R);
-    dim3 grid(strips * (a.Cout / 128));
+    dim3 grid(PAIR ? (strips + 1) / 2 : strips * (a.Cout / 128));
     const int linear = (n_img == 1 && R * (a.W + 2) <= 224) ? 1 : 0;
-    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL>), grid, dim3(256), lds, s, a, R, n_img, linear);
+    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR>), grid, dim3(256), lds, s, a, R, n_img, linear);
 }
 
 int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage (default: 64 KB ring, 2 workgroups per CU), 3 = LDS-DMA 3-stage
@@ -925,7 +935,8 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
     if (impl >= 2 && use_patch && patch_geometry(a, R, n_img, pps, single)) {
         const int slots = pps;
         static const int abl = getenv("FRT_CONV_ABLATE") ? atoi(getenv("FRT_CONV_ABLATE")) : 0;  // timing experiments only
-        if (single) return launch_patch_t<3, 5, 5, true>(a, R, n_img, s);            // 15 slots (60 KB) + 5 x 16 KB ring
+        if (a.Cout == 64) return launch_patch_t<3, 5, 5, true, 0, true>(a, R, n_img, s);  // pair mode: 2 strips x 68 KB patch
+        if (single) return launch_patch_t<3, 5, 5, true>(a, R, n_img, s);            // 15 slots (60 KB)
         if (slots <= 10) {                                                            // 2 x 40 KB patch + 5 x 16 KB ring = 160 KB
             if (abl == 1) return launch_patch_t<2, 5, 5, false, 1>(a, R, n_img, s);
             if (abl == 2) return launch_patch_t<2, 5, 5, false, 2>(a, R, n_img, s);
