@@ -500,6 +500,10 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
         }
         const half_t *sc_t = Y[cur];
         int sc_h = h, sc_stride = u.stride;
+        if (&u == &units[0]) {  // the input layer already wrote its raw output at the even positions only
+            sc_h = ho;
+            sc_stride = 1;
+        }
         if (u.wsc) {  // conv1x1 stride s + BN on the raw input
             ConvMfmaArgs a{};
             a.x = Y[cur];
@@ -578,6 +582,16 @@ struct frt_matcher {
     int q_cap = 0;
     size_t full_cap = 0;
     int blocks = 0;
+    // screened top-1 (fp16 shadow gallery; see kernels_match.hip).  Off for small galleries and with FRT_MATCH_SCREEN=0.
+    half_t *d_g16 = nullptr;
+    float gmax_norm = 0.f;
+    bool screen = false;
+    ScreenScratch scr{};
+    void free_screen_scratch() {
+        for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list, (void *)scr.count})
+            if (p) (void)hipFree(p);
+        scr = ScreenScratch{};
+    }
 
     void ensure_queries(int F) {
         if (F <= q_cap && d_partial) return;
@@ -590,13 +604,25 @@ struct frt_matcher {
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_sim), (size_t)cap * sizeof(float)));
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_idx), (size_t)cap * sizeof(int32_t)));
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_partial), (size_t)blocks * cap * sizeof(MatchPartial)));
+        if (screen) {
+            const size_t tiles = ((size_t)N + 127) / 128;
+            free_screen_scratch();
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.q16), (size_t)cap * D * sizeof(half_t)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tilemax), (size_t)cap * tiles * sizeof(float)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_flags), tiles * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_list), tiles * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.count), sizeof(int)));
+        }
         q_cap = cap;
     }
     // queries_dev [F][D] -> idx_dev, sim_dev (device pointers)
     void top1_dev(const float *queries_dev, int F, int32_t *idx_dev, float *sim_dev, hipStream_t s) {
         ProfScope ps(2, "match_top1", 2.0 * D * (double)N * F, s);
         // the partial scratch is [blocks][F]
-        launch_match_top1(d_gallery, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, 0, s);
+        if (screen)
+            launch_match_top1_screened(d_gallery, d_g16, N, D, queries_dev, F, gmax_norm, scr, d_partial, blocks, idx_dev, sim_dev, 0, s);
+        else
+            launch_match_top1(d_gallery, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, 0, s);
     }
 };
 
@@ -970,8 +996,9 @@ void frt_matcher_destroy(frt_matcher *m) {
         (void)hipStreamSynchronize(m->stream);
         (void)hipStreamDestroy(m->stream);
     }
-    for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full})
+    for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full, (void *)m->d_g16})
         if (p) (void)hipFree(p);
+    m->free_screen_scratch();
     delete m;
 }
 
@@ -991,6 +1018,23 @@ int frt_matcher_init(frt_matcher *m, const float *gallery, int num_row, int num_
             HIPCHK(hipMemcpy(m->d_gallery, gallery, (size_t)num_row * num_col * sizeof(float), hipMemcpyHostToDevice));
         }
         m->blocks = match_top1_blocks(num_row, 0);
+        if (m->d_g16) (void)hipFree(m->d_g16);
+        m->d_g16 = nullptr;
+        const char *scr_env = getenv("FRT_MATCH_SCREEN");
+        m->screen = num_row >= 32768 && !(scr_env && scr_env[0] == '0');
+        if (m->screen) {  // fp16 shadow copy + the largest row norm (for the rounding bound of the screening pass)
+            int *d_bits = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_g16), (size_t)num_row * num_col * sizeof(half_t)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_bits), sizeof(int)));
+            launch_gallery_shadow(m->d_gallery, num_row, num_col, m->d_g16, d_bits, m->stream);
+            int bits = 0;
+            HIPCHK(hipMemcpyAsync(&bits, d_bits, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            HIPCHK(hipStreamSynchronize(m->stream));
+            (void)hipFree(d_bits);
+            float n2;
+            std::memcpy(&n2, &bits, 4);
+            m->gmax_norm = std::sqrt(n2);
+        }
         m->q_cap = 0;  // partial scratch depends on `blocks`
         if (m->d_partial) {
             (void)hipFree(m->d_partial);

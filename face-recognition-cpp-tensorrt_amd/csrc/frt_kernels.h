@@ -20,6 +20,18 @@ struct MatchPartial {  // one per (workgroup, query)
 void launch_match_top1(const float *gallery, int N, int D, const float *queries, int F, MatchPartial *partial, int partial_blocks,
                        int32_t *idx_out, float *sim_out, int row_offset, hipStream_t s);
 int match_top1_blocks(int N, int F);
+// screened top-1: fp16 shadow gallery + coarse MFMA pass + exact re-rank of the few tiles that can hold the maximum
+struct ScreenScratch {
+    half_t *q16;       // [F][D]
+    float *tilemax;    // [F][tiles]
+    int *tile_flags;   // [tiles]
+    int *tile_list;    // [tiles]
+    int *count;        // [1]
+};
+void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int *max_norm2_bits, hipStream_t s);
+void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
+                                const ScreenScratch &w, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
+                                int row_offset, hipStream_t s);
 // full matrix: out[F][N]
 void launch_match_full(const float *gallery, int N, int D, const float *queries, int F, float *out, hipStream_t s);
 
@@ -103,7 +115,7 @@ struct ArcInputArgs {
     const float *s0, *b0; // folded BN after the conv
     const float *slope;   // PReLU
     const float *s1, *b1; // next unit's leading BN
-    half_t *y, *z;        // [F][112][112][64]
+    half_t *y, *z;        // z [F][112][112][64]; y (shortcut of unit 0) only at even positions: [F][56][56][64]
     int F, H, W;
 };
 void launch_arc_input(const ArcInputArgs &a, hipStream_t s);

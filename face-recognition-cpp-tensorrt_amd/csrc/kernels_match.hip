@@ -29,7 +29,9 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { retur
 template <int NQ, bool FULL>
 __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ G, int N, int D, const float *__restrict__ E, int F,
                                                     MatchPartial *__restrict__ partial, float *__restrict__ out_full, int num_tiles,
-                                                    int row_offset) {
+                                                    int row_offset, const int *__restrict__ tile_list, const int *__restrict__ d_num_tiles) {
+    // tile_list != nullptr: run only over the listed 128-row gallery tiles (num_tiles = list length): the exact re-rank pass of
+    // the screened top-1 (same code path per tile as the full scan -> bitwise-identical similarities)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *As = reinterpret_cast<float *>(smem);                        // [2][BM][BK]
     float *Bs = reinterpret_cast<float *>(smem) + 2 * BM * BK;          // [2][NQ*32][BK]
@@ -40,14 +42,16 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ G,
     const int q0 = blockIdx.y * QT;
     const int ksteps = D / BK;
 
-    const int my_tiles = (num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (tile_list) num_tiles = *d_num_tiles;  // list length produced on the device by the screening pass
+    const int my_tiles = num_tiles > (int)blockIdx.x ? (num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int total = my_tiles * ksteps;
 
     const int ld_row = tid >> 3, ld_ch = tid & 7;
 
     floatx4 ga[4], qa[NQ];
     auto load_global = [&](int it) {
-        const int tile = blockIdx.x + (it / ksteps) * gridDim.x;
+        int tile = blockIdx.x + (it / ksteps) * gridDim.x;
+        if (tile_list) tile = tile_list[tile];
         const int k0 = (it % ksteps) * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -119,7 +123,8 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ G,
         }
         if (it + 1 < total) store_lds(cur ^ 1);
         if ((it % ksteps) == ksteps - 1) {  // tile finished: epilogue
-            const int tile = blockIdx.x + (it / ksteps) * gridDim.x;
+            int tile = blockIdx.x + (it / ksteps) * gridDim.x;
+            if (tile_list) tile = tile_list[tile];
             const int gbase = tile * BM + wave * 32;
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ G,
                 MatchPartial p;
                 p.sim = v;
                 p.idx = i == INT_MAX ? -1 : i + row_offset;
-                partial[(long)blockIdx.x * F + q] = p;
+                partial[(long)blockIdx.x * F + q] = p;  // (blocks beyond a short tile list write the empty record)
             }
         }
     }
@@ -214,9 +219,154 @@ __global__ __launch_bounds__(64) void match_reduce_kernel(const MatchPartial *__
     }
 }
 
+// ---------------------------------------------------------------- screened top-1: fp16 coarse pass + exact re-rank of a few tiles
+// The exact fp32 scan above is bound by the fp32 matrix rate for a 128-face batch (2*512*N*F flop at <= 157 TF/s).  Screening
+// makes the common case HBM-bound instead without changing a single result bit:
+//   1. coarse: S~[q][g] on v_mfma_f32_32x32x16_f16 from an fp16 shadow copy of the gallery (half the bytes, 16x the matrix
+//      rate); only the maximum per (query, 128-row tile) is kept;
+//   2. select: with fp16-rounded inputs and fp32 accumulation |S~ - S| <= delta_q = 1.2e-3 * ||q|| * max_g ||g|| (2^-10 from the
+//      two roundings via Cauchy-Schwarz, plus accumulation slack), so every row that attains the exact maximum of query q lives
+//      in a tile whose coarse maximum is >= (best coarse maximum of q) - 2*delta_q.  Those tiles go on a list (each once);
+//   3. exact: match_kernel runs over the listed tiles only, for all queries - the same code path per tile as the full scan,
+//      so similarities are bitwise those of the full scan and the first-index tie rule is unchanged.  Extra tiles are harmless.
+constexpr int CBK = 64;  // halfs per k-step of the coarse kernel (128-byte rows)
+
+__global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ in, half_t *__restrict__ out, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const floatx4 a = *reinterpret_cast<const floatx4 *>(in + i * 8), b = *reinterpret_cast<const floatx4 *>(in + i * 8 + 4);
+    half8 o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+    *reinterpret_cast<half8 *>(out + i * 8) = o;
+}
+
+// max over rows of ||g||^2 (non-negative floats order like their bit patterns -> atomicMax on the int view); one wave per row
+__global__ __launch_bounds__(256) void row_norm_max_kernel(const float *__restrict__ G, int N, int D, int *__restrict__ out_bits) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float s = 0.f;
+    for (int k = lane * 4; k < D; k += 256) {
+        const floatx4 v = *reinterpret_cast<const floatx4 *>(G + (long)row * D + k);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) atomicMax(out_bits, __float_as_int(s));
+}
+
+__global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restrict__ G, int N, int D, const half_t *__restrict__ Q, int F,
+                                                           float *__restrict__ tilemax, int num_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t *As = reinterpret_cast<half_t *>(smem);                 // [2][128][64]
+    half_t *Bs = As + 2 * 128 * CBK;                               // [2][128][64]
+    float *red = reinterpret_cast<float *>(Bs + 2 * 128 * CBK);    // [4][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int q0 = blockIdx.y * 128;
+    const int ksteps = D / CBK;
+    const int my_tiles = num_tiles > (int)blockIdx.x ? (num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int total = my_tiles * ksteps;
+    const int ld_row = tid >> 3, ld_ch = tid & 7;
+    half8 ga[4], qa[4];
+    auto load_global = [&](int it) {
+        const int tile = blockIdx.x + (it / ksteps) * gridDim.x;
+        const int k0 = (it % ksteps) * CBK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long g = (long)tile * 128 + ld_row + 32 * i;
+            ga[i] = g < N ? *reinterpret_cast<const half8 *>(G + g * D + k0 + ld_ch * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+            const int q = q0 + ld_row + 32 * i;
+            qa[i] = q < F ? *reinterpret_cast<const half8 *>(Q + (long)q * D + k0 + ld_ch * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = ld_row + 32 * i;
+            *reinterpret_cast<half8 *>(As + buf * 128 * CBK + row * CBK + swz(row, ld_ch) * 8) = ga[i];
+            *reinterpret_cast<half8 *>(Bs + buf * 128 * CBK + row * CBK + swz(row, ld_ch) * 8) = qa[i];
+        }
+    };
+    floatx16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+    if (total > 0) {
+        load_global(0);
+        store_lds(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < total; ++it) {
+        if (it + 1 < total) load_global(it + 1);
+        const half_t *Ab = As + cur * 128 * CBK, *Bb = Bs + cur * 128 * CBK;
+        const int arow = wave * 32 + r;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ch = kk * 2 + hi;
+            const half8 a8 = *reinterpret_cast<const half8 *>(Ab + arow * CBK + swz(arow, ch) * 8);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int brow = n * 32 + r;
+                const half8 b8 = *reinterpret_cast<const half8 *>(Bb + brow * CBK + swz(brow, ch) * 8);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[n], 0, 0, 0);
+            }
+        }
+        if (it + 1 < total) store_lds(cur ^ 1);
+        const bool last = (it % ksteps) == ksteps - 1;
+        const int tile = blockIdx.x + (it / ksteps) * gridDim.x;
+        if (last) {  // per-query maximum over this wave's 32 gallery rows (rows beyond N are excluded)
+            const int gbase = tile * 128 + wave * 32;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int g = gbase + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    if (g < N) m = fmaxf(m, acc[n][e]);
+                    acc[n][e] = 0.f;
+                }
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (hi == 0) red[wave * 128 + n * 32 + r] = m;
+            }
+        }
+        __syncthreads();
+        if (last && tid < 128 && q0 + tid < F)
+            tilemax[(long)(q0 + tid) * num_tiles + tile] = fmaxf(fmaxf(red[tid], red[128 + tid]), fmaxf(red[256 + tid], red[384 + tid]));
+        cur ^= 1;
+    }
+}
+
+// one workgroup per query: best coarse tile maximum, ||q||, then every tile within 2*delta of the best goes on the list (once)
+__global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ tilemax, int num_tiles, const float *__restrict__ Q, int D,
+                                                           float gmax_norm, int *__restrict__ tile_flags, int *__restrict__ tile_list,
+                                                           int *__restrict__ count) {
+    __shared__ float sm[8];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float *row = tilemax + (long)q * num_tiles;
+    float m = -INFINITY, n2 = 0.f;
+    for (int t = tid; t < num_tiles; t += 256) m = fmaxf(m, row[t]);
+    for (int k = tid; k < D; k += 256) n2 += Q[(long)q * D + k] * Q[(long)q * D + k];
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off));
+        n2 += __shfl_xor(n2, off);
+    }
+    if ((tid & 63) == 0) {
+        sm[tid >> 6] = m;
+        sm[4 + (tid >> 6)] = n2;
+    }
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    const float qn = sqrtf(sm[4] + sm[5] + sm[6] + sm[7]);
+    const float delta = 1.2e-3f * qn * gmax_norm;
+    // fp16 overflow / non-finite inputs: no valid bound -> take every tile (degenerates to the exact full scan)
+    const float thr = (qn < 6.0e4f && gmax_norm < 6.0e4f && m == m && m > -INFINITY && m < INFINITY) ? m - 2.f * delta : -INFINITY;
+    for (int t = tid; t < num_tiles; t += 256)
+        if (!(row[t] < thr) && atomicExch(&tile_flags[t], 1) == 0) tile_list[atomicAdd(count, 1)] = t;
+}
+
 template <int NQ, bool FULL>
 void launch_t(const float *G, int N, int D, const float *E, int F, MatchPartial *partial, float *out_full, int blocks, int row_offset,
-              hipStream_t s) {
+              hipStream_t s, const int *tile_list = nullptr, const int *d_num_tiles = nullptr) {
     const int tiles = (N + BM - 1) / BM;
     const size_t lds = (size_t)2 * (BM + NQ * 32) * BK * sizeof(float);
     static bool attr_done = false;
@@ -225,7 +375,7 @@ void launch_t(const float *G, int N, int D, const float *E, int F, MatchPartial 
         attr_done = true;
     }
     dim3 grid(blocks, (F + NQ * 32 - 1) / (NQ * 32));
-    hipLaunchKernelGGL((match_kernel<NQ, FULL>), grid, dim3(256), lds, s, G, N, D, E, F, partial, out_full, tiles, row_offset);
+    hipLaunchKernelGGL((match_kernel<NQ, FULL>), grid, dim3(256), lds, s, G, N, D, E, F, partial, out_full, tiles, row_offset, tile_list, d_num_tiles);
 }
 
 }  // namespace
@@ -254,4 +404,39 @@ void launch_match_full(const float *gallery, int N, int D, const float *queries,
         launch_t<1, true>(gallery, N, D, queries, F, nullptr, out, blocks, 0, s);
     else
         launch_t<4, true>(gallery, N, D, queries, F, nullptr, out, blocks, 0, s);
+}
+
+// ---------------------------------------------------------------- screened top-1 (host side)
+void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int *max_norm2_bits, hipStream_t s) {
+    (void)hipMemsetAsync(max_norm2_bits, 0, sizeof(int), s);
+    const long n8 = (long)N * D / 8;
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, gallery, g16, n8);
+    hipLaunchKernelGGL(row_norm_max_kernel, dim3((N + 3) / 4), dim3(256), 0, s, gallery, N, D, max_norm2_bits);
+}
+
+void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
+                                const ScreenScratch &w, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
+                                int row_offset, hipStream_t s) {
+    const int tiles = (N + BM - 1) / BM;
+    (void)hipMemsetAsync(w.tile_flags, 0, sizeof(int) * (size_t)tiles, s);
+    (void)hipMemsetAsync(w.count, 0, sizeof(int), s);
+    const long q8 = (long)F * D / 8;
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((q8 + 255) / 256)), dim3(256), 0, s, queries, w.q16, q8);
+    const size_t lds = (size_t)4 * 128 * CBK * sizeof(half_t) + 4 * 128 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 cgrid(tiles < 1024 ? tiles : 1024, (F + 127) / 128);
+    hipLaunchKernelGGL(match_coarse_kernel, cgrid, dim3(256), lds, s, g16, N, D, w.q16, F, w.tilemax, tiles);
+    hipLaunchKernelGGL(match_select_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles, queries, D, gmax_norm, w.tile_flags, w.tile_list, w.count);
+    // exact re-rank over the listed tiles (count lives on the device); the partial scratch is [partial_blocks][F]
+    if (F <= 32)
+        launch_t<1, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
+    else if (F <= 64)
+        launch_t<2, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
+    else
+        launch_t<4, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out);
 }

@@ -74,3 +74,30 @@ def test_one_million_gallery_properties(frt, synth, mm):
     from oracle import match
     oi, osim = match.top1(q[:2], g)
     assert np.array_equal(oi, i[:2]) and np.abs(osim - s[:2]).max() < 1e-5
+
+
+def test_screened_top1_is_bit_identical_to_the_exact_scan(frt, synth, mm):
+    """N >= 32768 takes the fp16-screened path: it must return exactly what the full exact-fp32 scan returns, also when many
+    rows sit inside the fp16 rounding band of the maximum, for non-unit norms, and for the first-index rule."""
+    N = 40000 + 77
+    r = np.random.Generator(np.random.PCG64(99))
+    g = synth.make_gallery(N)
+    g *= r.uniform(0.1, 30.0, (N, 1)).astype(np.float32)            # row norms from 0.1 to 30
+    base = g[100].copy()
+    for k, row in enumerate(range(20000, 20064)):                    # 64 near-duplicates of row 100: similarities within ~1e-4
+        g[row] = base * np.float32(1 + 1e-5 * (k % 7)) + np.float32(1e-5) * r.standard_normal(512).astype(np.float32)
+    g[39000] = g[123]                                                # exact duplicate far away: index 123 must win
+    g[5] = 0                                                         # a zero row
+    q = np.concatenate([synth.make_queries(g, [100, 123, 39000, 20010, 7], noise=0.0),
+                        7.5 * synth.make_queries(g, [31000, 64, 40076], noise=0.05),  # non-unit query norms
+                        r.standard_normal((24, 512)).astype(np.float32)])             # unrelated queries: tiny margins
+    mm.init(g)
+    i, s = mm.top1(q)
+    full = mm.calculate(q)                                           # exact fp32 scan (full matrix)
+    assert np.array_equal(i, full.argmax(1).astype(np.int32))
+    assert np.array_equal(s, full.max(1))
+    assert i[1] == 123 and i[2] == 123
+    from oracle import match
+    oi, osim = match.top1(q, g)
+    agree = (oi == i)
+    assert agree.mean() > 0.9 and np.abs(osim - s).max() < 2e-3 * np.abs(osim).max()  # NumPy sums in another order: near-ties may differ
