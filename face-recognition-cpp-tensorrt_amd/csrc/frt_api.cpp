@@ -495,7 +495,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             a.out0 = T;
             a.splits = 1;
             a.zeros = zeros;
-            ProfScope pk(1, "conv3x3_mfma", 2.0 * 9 * u.cin * u.depth * (double)F * h * h, s);
+            ProfScope pk(1, conv_kernel_label(a), 2.0 * 9 * u.cin * u.depth * (double)F * h * h, s);
             launch_conv_mfma(a, s);
         }
         const half_t *sc_t = Y[cur];
@@ -542,7 +542,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
                 a.out0 = RES;
             }
             {
-                ProfScope pk(1, "conv3x3_mfma", 2.0 * 9 * u.depth * u.depth * (double)F * ho * ho, s);
+                ProfScope pk(1, conv_kernel_label(a), 2.0 * 9 * u.depth * u.depth * (double)F * ho * ho, s);
                 launch_conv_mfma(a, s);
             }
             if (se) {

@@ -109,6 +109,7 @@ struct ConvMfmaArgs {
     const half_t *zeros;  // >= 16 bytes of zeros (source of padded taps for the LDS-DMA path)
 };
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
+const char *conv_kernel_label(const ConvMfmaArgs &a);  // kernel symbol (as rocprofv3 prints it) a launch resolves to
 struct ArcInputArgs {
     const float *x;       // [F][3][112][112] planar RGB
     const float *w;       // [27][64]  (k = ci*9 + kh*3 + kw)

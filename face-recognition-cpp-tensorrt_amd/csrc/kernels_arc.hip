@@ -929,40 +929,56 @@ int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage
 
 }  // namespace
 
-void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
+// Which kernel symbol a launch resolves to (also the profiling label, so bench.py / rocprofv3 can be matched by name).
+enum { CV_V1_22, CV_V1_14, CV_G2_22, CV_G2_14, CV_G3_22, CV_G3_14, CV_P_PAIR, CV_P_SINGLE, CV_P_255, CV_P_264 };
+static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
     const int impl = conv_impl();
     static const int use_patch = getenv("FRT_CONV_PATCH") ? atoi(getenv("FRT_CONV_PATCH")) : 1;
-    int R, n_img, pps;
+    int slots;
     bool single;
-    if (impl >= 2 && use_patch && patch_geometry(a, R, n_img, pps, single)) {
-        const int slots = pps;
-        static const int abl = getenv("FRT_CONV_ABLATE") ? atoi(getenv("FRT_CONV_ABLATE")) : 0;  // timing experiments only
-        if (a.Cout == 64) return launch_patch_t<3, 5, 5, true, 0, true>(a, R, n_img, s);  // pair mode: 2 strips x 68 KB patch
-        if (single) return launch_patch_t<3, 5, 5, true>(a, R, n_img, s);            // 15 slots (60 KB)
-        if (slots <= 10) {                                                            // 2 x 40 KB patch + 5 x 16 KB ring = 160 KB
+    if (impl >= 2 && use_patch && patch_geometry(a, R, n_img, slots, single)) {
+        if (a.Cout == 64) return CV_P_PAIR;   // pair mode: 2 strips x 68 KB patch
+        if (single) return CV_P_SINGLE;       // 15 slots (60 KB)
+        return slots <= 10 ? CV_P_255 : CV_P_264;  // 2 x 40 KB / 2 x 48 KB patch buffers
+    }
+    const bool wide = a.Cout % 128 == 0;
+    if (impl == 1) return wide ? CV_V1_22 : CV_V1_14;
+    if (impl == 2) return wide ? CV_G2_22 : CV_G2_14;
+    return wide ? CV_G3_22 : CV_G3_14;
+}
+
+const char *conv_kernel_label(const ConvMfmaArgs &a) {
+    static const char *names[] = {"conv_mfma_kernel<2, 2>", "conv_mfma_kernel<1, 4>", "conv_glds_kernel<2, 2, 2, 0>", "conv_glds_kernel<1, 4, 2, 0>",
+                                  "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true>",
+                                  "conv_patch_kernel<3, 5, 5, true, 0, false>", "conv_patch_kernel<2, 5, 5, false, 0, false>",
+                                  "conv_patch_kernel<2, 6, 4, false, 0, false>"};
+    int R, n_img;
+    return names[conv_variant(a, R, n_img)];
+}
+
+void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
+    int R = 0, n_img = 0;
+    const int v = conv_variant(a, R, n_img);
+    static const int abl = getenv("FRT_CONV_ABLATE") ? atoi(getenv("FRT_CONV_ABLATE")) : 0;  // timing experiments only
+    switch (v) {
+        case CV_P_PAIR: return launch_patch_t<3, 5, 5, true, 0, true>(a, R, n_img, s);
+        case CV_P_SINGLE: return launch_patch_t<3, 5, 5, true>(a, R, n_img, s);
+        case CV_P_255:
             if (abl == 1) return launch_patch_t<2, 5, 5, false, 1>(a, R, n_img, s);
             if (abl == 2) return launch_patch_t<2, 5, 5, false, 2>(a, R, n_img, s);
             if (abl == 4) return launch_patch_t<2, 5, 5, false, 4>(a, R, n_img, s);
             if (abl == 5) return launch_patch_t<2, 5, 5, false, 5>(a, R, n_img, s);
-            if (abl == 6) return launch_patch_t<2, 5, 5, false, 6>(a, R, n_img, s);
-            if (abl == 7) return launch_patch_t<2, 5, 5, false, 7>(a, R, n_img, s);
             return launch_patch_t<2, 5, 5, false>(a, R, n_img, s);
-        }
-        return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);                       // 2 x 48 KB patch + 4 x 16 KB ring = 160 KB
-    }
-    const bool wide = a.Cout % 128 == 0;
-    if (impl == 1) {
-        if (wide) launch_conv_t<2, 2>(a, s);
-        else launch_conv_t<1, 4>(a, s);
-    } else if (impl == 2) {
-        static const int abl = getenv("FRT_CONV_ABLATE") ? atoi(getenv("FRT_CONV_ABLATE")) : 0;  // timing experiments only
-        if (wide && abl == 1) return launch_glds_t<2, 2, 2, 1>(a, s);
-        if (wide && abl == 2) return launch_glds_t<2, 2, 2, 2>(a, s);
-        if (wide) launch_glds_t<2, 2, 2>(a, s);
-        else launch_glds_t<1, 4, 2>(a, s);
-    } else {
-        if (wide) launch_glds_t<2, 2, 3>(a, s);
-        else launch_glds_t<1, 4, 3>(a, s);
+        case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
+        case CV_V1_22: return launch_conv_t<2, 2>(a, s);
+        case CV_V1_14: return launch_conv_t<1, 4>(a, s);
+        case CV_G2_22:
+            if (abl == 1) return launch_glds_t<2, 2, 2, 1>(a, s);
+            if (abl == 2) return launch_glds_t<2, 2, 2, 2>(a, s);
+            return launch_glds_t<2, 2, 2>(a, s);
+        case CV_G2_14: return launch_glds_t<1, 4, 2>(a, s);
+        case CV_G3_22: return launch_glds_t<2, 2, 3>(a, s);
+        default: return launch_glds_t<1, 4, 3>(a, s);
     }
 }
 

@@ -242,14 +242,16 @@ __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ 
 // max over rows of ||g||^2 (non-negative floats order like their bit patterns -> atomicMax on the int view); one wave per row
 __global__ __launch_bounds__(256) void row_norm_max_kernel(const float *__restrict__ G, int N, int D, int *__restrict__ out_bits) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= N) return;
     float s = 0.f;
-    for (int k = lane * 4; k < D; k += 256) {
+    for (int k = lane * 4; k < D && row < N; k += 256) {
         const floatx4 v = *reinterpret_cast<const floatx4 *>(G + (long)row * D + k);
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) atomicMax(out_bits, __float_as_int(s));
+    __shared__ float wmax[4];
+    if (lane == 0) wmax[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out_bits, __float_as_int(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restrict__ G, int N, int D, const half_t *__restrict__ Q, int F,
