@@ -61,6 +61,7 @@ ABI = {
     "frt_matcher_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "frt_matcher_destroy": (None, [_vp]),
     "frt_matcher_init": (_i, [_vp, _vp, _i, _i]),
+    "frt_matcher_set_row_offset": (_i, [_vp, _i]),
     "frt_matcher_calculate": (_i, [_vp, _vp, _i, _vp]),
     "frt_matcher_top1": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_merge_top1": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -120,6 +121,10 @@ class MatMul:
         numCol = g.shape[1] if numCol is None else numCol
         _check(lib.frt_matcher_init(self._h, _ptr(g), int(numRow), int(numCol)))
         self.m, self.k = int(numRow), int(numCol)
+
+    def setRowOffset(self, row_offset):
+        """Sharded gallery: local row 0 is global row ``row_offset`` (top-1 indices become global)."""
+        _check(lib.frt_matcher_set_row_offset(self._h, int(row_offset)))
 
     def calculate(self, embeds, embedCount=None):
         e = np.ascontiguousarray(embeds, np.float32).reshape(-1, self.k)

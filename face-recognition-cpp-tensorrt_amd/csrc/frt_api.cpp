@@ -575,6 +575,7 @@ struct frt_matcher {
     std::mutex mu;
     float *d_gallery = nullptr;
     int N = 0, D = 0;
+    int row_offset = 0;  // global index of local row 0 (sharded galleries)
     // scratch (grown on demand)
     float *d_q = nullptr, *d_sim = nullptr, *d_full = nullptr;
     int32_t *d_idx = nullptr;
@@ -620,9 +621,9 @@ struct frt_matcher {
         ProfScope ps(2, "match_top1", 2.0 * D * (double)N * F, s);
         // the partial scratch is [blocks][F]
         if (screen)
-            launch_match_top1_screened(d_gallery, d_g16, N, D, queries_dev, F, gmax_norm, scr, d_partial, blocks, idx_dev, sim_dev, 0, s);
+            launch_match_top1_screened(d_gallery, d_g16, N, D, queries_dev, F, gmax_norm, scr, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
         else
-            launch_match_top1(d_gallery, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, 0, s);
+            launch_match_top1(d_gallery, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
     }
 };
 
@@ -1040,6 +1041,14 @@ int frt_matcher_init(frt_matcher *m, const float *gallery, int num_row, int num_
             (void)hipFree(m->d_partial);
             m->d_partial = nullptr;
         }
+    });
+}
+
+int frt_matcher_set_row_offset(frt_matcher *m, int row_offset) {
+    return guarded([&] {
+        if (!m || row_offset < 0) raise(FRT_ERR_INVALID, "set_row_offset: bad argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->row_offset = row_offset;
     });
 }
 

@@ -124,6 +124,9 @@ int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, 
 /* Fused calculate + getOutputs argmax: idx_out[i] = FIRST j maximising the similarity (std::max_element semantics),
  * sim_out[i] = that similarity.  Never materialises the [n x num_row] matrix. */
 int frt_matcher_top1(frt_matcher *m, const float *embeds, int embed_count, int32_t *idx_out, float *sim_out);
+/* Sharded galleries: declare that local row 0 of this matcher is global row `row_offset`; top-1
+ * indices (frt_matcher_top1, the pipeline's match_idx) are then global.  The full matrix of calculate() stays local. */
+int frt_matcher_set_row_offset(frt_matcher *m, int row_offset);
 /* Sharded-gallery variant: rows of this matcher are global rows [row_offset, row_offset+num_row).
  * Merges with an existing (idx, sim) pair per query, keeping the higher similarity and the LOWER global index on ties. */
 int frt_merge_top1(int n, const int32_t *idx_a, const float *sim_a, const int32_t *idx_b, const float *sim_b, int32_t *idx_out,

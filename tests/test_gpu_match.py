@@ -101,3 +101,27 @@ def test_screened_top1_is_bit_identical_to_the_exact_scan(frt, synth, mm):
     oi, osim = match.top1(q, g)
     agree = (oi == i)
     assert agree.mean() > 0.9 and np.abs(osim - s).max() < 2e-3 * np.abs(osim).max()  # NumPy sums in another order: near-ties may differ
+
+
+@pytest.mark.parametrize("N", [5000, 70001])
+def test_sharded_gallery_merge_equals_single_gallery(frt, synth, N):
+    """Config 5 on one GPU: two matchers own disjoint row ranges (global indices via setRowOffset); the first-maximum merge of
+    their winners must equal the single-gallery answer, duplicates across the shard boundary included."""
+    g = synth.make_gallery(N)
+    cut = N // 2 + 13
+    g[cut + 5] = g[7]          # duplicate across shards: global index 7 wins
+    g[cut - 1] = g[cut]        # duplicates straddling the boundary: cut-1 wins
+    q = synth.make_queries(g, [7, cut + 5, cut, cut - 1, N - 1, 0], noise=0.0)
+    whole, a, b = frt.MatMul(0), frt.MatMul(0), frt.MatMul(0)
+    whole.init(g)
+    a.init(g[:cut])
+    b.init(g[cut:])
+    b.setRowOffset(cut)
+    wi, ws = whole.top1(q)
+    ai, as_ = a.top1(q)
+    bi, bs = b.top1(q)
+    mi, ms = frt.merge_top1(ai, as_, bi, bs)
+    assert np.array_equal(mi, wi) and np.array_equal(ms, ws)
+    assert wi.tolist() == [7, 7, cut - 1, cut - 1, N - 1, 0]
+    for m in (whole, a, b):
+        m.close()
