@@ -72,6 +72,12 @@ ABI = {
     "frt_pipeline_sync": (_i, [_vp]),
     "frt_pipeline_set_stream": (_i, [_vp, _vp]),
     "frt_pipeline_set_overlap": (_i, [_vp, _i]),
+    "frt_detector_has_landmarks": (_i, [_vp]),
+    "frt_detector_find_faces_landmarks": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _vp]),
+    "frt_detector_infer_landmarks": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "frt_align_faces": (_i, [_vp, _i, _i, _sz, _vp, _i, _vp, _i]),
+    "frt_embedder_forward_aligned": (_i, [_vp, _vp, _i, _i, _sz, _vp, _i, _vp, _vp]),
+    "frt_pipeline_set_align": (_i, [_vp, _i]),
     "frt_profile_enable": (_i, [_i]),
     "frt_profile_collect": (_i, [_vp, _sz, _vp, _vp, _i]),
 }
@@ -175,6 +181,27 @@ class RetinaFace:
         _check(lib.frt_detector_create(os.fsencode(engineFile), self.frameWidth, self.frameHeight, *self.inputShape, self.maxBatchSize,
                                        self.maxFacesPerScene, nms_threshold, bbox_threshold, device, ctypes.byref(self._h)))
         self.numAnchors = lib.frt_detector_num_anchors(self._h)
+        self.hasLandmarks = bool(lib.frt_detector_has_landmarks(self._h))
+
+    # ---- optional alignment mode (no counterpart in the reference, see include/frt.h)
+    def findFaceLandmarks(self, img):
+        """-> (boxes, landmarks [n][5][2] as (x=col, y=row) frame pixels)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros(self.maxFacesPerScene, BBOX_DTYPE)
+        ldm = np.zeros((self.maxFacesPerScene, 5, 2), np.float32)
+        n = ctypes.c_int(0)
+        _check(lib.frt_detector_find_faces_landmarks(self._h, _ptr(img), img.shape[0], img.shape[1], img.strides[0], _ptr(out), _ptr(ldm),
+                                                     ctypes.byref(n)))
+        return out[:n.value].copy(), ldm[:n.value].copy()
+
+    def doInferenceLandmarks(self, chw):
+        x = np.ascontiguousarray(chw, np.float32).reshape((-1,) + self.inputShape)
+        b = x.shape[0]
+        loc = np.empty((b, self.numAnchors, 4), np.float32)
+        conf = np.empty((b, self.numAnchors, 2), np.float32)
+        ldm = np.empty((b, self.numAnchors, 10), np.float32)
+        _check(lib.frt_detector_infer_landmarks(self._h, _ptr(x), b, _ptr(loc), _ptr(conf), _ptr(ldm)))
+        return loc, conf, ldm
 
     def findFace(self, img):
         img = np.ascontiguousarray(img, np.uint8)
@@ -233,6 +260,15 @@ def getCroppedFaces(frame, outputBbox, resize_w=112, resize_h=112, device=0):
     out = np.zeros((len(boxes), resize_h, resize_w, 3), np.uint8)
     _check(lib.frt_crop_faces(_ptr(frame), frame.shape[0], frame.shape[1], frame.strides[0], _ptr(boxes), len(boxes), resize_w, resize_h,
                               _ptr(out), device))
+    return out
+
+
+def alignFaces(frame, landmarks, device=0):
+    """Optional alignment mode: 5-point similarity warp to the ArcFace template -> u8 BGR [n][112][112][3]."""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    lm = np.ascontiguousarray(landmarks, np.float32).reshape(-1, 10)
+    out = np.zeros((len(lm), 112, 112, 3), np.uint8)
+    _check(lib.frt_align_faces(_ptr(frame), frame.shape[0], frame.shape[1], frame.strides[0], _ptr(lm), len(lm), _ptr(out), device))
     return out
 
 
@@ -311,6 +347,22 @@ class ArcFaceIR50:
         self.croppedFaces = [dict(face=crops[i], x1=int(b["x1"]), y1=int(b["y1"]), x2=int(b["x2"]), y2=int(b["y2"])) for i, b in enumerate(boxes)]
         return embeds
 
+    def forwardAligned(self, image, outputBbox, landmarks):
+        """``forward`` with the optional aligned crop (boxes are only carried into ``croppedFaces``)."""
+        image = np.ascontiguousarray(image, np.uint8)
+        boxes = np.ascontiguousarray(outputBbox, BBOX_DTYPE)
+        lm = np.ascontiguousarray(landmarks, np.float32).reshape(-1, 10)
+        n = len(lm)
+        assert len(boxes) == n
+        embeds = np.zeros((n, self.outputDim), np.float32)
+        crops = np.zeros((n, 112, 112, 3), np.uint8)
+        if n:
+            _check(lib.frt_embedder_forward_aligned(self._h, _ptr(image), image.shape[0], image.shape[1], image.strides[0], _ptr(lm), n,
+                                                    _ptr(embeds), _ptr(crops)))
+        self._embeds = embeds
+        self.croppedFaces = [dict(face=crops[i], x1=int(b["x1"]), y1=int(b["y1"]), x2=int(b["x2"]), y2=int(b["y2"])) for i, b in enumerate(boxes)]
+        return embeds
+
     def featureMatching(self):
         if not len(self.classNames) or not self.croppedFaces:
             raise FrtError(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found")  # arcface.cpp:198
@@ -370,6 +422,10 @@ class Pipeline:
     def set_overlap(self, enable):
         """Two-stream software pipelining of consecutive calls (detector of call b+1 under embed/match of call b)."""
         _check(lib.frt_pipeline_set_overlap(self._h, 1 if enable else 0))
+
+    def set_align(self, enable):
+        """Optional 5-point aligned crop instead of the reference's bbox crop (needs a detector blob with LandmarkHead)."""
+        _check(lib.frt_pipeline_set_align(self._h, 1 if enable else 0))
 
     def set_stream(self, hip_stream):
         """``hip_stream``: raw hipStream_t value (e.g. ``torch.cuda.current_stream().cuda_stream``) or None."""

@@ -133,6 +133,11 @@ struct frt_detector {
     int *d_cand_count = nullptr, *d_nout = nullptr;
     uint8_t *d_dead = nullptr;
     frt_bbox *d_boxes = nullptr;
+    // optional alignment mode: present only when the blob carries the LandmarkHead (the reference trims it away)
+    bool has_landmarks = false;
+    float *d_ldm = nullptr;        // raw head output [B][A][10]
+    int *d_kept_anchor = nullptr;  // [B][max_faces]
+    float *d_landmarks = nullptr;  // decoded, frame coordinates [B][max_faces][10]
 
     void build(const frt::Blob &b);
     void forward(int n, hipStream_t s);          // d_input -> d_loc/d_conf
@@ -295,8 +300,20 @@ void frt_detector::build(const frt::Blob &b) {
             for (int ci = 0; ci < 64; ++ci) tc[ci * 4 + co] = wc[co * 64 + ci];
         std::vector<float> bb(b.get(hb + ".bias", 8).data, b.get(hb + ".bias", 8).data + 8);
         std::vector<float> bc(b.get(hc + ".bias", 4).data, b.get(hc + ".bias", 4).data + 4);
-        ho.hd[k] = HeadArgs{cat[k], arena.upload(tb), arena.upload(bb), arena.upload(tc), arena.upload(bc), d_loc, d_conf, B, 64, fh[k], fw[k], g.A, g.base[k]};
+        ho.hd[k] = HeadArgs{cat[k], arena.upload(tb), arena.upload(bb), arena.upload(tc), arena.upload(bc), d_loc, d_conf, B, 64, fh[k], fw[k], g.A, g.base[k],
+                            nullptr, nullptr, nullptr};
         flops_per_frame += 2.0 * fh[k] * fw[k] * 64 * 12;
+        if (has_landmarks) {
+            const std::string hl = "LandmarkHead." + std::to_string(k) + ".conv1x1";
+            const float *wl = b.get(hl + ".weight", 20 * 64).data, *bl = b.get(hl + ".bias", 20).data;
+            std::vector<float> tl(64 * 20), blv(bl, bl + 20);
+            for (int co = 0; co < 20; ++co)
+                for (int ci = 0; ci < 64; ++ci) tl[ci * 20 + co] = wl[co * 64 + ci];
+            ho.hd[k].wl = arena.upload(tl);
+            ho.hd[k].bl = arena.upload(blv);
+            ho.hd[k].ldm = d_ldm;
+            flops_per_frame += 2.0 * fh[k] * fw[k] * 64 * 20;
+        }
     }
     ops.push_back(ho);
 }
@@ -325,7 +342,8 @@ void frt_detector::forward(int n, hipStream_t s) {
 void frt_detector::postprocess(int n, hipStream_t s) {
     ProfScope ps(2, "det_postprocess", (double)n * g.A, s);
     launch_decode(d_loc, d_conf, n, g, d_cand, d_cand_count, s);
-    launch_nms(d_cand, d_cand_count, n, g, d_dead, d_boxes, d_nout, s);
+    launch_nms(d_cand, d_cand_count, n, g, d_dead, d_boxes, d_nout, d_kept_anchor, s);
+    if (has_landmarks) launch_landmark_decode(d_ldm, d_kept_anchor, d_nout, n, g, d_landmarks, s);
 }
 
 // =====================================================================================================================
@@ -357,6 +375,7 @@ struct frt_embedder {
     uint8_t *d_crops = nullptr;
     int *d_valid = nullptr;
     frt_bbox *d_boxes = nullptr;
+    float *d_lm = nullptr;  // landmark staging of forward_aligned [max_batch][10]
     uint8_t *d_frame = nullptr;
     size_t frame_cap = 0;
     static constexpr int FC_SPLITS = 49;
@@ -474,6 +493,7 @@ void frt_embedder::build(const frt::Blob &b) {
     d_crops = arena.alloc<uint8_t>(F * 112 * 112 * 3);
     d_valid = arena.alloc<int>(F);
     d_boxes = arena.alloc<frt_bbox>(F);
+    d_lm = arena.alloc<float>((size_t)F * 10);
     zeros = arena.alloc<half_t>(256);
     HIPCHK(hipMemset(zeros, 0, 256 * sizeof(half_t)));
 }
@@ -643,6 +663,8 @@ struct frt_pipeline {
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_det[2] = {nullptr, nullptr};
     frt_bbox *slot_boxes[2];
     int *slot_nout[2];
+    float *slot_landmarks[2] = {nullptr, nullptr};
+    bool align = false;  // optional: 5-point similarity warp instead of the reference's bbox crop + bicubic resize
     unsigned seq = 0;
     bool overlap = true;
     Arena arena;
@@ -668,13 +690,18 @@ struct frt_pipeline {
         det->postprocess(n, ds);
         HIPCHK(hipMemcpyAsync(slot_boxes[slot], det->d_boxes, sizeof(frt_bbox) * F, hipMemcpyDeviceToDevice, ds));
         HIPCHK(hipMemcpyAsync(slot_nout[slot], det->d_nout, sizeof(int) * n, hipMemcpyDeviceToDevice, ds));
+        if (align) HIPCHK(hipMemcpyAsync(slot_landmarks[slot], det->d_landmarks, sizeof(float) * 10 * F, hipMemcpyDeviceToDevice, ds));
         if (ds != s) {
             HIPCHK(hipEventRecord(ev_det[slot], ds));
             HIPCHK(hipStreamWaitEvent(s, ev_det[slot], 0));
         }
         const frt_bbox *boxes = slot_boxes[slot];
         const int *nout = slot_nout[slot];
-        {
+        if (align) {
+            ProfScope ps(2, "align_faces", (double)F * 112 * 112 * 3, s);
+            launch_align_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, slot_landmarks[slot], nout,
+                               max_faces, F, 0, nullptr, d_chw, d_valid, s);
+        } else {
             ProfScope ps(2, "crop_faces", (double)F * 112 * 112 * 3, s);
             launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, boxes, nout, max_faces, F, 0,
                               112, 112, nullptr, d_chw, d_valid, s);
@@ -751,6 +778,12 @@ int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int 
         d->d_dead = d->arena.alloc<uint8_t>(B * g.A);
         d->d_boxes = d->arena.alloc<frt_bbox>(B * max_faces);
         d->d_tmp = d->arena.alloc<float>(B * 64 * (size_t)g.fh[0] * g.fw[0]);  // largest depthwise intermediate of a split conv_dw block
+        d->has_landmarks = blob.has("LandmarkHead.0.conv1x1.weight");
+        if (d->has_landmarks) {
+            d->d_ldm = d->arena.alloc<float>(B * g.A * 10);
+            d->d_kept_anchor = d->arena.alloc<int>(B * max_faces);
+            d->d_landmarks = d->arena.alloc<float>(B * max_faces * 10);
+        }
         d->build(blob);
         HIPCHK(hipDeviceSynchronize());
         *out = d.release();
@@ -796,6 +829,29 @@ int frt_detector_find_faces(frt_detector *d, const uint8_t *bgr, int rows, int c
     return frt_detector_find_faces_batch(d, bgr, 1, rows, cols, row_stride, row_stride * (size_t)rows, out, n_out);
 }
 
+int frt_detector_has_landmarks(const frt_detector *d) { return d && d->has_landmarks ? 1 : 0; }
+
+int frt_detector_find_faces_landmarks(frt_detector *d, const uint8_t *bgr, int rows, int cols, size_t row_stride, frt_bbox *out,
+                                      float *landmarks_out, int *n_out) {
+    return guarded([&] {
+        if (!d || !bgr || !out || !n_out || !landmarks_out) raise(FRT_ERR_INVALID, "null argument");
+        if (!d->has_landmarks) raise(FRT_ERR_FORMAT, "findFaceLandmarks: the detector blob has no LandmarkHead (trimmed export)");
+        if (rows != d->g.frame_h || cols != d->g.frame_w) raise(FRT_ERR_INVALID, "findFace: frame must be frameWidth x frameHeight");
+        std::lock_guard<std::mutex> lk(d->mu);
+        use_device(d->device);
+        hipStream_t s = d->stream;
+        const size_t tight = (size_t)cols * 3;
+        HIPCHK(hipMemcpy2DAsync(d->d_frames, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice, s));
+        d->preprocess(d->d_frames, 1, tight, (size_t)rows * tight, s);
+        d->forward(1, s);
+        d->postprocess(1, s);
+        HIPCHK(hipMemcpyAsync(out, d->d_boxes, sizeof(frt_bbox) * d->g.max_faces, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(landmarks_out, d->d_landmarks, sizeof(float) * 10 * d->g.max_faces, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(n_out, d->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
 int frt_detector_preprocess(frt_detector *d, const uint8_t *bgr, int rows, int cols, size_t row_stride, float *chw_out) {
     return guarded([&] {
         if (!d || !bgr || !chw_out) raise(FRT_ERR_INVALID, "null argument");
@@ -823,6 +879,24 @@ int frt_detector_infer(frt_detector *d, const float *chw, int batch, float *loc_
         d->forward(batch, s);
         HIPCHK(hipMemcpyAsync(loc_out, d->d_loc, sizeof(float) * (size_t)batch * d->g.A * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(conf_out, d->d_conf, sizeof(float) * (size_t)batch * d->g.A * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_detector_infer_landmarks(frt_detector *d, const float *chw, int batch, float *loc_out, float *conf_out, float *ldm_out) {
+    return guarded([&] {
+        if (!d || !chw || !loc_out || !conf_out || !ldm_out) raise(FRT_ERR_INVALID, "null argument");
+        if (!d->has_landmarks) raise(FRT_ERR_FORMAT, "doInference: the detector blob has no LandmarkHead (trimmed export)");
+        if (batch < 1 || batch > d->max_batch) raise(FRT_ERR_CAPACITY, "doInference: batch exceeds det_maxBatchSize");
+        std::lock_guard<std::mutex> lk(d->mu);
+        use_device(d->device);
+        hipStream_t s = d->stream;
+        const size_t in_elems = (size_t)3 * d->g.in_h * d->g.in_w;
+        HIPCHK(hipMemcpyAsync(d->d_input, chw, sizeof(float) * in_elems * batch, hipMemcpyHostToDevice, s));
+        d->forward(batch, s);
+        HIPCHK(hipMemcpyAsync(loc_out, d->d_loc, sizeof(float) * (size_t)batch * d->g.A * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(conf_out, d->d_conf, sizeof(float) * (size_t)batch * d->g.A * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ldm_out, d->d_ldm, sizeof(float) * (size_t)batch * d->g.A * 10, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     });
 }
@@ -974,6 +1048,66 @@ int frt_embedder_forward(frt_embedder *e, const uint8_t *bgr, int rows, int cols
             for (int v : valid) bad = bad || !v;
         }
         if (bad) raise(FRT_ERR_EMPTY_ROI, "forward: empty or out-of-frame ROI (embedding set to zeros)");
+    });
+}
+
+int frt_align_faces(const uint8_t *bgr, int rows, int cols, size_t row_stride, const float *landmarks, int n, uint8_t *crops_out, int device) {
+    return guarded([&] {
+        if (!bgr || !landmarks || !crops_out || n < 0 || rows < 1 || cols < 1) raise(FRT_ERR_INVALID, "alignFaces: bad argument");
+        if (n == 0) return;
+        if (device >= 0) use_device(device);
+        Arena a;
+        struct Guard {
+            Arena &a;
+            ~Guard() { a.release(); }
+        } guard{a};
+        const size_t tight = (size_t)cols * 3;
+        uint8_t *d_frame = a.alloc<uint8_t>((size_t)rows * tight);
+        float *d_lm = a.alloc<float>((size_t)n * 10);
+        uint8_t *d_crops = a.alloc<uint8_t>((size_t)n * 112 * 112 * 3);
+        float *d_chw = a.alloc<float>((size_t)n * 112 * 112 * 3);
+        int *d_valid = a.alloc<int>(n);
+        HIPCHK(hipMemcpy2D(d_frame, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_lm, landmarks, sizeof(float) * 10 * n, hipMemcpyHostToDevice));
+        launch_align_faces(d_frame, rows, cols, tight, 0, d_lm, nullptr, 1, n, 1, d_crops, d_chw, d_valid, nullptr);
+        std::vector<int> valid(n);
+        HIPCHK(hipMemcpy(valid.data(), d_valid, sizeof(int) * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(crops_out, d_crops, (size_t)n * 112 * 112 * 3, hipMemcpyDeviceToHost));
+        for (int v : valid)
+            if (!v) raise(FRT_ERR_EMPTY_ROI, "alignFaces: degenerate landmarks (crop set to zeros)");
+    });
+}
+
+int frt_embedder_forward_aligned(frt_embedder *e, const uint8_t *bgr, int rows, int cols, size_t row_stride, const float *landmarks, int n,
+                                 float *embeds_out, uint8_t *crops_out) {
+    return guarded([&] {
+        if (!e || !bgr || !landmarks || !embeds_out || n < 0 || rows < 1 || cols < 1) raise(FRT_ERR_INVALID, "forwardAligned: bad argument");
+        if (n == 0) return;
+        std::lock_guard<std::mutex> lk(e->mu);
+        use_device(e->device);
+        hipStream_t s = e->stream;
+        const size_t tight = (size_t)cols * 3, need = (size_t)rows * tight;
+        if (need > e->frame_cap) {
+            if (e->d_frame) (void)hipFree(e->d_frame);
+            e->d_frame = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&e->d_frame), need));
+            e->frame_cap = need;
+        }
+        HIPCHK(hipMemcpy2DAsync(e->d_frame, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice, s));
+        bool bad = false;
+        for (int f0 = 0; f0 < n; f0 += e->max_batch) {
+            const int nf = std::min(e->max_batch, n - f0);
+            HIPCHK(hipMemcpyAsync(e->d_lm, landmarks + (size_t)f0 * 10, sizeof(float) * 10 * nf, hipMemcpyHostToDevice, s));
+            launch_align_faces(e->d_frame, rows, cols, tight, 0, e->d_lm, nullptr, 1, nf, 1, e->d_crops, e->d_in, e->d_valid, s);
+            e->forward(e->d_in, nf, e->d_valid, e->d_out, s);
+            HIPCHK(hipMemcpyAsync(embeds_out + (size_t)f0 * 512, e->d_out, sizeof(float) * 512 * nf, hipMemcpyDeviceToHost, s));
+            if (crops_out) HIPCHK(hipMemcpyAsync(crops_out + (size_t)f0 * 112 * 112 * 3, e->d_crops, (size_t)nf * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
+            std::vector<int> valid(nf);
+            HIPCHK(hipMemcpyAsync(valid.data(), e->d_valid, sizeof(int) * nf, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (int v : valid) bad = bad || !v;
+        }
+        if (bad) raise(FRT_ERR_EMPTY_ROI, "forwardAligned: degenerate landmarks (embedding set to zeros)");
     });
 }
 
@@ -1131,6 +1265,7 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
             HIPCHK(hipEventCreateWithFlags(&p->ev_det[i], hipEventDisableTiming));
             p->slot_boxes[i] = p->arena.alloc<frt_bbox>(F);
             p->slot_nout[i] = p->arena.alloc<int>((size_t)max_frames);
+            if (d->has_landmarks) p->slot_landmarks[i] = p->arena.alloc<float>(F * 10);
         }
         {
             const char *e = getenv("FRT_PIPELINE_OVERLAP");
@@ -1210,6 +1345,17 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable) {
         HIPCHK(hipStreamSynchronize(p->stream));
         p->overlap = enable != 0;
         p->seq = 0;
+    });
+}
+
+int frt_pipeline_set_align(frt_pipeline *p, int enable) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        if (enable && !p->det->has_landmarks) raise(FRT_ERR_FORMAT, "pipeline: alignment needs a detector blob with the LandmarkHead");
+        use_device(p->det->device);
+        HIPCHK(hipStreamSynchronize(p->det_stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        p->align = enable != 0;
     });
 }
 

@@ -51,7 +51,12 @@ struct Candidate {
 };
 void launch_decode(const float *loc, const float *conf, int n_frames, const DetGeom &g, Candidate *cand, int *cand_count, hipStream_t s);
 void launch_nms(const Candidate *cand, const int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
-                hipStream_t s);
+                int *kept_anchor, hipStream_t s);
+// landmarks of the kept boxes: raw head output ldm [B][A][10] + kept anchors [B][K] -> frame coordinates (x0,y0,...,x4,y4) [B][K][10]
+void launch_landmark_decode(const float *ldm, const int *kept_anchor, const int *n_out, int n_frames, const DetGeom &g, float *out, hipStream_t s);
+// 5-point similarity alignment (ArcFace 112x112 template) + bilinear warp, fused with the recogniser's normalisation
+void launch_align_faces(const uint8_t *frames, int frame_h, int frame_w, size_t row_stride, size_t frame_stride, const float *landmarks,
+                        const int *n_boxes, int max_faces, int F, int frames_shared, uint8_t *crops, float *chw, int *valid, hipStream_t s);
 
 // ---------------------------------------------------------------- image ops (kernels_image.hip)
 // u8 BGR frames [n][frame_h][frame_w][3] (row_stride / frame_stride in bytes) -> fp32 planar [n][3][in_h][in_w]
@@ -89,6 +94,8 @@ struct HeadArgs {
     const float *wc, *bc;   // class head [64][4], [4]
     float *loc, *conf;      // [B][A][4], [B][A][2]
     int B, C, H, W, A, base;
+    const float *wl, *bl;   // optional landmark head [64][20], [20] (null: trimmed network, the reference's default)
+    float *ldm;             // [B][A][10]
 };
 void launch_heads(const HeadArgs &a, hipStream_t s);
 void launch_heads_multi(const HeadArgs *a, int n, hipStream_t s);

@@ -243,6 +243,18 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadMulti mm) {
     }
     // anchor index = base + (i*W + j)*2 + l ; channels 4l..4l+3 / 2l..2l+1 belong to anchor l (retinaface_trim.py:22-24,33-35)
     const long an = (long)b * a.A + a.base + (long)p * 2;
+    if (a.wl) {  // optional LandmarkHead (retinaface.py:37-46): 1x1 64 -> 20, channels 10l..10l+9 belong to anchor l
+        float ll[20];
+#pragma unroll
+        for (int c = 0; c < 20; ++c) ll[c] = 0.f;
+        for (int ci = 0; ci < a.C; ++ci) {
+            const float x = inb[(long)ci * HW];
+#pragma unroll
+            for (int c = 0; c < 20; ++c) ll[c] = fmaf(x, a.wl[ci * 20 + c], ll[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 20; ++c) a.ldm[an * 10 + c] = ll[c] + a.bl[c];
+    }
     floatx4 o0 = {lb[0] + a.bb[0], lb[1] + a.bb[1], lb[2] + a.bb[2], lb[3] + a.bb[3]};
     floatx4 o1 = {lb[4] + a.bb[4], lb[5] + a.bb[5], lb[6] + a.bb[6], lb[7] + a.bb[7]};
     *reinterpret_cast<floatx4 *>(a.loc + an * 4) = o0;

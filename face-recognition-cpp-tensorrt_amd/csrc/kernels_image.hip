@@ -191,6 +191,90 @@ void launch_crop_faces(const uint8_t *frames, int frame_h, int frame_w, size_t r
                        frames_shared, oh, ow, crops, chw, valid);
 }
 
+// ---------------------------------------------------------------- 5-point alignment (optional mode; absent from the reference)
+// Least-squares similarity (scale * rotation + translation; equals Umeyama's solution whenever that is not a reflection) from the
+// 5 detected landmarks to the public ArcFace 112x112 template, then an inverse-mapped bilinear warp with zero border, fused
+// with the recogniser's BGR->RGB / (x-127.5)/128 / planar normalisation.  Float arithmetic; restated in oracle/align.py.
+namespace {
+__constant__ float c_arc_template[10] = {38.2946f, 51.6963f, 73.5318f, 51.5014f, 56.0252f, 71.7366f, 41.5493f, 92.3655f, 70.7299f, 92.2041f};
+
+__global__ __launch_bounds__(256) void align_faces_kernel(const uint8_t *__restrict__ frames, int frame_h, int frame_w, size_t row_stride,
+                                                          size_t frame_stride, const float *__restrict__ landmarks, const int *__restrict__ n_boxes,
+                                                          int max_faces, int frames_shared, uint8_t *__restrict__ crops, float *__restrict__ chw,
+                                                          int *__restrict__ valid) {
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frame = frames_shared ? 0 : f / max_faces;
+    bool ok = !n_boxes || (f % max_faces) < n_boxes[f / max_faces];
+    // every thread derives the same 2x3 inverse transform (25 flops; cheaper than a broadcast)
+    const float *lm = landmarks + (long)f * 10;
+    float msx = 0.f, msy = 0.f, mdx = 0.f, mdy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        msx += lm[2 * k];
+        msy += lm[2 * k + 1];
+        mdx += c_arc_template[2 * k];
+        mdy += c_arc_template[2 * k + 1];
+    }
+    msx *= 0.2f; msy *= 0.2f; mdx *= 0.2f; mdy *= 0.2f;
+    float sa = 0.f, sb = 0.f, den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float sx = lm[2 * k] - msx, sy = lm[2 * k + 1] - msy;
+        const float dx = c_arc_template[2 * k] - mdx, dy = c_arc_template[2 * k + 1] - mdy;
+        sa += sx * dx + sy * dy;
+        sb += sx * dy - sy * dx;
+        den += sx * sx + sy * sy;
+    }
+    ok = ok && den > 1e-6f && (sa * sa + sb * sb) > 1e-12f;
+    if (p == 0 && valid) valid[f] = ok ? 1 : 0;
+    if (p >= 112 * 112) return;
+    int v[3] = {0, 0, 0};
+    if (ok) {
+        const float a = sa / den, b = sb / den;            // dst = [a -b; b a] * src + t
+        const float tx = mdx - (a * msx - b * msy), ty = mdy - (b * msx + a * msy);
+        const float n2 = a * a + b * b;
+        const float ia = a / n2, ib = b / n2;               // src = [ia ib; -ib ia] * (dst - t)
+        const int oy = p / 112, ox = p - oy * 112;
+        const float ux = (float)ox - tx, uy = (float)oy - ty;
+        const float sxf = ia * ux + ib * uy, syf = -ib * ux + ia * uy;
+        const float fx0 = floorf(sxf), fy0 = floorf(syf);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float wx = sxf - fx0, wy = syf - fy0;
+        const uint8_t *src = frames + (size_t)frame * frame_stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xx = x0 + (q & 1), yy = y0 + (q >> 1);
+                t4[q] = (xx >= 0 && xx < frame_w && yy >= 0 && yy < frame_h) ? (float)src[(size_t)yy * row_stride + (size_t)xx * 3 + c] : 0.f;
+            }
+            const float top = t4[0] + wx * (t4[1] - t4[0]), bot = t4[2] + wx * (t4[3] - t4[2]);
+            const float val = top + wy * (bot - top);
+            v[c] = clampi((int)floorf(val + 0.5f), 0, 255);
+        }
+    }
+    if (crops) {
+        uint8_t *o = crops + ((size_t)f * 112 * 112 + p) * 3;
+        o[0] = (uint8_t)v[0];
+        o[1] = (uint8_t)v[1];
+        o[2] = (uint8_t)v[2];
+    }
+    float *o = chw + (size_t)f * 3 * 112 * 112 + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[(size_t)c * 112 * 112] = ok ? ((float)v[2 - c] - 127.5f) * 0.0078125f : 0.f;
+}
+}  // namespace
+
+void launch_align_faces(const uint8_t *frames, int frame_h, int frame_w, size_t row_stride, size_t frame_stride, const float *landmarks,
+                        const int *n_boxes, int max_faces, int F, int frames_shared, uint8_t *crops, float *chw, int *valid, hipStream_t s) {
+    if (F <= 0) return;
+    dim3 grid((112 * 112 + 255) / 256, F);
+    hipLaunchKernelGGL(align_faces_kernel, grid, dim3(256), 0, s, frames, frame_h, frame_w, row_stride, frame_stride, landmarks, n_boxes, max_faces,
+                       frames_shared, crops, chw, valid);
+}
+
 void launch_face_normalize(const uint8_t *crops, int F, int oh, int ow, float *chw, hipStream_t s) {
     if (F <= 0) return;
     dim3 grid((oh * ow + 255) / 256, F);

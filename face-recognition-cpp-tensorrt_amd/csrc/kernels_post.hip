@@ -87,7 +87,8 @@ __global__ void decode_kernel(const float *__restrict__ loc, const float *__rest
 __device__ __forceinline__ bool cand_better(float s, int a, float bs, int ba) { return (s > bs) || (s == bs && a < ba); }
 
 __global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ cand_all, const int *__restrict__ cand_count, DetGeom g,
-                                                  uint8_t *__restrict__ dead_all, frt_bbox *__restrict__ out, int *__restrict__ n_out) {
+                                                  uint8_t *__restrict__ dead_all, frt_bbox *__restrict__ out, int *__restrict__ n_out,
+                                                  int *__restrict__ kept_anchor) {
     const int f = blockIdx.x, tid = threadIdx.x;
     const Candidate *cand = cand_all + (long)f * g.A;
     uint8_t *dead = dead_all + (long)f * g.A;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ 
                 s_win = cand[wp];
                 dead[wp] = 1;
                 out[(long)f * g.max_faces + kept] = cand[wp].box;
+                if (kept_anchor) kept_anchor[(long)f * g.max_faces + kept] = cand[wp].anchor;
             }
         }
         __syncthreads();
@@ -188,8 +190,52 @@ void launch_decode(const float *loc, const float *conf, int n_frames, const DetG
 }
 
 void launch_nms(const Candidate *cand, const int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
-                hipStream_t s) {
-    hipLaunchKernelGGL(nms_kernel, dim3(n_frames), dim3(256), 0, s, cand, cand_count, g, dead, out, n_out);
+                int *kept_anchor, hipStream_t s) {
+    hipLaunchKernelGGL(nms_kernel, dim3(n_frames), dim3(256), 0, s, cand, cand_count, g, dead, out, n_out, kept_anchor);
+}
+
+// ---------------------------------------------------------------- landmarks of the kept boxes (optional alignment mode)
+// The reference exports the detector WITHOUT the landmark head and has no landmark decode (src/retinaface.cpp:58-60,
+// conversion/retina/torch2trt.py:7-9), so this follows the upstream RetinaFace formula for the head defined in
+// conversion/retina/models/retinaface.py:37-46:  point_k = prior_centre + pre[2k..2k+1] * variance[0] * prior_size, then the
+// same un-letterboxing as the boxes - in float, without the reference's int truncation.  Parity unpinned (oracle/align.py).
+namespace {
+__global__ void landmark_decode_kernel(const float *__restrict__ ldm, const int *__restrict__ kept_anchor, const int *__restrict__ n_out,
+                                       DetGeom g, float *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (t >= g.max_faces * 5) return;
+    const int kbox = t / 5, k = t - kbox * 5;
+    float x = 0.f, y = 0.f;
+    if (kbox < n_out[f]) {
+        const int a = kept_anchor[(long)f * g.max_faces + kbox];
+        const int lv = a >= g.base[2] ? 2 : (a >= g.base[1] ? 1 : 0);
+        const int rel = a - g.base[lv];
+        const int l = rel & 1, cell = rel >> 1;
+        const int i = cell / g.fw[lv], j = cell - i * g.fw[lv];
+        const float step = c_steps[lv];
+        const float asx = (float)c_min_sizes[lv][l] / (float)g.in_w, asy = (float)c_min_sizes[lv][l] / (float)g.in_h;
+        const float acx = ((float)j + 0.5f) * step / (float)g.in_w, acy = ((float)i + 0.5f) * step / (float)g.in_h;
+        const float *p = ldm + ((long)f * g.A + a) * 10 + 2 * k;
+        x = (acx + p[0] * 0.1f * asx) * (float)g.in_w;
+        y = (acy + p[1] * 0.1f * asy) * (float)g.in_h;
+        if (g.scale_h > g.scale_w) {
+            x = x / g.scale_w;
+            y = (y - ((float)g.in_h - g.scale_w * (float)g.frame_h) / 2.f) / g.scale_w;
+        } else {
+            x = (x - ((float)g.in_w - g.scale_h * (float)g.frame_w) / 2.f) / g.scale_h;
+            y = y / g.scale_h;
+        }
+    }
+    float *o = out + ((long)f * g.max_faces + kbox) * 10 + 2 * k;
+    o[0] = x;
+    o[1] = y;
+}
+}  // namespace
+
+void launch_landmark_decode(const float *ldm, const int *kept_anchor, const int *n_out, int n_frames, const DetGeom &g, float *out, hipStream_t s) {
+    dim3 grid((g.max_faces * 5 + 63) / 64, n_frames);
+    hipLaunchKernelGGL(landmark_decode_kernel, grid, dim3(64), 0, s, ldm, kept_anchor, n_out, g, out);
 }
 
 // ---------------------------------------------------------------- per-face result records of the batched pipeline

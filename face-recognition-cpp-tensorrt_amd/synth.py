@@ -55,6 +55,10 @@ MNET_STAGES = OrderedDict(
 CLASS_BIAS = (-4.90, -2.65, -2.48)
 
 
+# public ArcFace 112x112 alignment template (x, y) x 5: eyes, nose, mouth corners
+ARC_TEMPLATE = (38.2946, 51.6963, 73.5318, 51.5014, 56.0252, 71.7366, 41.5493, 92.3655, 70.7299, 92.2041)
+
+
 def retinaface_state(seed=1, class_bias=CLASS_BIAS, class_scale=1.0, bbox_scale=3.0, landmarks=False):
     """state_dict of ``RetinaFace(cfg_mnet, 'test')`` (``conversion/retina/models/retinaface_trim.py:48-127``).
 
@@ -99,7 +103,11 @@ def retinaface_state(seed=1, class_bias=CLASS_BIAS, class_scale=1.0, bbox_scale=
         for i in range(3):
             n = "LandmarkHead.%d.conv1x1" % i
             _conv(sd, seed, n + ".weight", 20, 64, 1, gain=1.0, scale=0.6)
-            sd[n + ".bias"] = (0.1 * _rng(seed, n + ".bias").standard_normal(20)).astype(np.float32)
+            # bias = a face-like 5-point layout spanning about one anchor (point = centre + pre * 0.1 * anchor size), so that
+            # the similarity fit of the alignment mode is well conditioned; the random weights perturb it per anchor
+            tmpl = (np.array(ARC_TEMPLATE, np.float64).reshape(5, 2) - 56.0) / 112.0 * 10.0
+            b = np.tile(tmpl.reshape(-1), 2) + 0.1 * _rng(seed, n + ".bias").standard_normal(20)
+            sd[n + ".bias"] = b.astype(np.float32)
     return sd
 
 

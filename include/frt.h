@@ -164,6 +164,30 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream);
 int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Optional 5-point alignment mode (default OFF).  The reference has none: it trims the landmark head off the detector
+ * (conversion/retina/torch2trt.py:7-9, src/retinaface.cpp:58-60) and feeds the embedder a bbox crop + bicubic resize
+ * (src/arcface.cpp:3-17).  These entry points exist for accuracy work only and need a detector blob exported WITH
+ * LandmarkHead.* (conversion/retina/models/retinaface.py:37-46,117); their oracle (oracle/align.py) is "parity
+ * unpinned" - there is no reference behaviour to compare with.
+ *   landmarks layout: 10 floats per face = (x0,y0,...,x4,y4), x = column, y = row in FRAME pixels, order
+ *   left eye, right eye, nose, left mouth corner, right mouth corner (upstream RetinaFace order). */
+int frt_detector_has_landmarks(const frt_detector *d);
+/* findFace + landmarks of the kept boxes.  landmarks_out: capacity max_faces*10. */
+int frt_detector_find_faces_landmarks(frt_detector *d, const uint8_t *bgr, int rows, int cols, size_t row_stride, frt_bbox *out,
+                                      float *landmarks_out, int *n_out);
+/* doInference with the third output: ldm_out [batch][A][10] raw head values. */
+int frt_detector_infer_landmarks(frt_detector *d, const float *chw, int batch, float *loc_out, float *conf_out, float *ldm_out);
+/* Counterpart of frt_crop_faces: least-squares similarity from the 5 landmarks to the ArcFace 112x112 template, bilinear
+ * warp with zero border.  crops_out: n x 112 x 112 x 3 BGR u8.  FRT_ERR_EMPTY_ROI for degenerate (coincident) landmarks. */
+int frt_align_faces(const uint8_t *bgr, int rows, int cols, size_t row_stride, const float *landmarks, int n, uint8_t *crops_out,
+                    int device);
+/* Counterpart of frt_embedder_forward with aligned crops instead of bbox crops. */
+int frt_embedder_forward_aligned(frt_embedder *e, const uint8_t *bgr, int rows, int cols, size_t row_stride, const float *landmarks,
+                                 int n, float *embeds_out, uint8_t *crops_out);
+/* Switch a pipeline between the reference's crop (0, default) and the aligned crop (1). */
+int frt_pipeline_set_align(frt_pipeline *p, int enable);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Profiling hooks (HIP events on the library's own stream; used by bench.py for the roofline object).
  * ------------------------------------------------------------------------------------------------------------------ */
 /* kinds: 0 = off, 1 = time every launch of the dominant kernel family (conv3x3 MFMA), 2 = time every stage. */

@@ -9,6 +9,7 @@
 #define FRT_ARCFACE_H
 
 #include <algorithm>
+#include <array>
 #include <cassert>
 #include <tuple>
 
@@ -82,6 +83,12 @@ class ArcFaceIR50 {
         std::copy(embedding.begin(), embedding.end(), m_knownEmbeds.begin() + (size_t)classCount * m_OUTPUT_D);
         classCount++;
     }
+    // Extension: bulk enrolment (one copy instead of one call per row; db.cpp:339's loop collapses to this)
+    void addEmbeddings(const std::vector<std::string> &names, const float *embeddings) {
+        classNames.insert(classNames.end(), names.begin(), names.end());
+        std::copy(embeddings, embeddings + names.size() * (size_t)m_OUTPUT_D, m_knownEmbeds.begin() + (size_t)classCount * m_OUTPUT_D);
+        classCount += (int)names.size();
+    }
     void initKnownEmbeds(int num) { m_knownEmbeds.assign((size_t)num * m_OUTPUT_D, 0.f); }  // arcface.cpp:162
     void initMatMul() { matmul.init(m_knownEmbeds.data(), classCount, m_OUTPUT_D); }       // arcface.cpp:164
     void resetEmbeddings() {                                                                // arcface.cpp:233-236
@@ -106,6 +113,29 @@ class ArcFaceIR50 {
             c.y1 = outputBbox[i].y1;
             c.x2 = outputBbox[i].x2;
             c.y2 = outputBbox[i].y2;
+            croppedFaces.push_back(c);
+        }
+    }
+    // Optional alignment mode (no reference counterpart): forward() with the 5-point similarity warp instead of the bbox crop.
+    void forwardAligned(cv::Mat image, std::vector<struct Bbox> outputBbox, const std::vector<std::array<float, 10>> &landmarks) {
+        const int n = (int)landmarks.size();
+        croppedFaces.clear();
+        m_embeds.assign((size_t)std::max(n, 1) * m_OUTPUT_D, 0.f);
+        if (!n) return;
+        std::vector<unsigned char> crops((size_t)n * m_INPUT_H * m_INPUT_W * 3);
+        checkFrtStatus(frt_embedder_forward_aligned(h_, image.data, image.rows, image.cols, (size_t)image.step, landmarks[0].data(), n, m_embeds.data(),
+                                                    crops.data()));
+        for (int i = 0; i < n; ++i) {
+            CroppedFace c;
+            c.face = cv::Mat(m_INPUT_H, m_INPUT_W, CV_8UC3, &crops[(size_t)i * m_INPUT_H * m_INPUT_W * 3]).clone();
+            preprocessFace(c.face, c.faceMat);
+            c.x1 = c.y1 = c.x2 = c.y2 = 0;
+            if ((size_t)i < outputBbox.size()) {
+                c.x1 = outputBbox[(size_t)i].x1;
+                c.y1 = outputBbox[(size_t)i].y1;
+                c.x2 = outputBbox[(size_t)i].x2;
+                c.y2 = outputBbox[(size_t)i].y2;
+            }
             croppedFaces.push_back(c);
         }
     }

@@ -4,6 +4,7 @@
 #ifndef FRT_RETINAFACE_H
 #define FRT_RETINAFACE_H
 
+#include <array>
 #include <cassert>
 
 #include "common.h"
@@ -61,6 +62,19 @@ class RetinaFace {
             res[(size_t)f].assign(b, b + n[(size_t)f]);
         }
         return res;
+    }
+    // Optional alignment mode (no reference counterpart; needs an engine file exported WITH LandmarkHead, see include/frt.h).
+    // landmarks[i] = (x0,y0,...,x4,y4), x = column, y = row, frame pixels.
+    bool hasLandmarks() const { return frt_detector_has_landmarks(h_) != 0; }
+    std::vector<struct Bbox> findFaceLandmarks(cv::Mat &img, std::vector<std::array<float, 10>> &landmarks) {
+        std::vector<struct Bbox> out((size_t)m_maxFacesPerScene);
+        landmarks.assign((size_t)m_maxFacesPerScene, std::array<float, 10>());
+        int n = 0;
+        checkFrtStatus(frt_detector_find_faces_landmarks(h_, img.data, img.rows, img.cols, (size_t)img.step, reinterpret_cast<frt_bbox *>(out.data()),
+                                                         landmarks.empty() ? nullptr : landmarks[0].data(), &n));
+        out.resize((size_t)n);
+        landmarks.resize((size_t)n);
+        return out;
     }
     frt_detector *handle() { return h_; }
 

@@ -62,6 +62,9 @@ def blobs(frt, tmp_path_factory):
         if kind == "det":
             sd = s.retinaface_state(1)
             path = frt.write_weights(str(d / "retina.frtw"), sd, frt.weights_io.KIND_RETINAFACE_MNET025)
+        elif kind == "det_ldm":  # full export WITH the landmark head (optional alignment mode)
+            sd = s.retinaface_state(1, landmarks=True)
+            path = frt.write_weights(str(d / "retina_ldm.frtw"), sd, frt.weights_io.KIND_RETINAFACE_MNET025)
         elif kind == "ir":
             sd = s.arcface_state(2, "ir", calib=s.load_calibration("ir"))
             path = frt.write_weights(str(d / "ir50.frtw"), sd, frt.weights_io.KIND_ARCFACE_IR50)

@@ -160,6 +160,28 @@ def golden_retinaface():
     np.savez(os.path.join(HERE, "retinaface_mnet.npz"), seed=1, **out)
 
 
+def golden_retinaface_landmarks():
+    """Full model WITH LandmarkHead (conversion/retina/models/retinaface.py) - pins the raw landmark output of the optional
+    alignment mode.  Same torchvision stand-in as above."""
+    torchvision_standin()
+    sys.path.insert(0, os.path.join(REF, "retina"))
+    from config import cfg_mnet
+    from models.retinaface import RetinaFace
+    cfg = dict(cfg_mnet)
+    cfg["pretrain"] = False
+    sd = synth.retinaface_state(1, landmarks=True)
+    m = load_sd(RetinaFace(cfg, "test"), sd)
+    out = {}
+    for tag, (h, w) in (("288x320", (288, 320)), ("96x160", (96, 160))):
+        fr = synth.make_frames(2, h, w)
+        x = np.ascontiguousarray((fr.astype(np.float32) - np.array([104, 117, 123], np.float32)).transpose(0, 3, 1, 2))
+        with torch.no_grad():
+            loc, conf, ldm = m(torch.from_numpy(x))
+        out["loc_" + tag], out["conf_" + tag], out["ldm_" + tag] = loc.numpy()[:, ::3], conf.numpy()[:, ::3], ldm.numpy()[:, ::3]
+        print("retinaface+landmarks", tag, ldm.shape, "|ldm| mean %.3f" % np.abs(ldm.numpy()).mean())
+    np.savez(os.path.join(HERE, "retinaface_mnet_ldm.npz"), seed=1, **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--calib", action="store_true")
@@ -169,3 +191,4 @@ if __name__ == "__main__":
     else:
         golden_arcface()
         golden_retinaface()
+        golden_retinaface_landmarks()
