@@ -118,7 +118,7 @@ struct frt_detector {
     DetGeom g{};
     int max_batch = 1;
     struct Op {
-        int type;  // 0 dwpw, 1 conv3x3 (n same-shaped problems, one per pyramid level), 2 heads (n levels)
+        int type;  // 0 dwpw, 1 conv3x3 (n same-shaped problems, one per pyramid level), 2 heads (n levels), 3 fused conv3x3 pair
         int n;
         DwPwArgs dw;
         Conv3Args c3[3];
@@ -177,6 +177,19 @@ void fold_pw(const frt::Blob &b, const std::string &conv, const std::string &bn,
     bias = bi;
 }
 inline int conv_out(int x, int stride) { return (x + 2 - 3) / stride + 1; }
+// [Cin][9][Cout] -> matrix-core layout [9][Cin/kc][cpad][kc] (kernels_det_conv3.hip); empty when the shape is not covered
+std::vector<float> pack_conv3_mfma(const std::vector<float> &w, int cin, int cout, int &kc, int &cpad) {
+    kc = cin == 16 ? 16 : 32;
+    cpad = cout > 32 ? 64 : 32;
+    if (cin % kc || cout > 64 || cout < 16) return {};
+    const int ncc = cin / kc;
+    std::vector<float> o((size_t)9 * ncc * cpad * kc, 0.f);
+    for (int t = 0; t < 9; ++t)
+        for (int cc = 0; cc < ncc; ++cc)
+            for (int co = 0; co < cout; ++co)
+                for (int k = 0; k < kc; ++k) o[(((size_t)t * ncc + cc) * cpad + co) * kc + k] = w[((size_t)(cc * kc + k) * 9 + t) * cout + co];
+    return o;
+}
 
 }  // namespace
 
@@ -191,6 +204,10 @@ void frt_detector::build(const frt::Blob &b) {
         o.type = 1;
         o.n = 1;
         o.c3[0] = Conv3Args{in, out, arena.upload(w), arena.upload(bias), B, cin, h, w_, cout, conv_out(h, stride), conv_out(w_, stride), stride, 1, ctotal, coff};
+        if (stride == 1) {
+            const std::vector<float> pk = pack_conv3_mfma(w, cin, cout, o.c3[0].wm_kc, o.c3[0].wm_cpad);
+            if (!pk.empty()) o.c3[0].wm = arena.upload(pk);
+        }
         ops.push_back(o);
         flops_per_frame += 2.0 * cin * 9 * cout * o.c3[0].Ho * o.c3[0].Wo;
     };
@@ -204,7 +221,39 @@ void frt_detector::build(const frt::Blob &b) {
             const std::string pfx = "ssh" + std::to_string(k + 1) + "." + name;
             fold_conv3(b, pfx + ".0", pfx + ".1", cout, cin, w, bias);
             o.c3[k] = Conv3Args{in[k], out[k], arena.upload(w), arena.upload(bias), B, cin, hs[k], ws[k], cout, hs[k], ws[k], 1, 1, ctotal, coff};
+            const std::vector<float> pk = pack_conv3_mfma(w, cin, cout, o.c3[k].wm_kc, o.c3[k].wm_cpad);
+            if (!pk.empty()) o.c3[k].wm = arena.upload(pk);
             flops_per_frame += 2.0 * cin * 9 * cout * hs[k] * ws[k];
+        }
+        ops.push_back(o);
+    };
+    // two convs reading the same input on every level (SSH conv3X3 64->32 and conv5X5_1 64->16): ONE matrix-core launch with the
+    // output channels concatenated and a split epilogue; the two separate ops stay behind it as the scalar fallback
+    auto add_c3_pair_levels = [&](const float *const in[3], float *const outa[3], const std::string &na, int couta, int ctotala, int coffa,
+                                  float *const outb[3], const std::string &nb, int coutb, int ctotalb, int coffb, int cin, const int *hs,
+                                  const int *ws) {
+        Op o{};
+        o.type = 3;
+        o.n = 3;
+        const int cout = couta + coutb;
+        for (int k = 0; k < 3; ++k) {
+            const std::string pa = "ssh" + std::to_string(k + 1) + "." + na, pb = "ssh" + std::to_string(k + 1) + "." + nb;
+            fold_conv3(b, pa + ".0", pa + ".1", couta, cin, w, bias);
+            fold_conv3(b, pb + ".0", pb + ".1", coutb, cin, w2, bias2);
+            std::vector<float> wc((size_t)cin * 9 * cout), bc(bias);
+            bc.insert(bc.end(), bias2.begin(), bias2.end());
+            for (size_t row = 0; row < (size_t)cin * 9; ++row) {
+                std::copy(w.begin() + row * couta, w.begin() + (row + 1) * couta, wc.begin() + row * cout);
+                std::copy(w2.begin() + row * coutb, w2.begin() + (row + 1) * coutb, wc.begin() + row * cout + couta);
+            }
+            o.c3[k] = Conv3Args{in[k], outa[k], nullptr, arena.upload(bc), B, cin, hs[k], ws[k], cout, hs[k], ws[k], 1, 1, ctotala, coffa};
+            const std::vector<float> pk = pack_conv3_mfma(wc, cin, cout, o.c3[k].wm_kc, o.c3[k].wm_cpad);
+            if (pk.empty()) raise(FRT_ERR_INVALID, "detector: fused SSH conv shape not covered");
+            o.c3[k].wm = arena.upload(pk);
+            o.c3[k].out2 = outb[k];
+            o.c3[k].split = couta;
+            o.c3[k].out2_ctotal = ctotalb;
+            o.c3[k].out2_coff = coffb;
         }
         ops.push_back(o);
     };
@@ -282,6 +331,7 @@ void frt_detector::build(const frt::Blob &b) {
         t1[k] = act(16, fh[k], fw[k]);
         t2[k] = act(16, fh[k], fw[k]);
     }
+    add_c3_pair_levels(pyr, cat, "conv3X3", 32, 64, 0, t1, "conv5X5_1", 16, 16, 0, 64, fh, fw);  // type 3: skips the next two ops when it ran
     add_c3_levels(pyr, cat, "conv3X3", 64, 32, fh, fw, 64, 0);
     add_c3_levels(pyr, t1, "conv5X5_1", 64, 16, fh, fw, 16, 0);
     add_c3_levels(t1, cat, "conv5X5_2", 16, 16, fh, fw, 64, 32);
@@ -325,7 +375,17 @@ void frt_detector::preprocess(const uint8_t *frames_dev, int n, size_t row_strid
 
 void frt_detector::forward(int n, hipStream_t s) {
     ProfScope ps(2, "det_network", flops_per_frame * n, s);
+    int skip = 0;
     for (Op &o : ops) {
+        if (skip > 0) {
+            --skip;
+            continue;
+        }
+        if (o.type == 3) {
+            for (int k = 0; k < o.n; ++k) o.c3[k].B = n;
+            if (det_mfma_enabled() && launch_conv3x3_mfma(o.c3, o.n, s)) skip = 2;  // else: the two separate convs that follow
+            continue;
+        }
         if (o.type == 0) {
             o.dw.B = n;
             launch_dwpw(o.dw, s);

@@ -80,13 +80,21 @@ struct DwPwArgs {
     float *tmp;             // scratch [B][Cin][Ho][Wo] for the split depthwise -> pointwise path (null: always fused)
 };
 void launch_dwpw(const DwPwArgs &a, hipStream_t s);
+bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s);  // false: shape not covered, use the scalar kernels
 struct Conv3Args {
     const float *in; float *out;
     const float *w, *b;     // [Cin][9][Cout] (transposed), bias [Cout]
     int B, Cin, H, W, Cout, Ho, Wo, stride, relu;
     int out_ctotal, out_coff;  // write into channels [coff, coff+Cout) of a [B][ctotal][Ho][Wo] tensor
+    // matrix-core path (kernels_det_conv3.hip); all optional
+    const float *wm;           // host-packed weights [9][Cin/wm_kc][wm_cpad][wm_kc] (zero rows beyond Cout); null: scalar kernel only
+    int wm_kc, wm_cpad;
+    float *out2;               // channels >= split go to out2 (channel co - split of a [B][out2_ctotal][Ho][Wo] tensor, + out2_coff)
+    int split, out2_ctotal, out2_coff;
 };
+bool det_mfma_enabled();       // env FRT_DET_MFMA=0 switches the detector back to the scalar kernels (A/B measurements)
 void launch_conv3x3(const Conv3Args &a, hipStream_t s);
+bool launch_conv3x3_mfma(const Conv3Args *a, int n, hipStream_t s);   // false: shape not covered, use the scalar kernel
 void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s);  // up to 3 same-Cout problems in one launch
 struct HeadArgs {
     const float *in;        // [B][64][H][W]

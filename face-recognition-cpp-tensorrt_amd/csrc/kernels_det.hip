@@ -18,6 +18,8 @@
 //     thread: 4*PPT..8*PPT FMAs per LDS/global read) - the round trip of the small intermediate is cheaper than the recompute;
 //   * the three pyramid levels of every SSH / head op are launched together (blockIdx.z = level): the 40x40 and 20x20 levels
 //     are pure latency on their own and hide inside the 80x80 level's launch.
+#include <cstdlib>
+
 #include "frt_kernels.h"
 
 namespace {
@@ -298,7 +300,16 @@ void launch_pw(const DwPwArgs &a, hipStream_t s) {
 
 }  // namespace
 
+bool det_mfma_enabled() {
+    static const bool use_mfma = [] {
+        const char *e = getenv("FRT_DET_MFMA");
+        return !(e && e[0] == '0');
+    }();
+    return use_mfma;
+}
+
 void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
+    if (det_mfma_enabled() && launch_dwpw_mfma(a, s)) return;  // fp32 matrix-core kernels (kernels_det_mfma.hip); scalar kernels = generic fallback
     if (!a.wd) return launch_pw(a, s);
     const long total = (long)a.B * a.Ho * a.Wo;
     const long blocks = (total + 255) / 256;
@@ -329,6 +340,7 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
 }
 
 void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s) {
+    if (det_mfma_enabled() && launch_conv3x3_mfma(a, n, s)) return;  // fp32 matrix-core kernel (kernels_det_mfma.hip)
     Conv3Multi mm;
     long max_total = 0;
     int cout = a[0].Cout;

@@ -1,0 +1,353 @@
+// RetinaFace-mobilenet0.25 conv_dw blocks and 1x1 convs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: true fp32
+// multiply-add, so the result stays inside the fp32 tolerances of tests/test_gpu_detector.py).
+//
+// Arithmetic spec: /root/reference/conversion/retina/models/net.py:19-31 (conv_dw = depthwise 3x3 + BN + ReLU, pointwise 1x1
+// + BN + ReLU), :68-98 (FPN laterals: 1x1 + BN + ReLU, nearest upsample + add).  BN is folded on the host.
+//
+// Why MFMA here although the detector is memory-bound: the scalar-FMA version (kernels_det.hip, kept as the generic
+// fallback) spends one VALU instruction per 64 FMAs and reaches 15-37 TFLOP/s on the pointwise part; every block below
+// 80x80 was latency-, not bandwidth-bound (measured 45-170 us against HBM floors of 5-20 us).  One MFMA retires 4096 FMAs
+// per wave instruction, which leaves the issue slots to the depthwise stencil and the loads.
+//
+//   dwpw_mfma_kernel   one workgroup = NPW pixel groups (32 output pixels each) x NCW output-channel groups.
+//                      Per chunk of KC input channels: all threads compute depthwise+bias+ReLU for the chunk's
+//                      KC x 32*NPW values (4 consecutive pixels per thread: 3 rows x (aligned float4 + 2 edge scalars)) and
+//                      write them to LDS [KC][32*NPW] - already the B-operand layout (k = row, pixel = lane) - then every
+//                      wave runs KC/2 x CBW MFMAs with A = pointwise weights [Cout][k] streamed L2 -> registers one chunk
+//                      ahead.  The LDS chunk is double-buffered: one barrier per chunk.  The depthwise intermediate never
+//                      touches HBM (the split path wrote and re-read it) and is computed exactly once (no per-channel-tile
+//                      recompute of the fused scalar path).
+//   pw_mfma_kernel     plain 1x1 conv (FPN laterals): B operand straight from global (32 consecutive pixels x 2 channels per
+//                      load instruction, 128-byte segments), no LDS, waves independent; fused bias/ReLU/upsample-add epilogue.
+//
+// Pixel mapping: 8x16 2-D tiles where the map is wide (halo re-read 1.4x instead of 3x), linear order over (b, y, x) on the
+// small maps (no tile-shape waste at 40x40 / 20x20).  Logical tiles are assigned so that every XCD's L2 sees a contiguous
+// range (neighbouring tiles share halo rows).
+#include <cstdlib>
+
+#include "frt_kernels.h"
+
+namespace {
+
+struct PixMap {
+    int b, oy, ox;
+    bool ok;
+};
+
+// t: pixel index inside the workgroup tile (TP pixels), lid: logical tile id
+template <bool MODE2D, int TP>
+__device__ __forceinline__ PixMap map_pixel(int lid, int t, int B, int Ho, int Wo, int tiles_x, int tiles_y) {
+    PixMap m;
+    if (MODE2D) {
+        const int per = tiles_x * tiles_y;
+        m.b = lid / per;
+        const int rem = lid - m.b * per;
+        const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+        m.oy = tyi * 8 + (t >> 4);
+        m.ox = txi * 16 + (t & 15);
+        m.ok = m.b < B && m.oy < Ho && m.ox < Wo;
+    } else {
+        const long g = (long)lid * TP + t;
+        const int HoWo = Ho * Wo;
+        m.b = (int)(g / HoWo);
+        const int p = (int)(g - (long)m.b * HoWo);
+        m.oy = p / Wo;
+        m.ox = p - m.oy * Wo;
+        m.ok = m.b < B;
+    }
+    return m;
+}
+
+__device__ __forceinline__ int xcd_logical_tile(int nblocks) {
+    // block b runs on XCD b % 8: give every XCD a contiguous range of logical tiles (bijective)
+    const int bq = nblocks >> 3, brem = nblocks & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    return (xcd < brem ? xcd * (bq + 1) : brem * (bq + 1) + (xcd - brem) * bq) + slot;
+}
+
+template <int NPW, int NCW, int KC, int CBW, int STRIDE, bool MODE2D>
+__global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, int tiles_x, int tiles_y) {
+    constexpr int T = 64 * NPW * NCW;       // threads
+    constexpr int TP = 32 * NPW;            // pixels per workgroup tile
+    constexpr int SEGS = TP / 4;            // 4-pixel segments per channel
+    constexpr int CH_PASS = T / SEGS;       // channels covered by one pass of all threads
+    constexpr int ITEMS = KC / CH_PASS;     // depthwise segments per thread per chunk
+    static_assert(ITEMS >= 1 && KC % CH_PASS == 0, "chunk must cover whole passes");
+    constexpr int KS = KC / 2;              // MFMA k-steps per chunk
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wsm = smem;                       // [Cin][12]: 9 taps, bias, 2 pad
+    float *buf = smem + a.Cin * 12;          // [2][KC][TP]
+
+    for (int i = threadIdx.x; i < a.Cin * 12; i += T) {
+        const int ci = i / 12, r = i - ci * 12;
+        wsm[i] = r < 9 ? a.wd[ci * 9 + r] : (r == 9 ? a.bd[ci] : 0.f);
+    }
+
+    const int lid = xcd_logical_tile(gridDim.x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wp = wave % NPW, wc = wave / NPW;
+    const int r = lane & 31, hi = lane >> 5;
+    const int HW = a.H * a.W;
+
+    // ---- depthwise role: one 4-pixel segment, CH_PASS-strided channels
+    const int seg = threadIdx.x % SEGS, chl = threadIdx.x / SEGS;
+    const PixMap ms = map_pixel<MODE2D, TP>(lid, seg * 4, a.B, a.Ho, a.Wo, tiles_x, tiles_y);
+    const float *inb = a.in + (long)(ms.ok ? ms.b : 0) * a.Cin * HW;
+    int roff[3];
+    bool rok[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int iy = ms.oy * STRIDE - 1 + k;
+        rok[k] = ms.ok && iy >= 0 && iy < a.H;
+        roff[k] = rok[k] ? iy * a.W + ms.ox * STRIDE : 0;
+    }
+    const bool left_ok = ms.ox > 0;                            // column ox*STRIDE - 1 exists
+    const bool right_ok = STRIDE == 1 && ms.ox + 4 < a.W;      // column ox + 4 exists (stride 1 only)
+
+    auto depthwise_chunk = [&](int c0, float *dst) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int cl = it * CH_PASS + chl;
+            const int ch = c0 + cl;
+            const float *x = inb + (long)ch * HW;
+            const floatx4 w0 = *reinterpret_cast<const floatx4 *>(wsm + ch * 12);
+            const floatx4 w1 = *reinterpret_cast<const floatx4 *>(wsm + ch * 12 + 4);
+            const floatx4 w2 = *reinterpret_cast<const floatx4 *>(wsm + ch * 12 + 8);
+            const float wt[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0]};
+            floatx4 o = {w2[1], w2[1], w2[1], w2[1]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (STRIDE == 1) {
+                    float v[6];
+                    const floatx4 m = rok[k] ? *reinterpret_cast<const floatx4 *>(x + roff[k]) : floatx4{0.f, 0.f, 0.f, 0.f};
+                    v[0] = (rok[k] && left_ok) ? x[roff[k] - 1] : 0.f;
+                    v[5] = (rok[k] && right_ok) ? x[roff[k] + 4] : 0.f;
+                    v[1] = m[0]; v[2] = m[1]; v[3] = m[2]; v[4] = m[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = fmaf(v[j + 2], wt[3 * k + 2], fmaf(v[j + 1], wt[3 * k + 1], fmaf(v[j], wt[3 * k], o[j])));
+                } else {
+                    float v[9];
+                    const floatx4 m0 = rok[k] ? *reinterpret_cast<const floatx4 *>(x + roff[k]) : floatx4{0.f, 0.f, 0.f, 0.f};
+                    const floatx4 m1 = rok[k] ? *reinterpret_cast<const floatx4 *>(x + roff[k] + 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+                    v[0] = (rok[k] && left_ok) ? x[roff[k] - 1] : 0.f;
+                    v[1] = m0[0]; v[2] = m0[1]; v[3] = m0[2]; v[4] = m0[3];
+                    v[5] = m1[0]; v[6] = m1[1]; v[7] = m1[2]; v[8] = m1[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = fmaf(v[2 * j + 2], wt[3 * k + 2], fmaf(v[2 * j + 1], wt[3 * k + 1], fmaf(v[2 * j], wt[3 * k], o[j])));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+            *reinterpret_cast<floatx4 *>(dst + cl * TP + seg * 4) = o;
+        }
+    };
+
+    // ---- MFMA role: 32 pixels (wp) x CBW blocks of 32 output channels (wc)
+    floatx16 acc[CBW];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+    const int co_base = wc * CBW * 32;
+    float areg[KS][CBW], anext[KS][CBW];
+    auto load_weights = [&](int c0, float (&dst)[KS][CBW]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                const int co = co_base + cb * 32 + r;
+                dst[ks][cb] = co < a.Cout ? a.wp[(long)(c0 + 2 * ks + hi) * a.Cout + co] : 0.f;
+            }
+    };
+
+    const int nchunk = a.Cin / KC;
+    load_weights(0, areg);
+    __syncthreads();  // wsm ready
+    depthwise_chunk(0, buf);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const float *cur = buf + (c & 1) * KC * TP;
+        if (c + 1 < nchunk) {
+            load_weights((c + 1) * KC, anext);
+            depthwise_chunk((c + 1) * KC, buf + ((c + 1) & 1) * KC * TP);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float b = cur[(2 * ks + hi) * TP + wp * 32 + r];
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[ks][cb], b, acc[cb], 0, 0, 0);
+        }
+        if (c + 1 < nchunk) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) areg[ks][cb] = anext[ks][cb];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (r, hi) owns pixel r and channels cb*32 + (e&3) + 8*(e>>2) + 4*hi
+    const PixMap mo = map_pixel<MODE2D, TP>(lid, wp * 32 + r, a.B, a.Ho, a.Wo, tiles_x, tiles_y);
+    if (!mo.ok) return;
+    const int HoWo = a.Ho * a.Wo;
+    float *ob = a.out + (long)mo.b * a.Cout * HoWo + mo.oy * a.Wo + mo.ox;
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co < a.Cout) {
+                float v = acc[cb][e] + a.bp[co];
+                if (a.relu) v = fmaxf(v, 0.f);
+                ob[(long)co * HoWo] = v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------- plain 1x1 conv, one wave = 32 pixels x CBW*32 output channels
+template <int CBW>
+__global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_groups) {
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave id
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int n_cgroups = (a.Cout + CBW * 32 - 1) / (CBW * 32);
+    const int pg = gw / n_cgroups, cg = gw - pg * n_cgroups;
+    if (pg >= n_pix_groups) return;
+    const int HW = a.H * a.W;  // == Ho*Wo (stride 1)
+    const long g = (long)pg * 32 + r;
+    const bool ok = g < (long)a.B * HW;
+    const int b = ok ? (int)(g / HW) : 0;
+    const int p = ok ? (int)(g - (long)b * HW) : 0;
+    const float *x = a.in + (long)b * a.Cin * HW + p + (long)hi * HW;  // channel hi of k-step 0
+    const int co_base = cg * CBW * 32;
+    const float *w = a.wp + (long)hi * a.Cout + co_base + r;
+
+    floatx16 acc[CBW];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+
+    constexpr int U = 8;  // k-steps in flight
+    const int ksteps = a.Cin / 2;
+    float bx[U], aw[U][CBW];
+    auto load = [&](int ks0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = ks0 + u;
+            bx[u] = (ok && ks < ksteps) ? x[(long)2 * ks * HW] : 0.f;
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+                aw[u][cb] = (ks < ksteps && co_base + cb * 32 + r < a.Cout) ? w[(long)2 * ks * a.Cout + cb * 32] : 0.f;
+        }
+    };
+    load(0);
+    for (int ks0 = 0; ks0 < ksteps; ks0 += U) {
+        float cbx[U], caw[U][CBW];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cbx[u] = bx[u];
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) caw[u][cb] = aw[u][cb];
+        }
+        if (ks0 + U < ksteps) load(ks0 + U);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(caw[u][cb], cbx[u], acc[cb], 0, 0, 0);
+    }
+
+    if (!ok) return;
+    const int oy = p / a.W, ox = p - oy * a.W;
+    const float *addb = nullptr;
+    long add_cs = 0;
+    if (a.add) {
+        // F.interpolate(mode="nearest") to (Ho,Wo): src = min(floor(dst * (float)in/out), in-1)   (net.py:89,93)
+        const float sh = (float)a.add_h / (float)a.Ho, sw = (float)a.add_w / (float)a.Wo;
+        int ah = (int)floorf(oy * sh), awd = (int)floorf(ox * sw);
+        ah = ah < a.add_h - 1 ? ah : a.add_h - 1;
+        awd = awd < a.add_w - 1 ? awd : a.add_w - 1;
+        add_cs = (long)a.add_h * a.add_w;
+        addb = a.add + (long)b * a.Cout * add_cs + ah * a.add_w + awd;
+    }
+    float *ob = a.out + (long)b * a.Cout * HW + p;
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (co < a.Cout) {
+                float v = acc[cb][e] + a.bp[co];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (addb) v += addb[co * add_cs];
+                ob[(long)co * HW] = v;
+            }
+        }
+}
+
+template <int NPW, int NCW, int KC, int CBW, bool MODE2D>
+void launch_fused(const DwPwArgs &a, hipStream_t s) {
+    constexpr int TP = 32 * NPW;
+    int tiles_x = 0, tiles_y = 0;
+    long nblocks;
+    if (MODE2D) {
+        tiles_x = (a.Wo + 15) / 16;
+        tiles_y = (a.Ho + 7) / 8;
+        nblocks = (long)a.B * tiles_x * tiles_y;
+    } else {
+        nblocks = ((long)a.B * a.Ho * a.Wo + TP - 1) / TP;
+    }
+    const size_t lds = ((size_t)a.Cin * 12 + 2 * (size_t)KC * TP) * sizeof(float);
+    if (a.stride == 1)
+        hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 1, MODE2D>), dim3((unsigned)nblocks), dim3(64 * NPW * NCW), lds, s, a, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 2, MODE2D>), dim3((unsigned)nblocks), dim3(64 * NPW * NCW), lds, s, a, tiles_x, tiles_y);
+}
+
+}  // namespace
+
+// Returns false when the shape is outside what the MFMA kernels cover (the caller falls back to the scalar kernels).
+bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
+    if ((a.Cin & 1) || a.Cout < 16) return false;
+    if (!a.wd) {
+        if (a.stride != 1 || a.H != a.Ho || a.W != a.Wo) return false;
+        const long total = (long)a.B * a.H * a.W;
+        const int n_pix_groups = (int)((total + 31) / 32);
+        // one wave covers all output channels while that still fills the chip, otherwise 32 channels per wave
+        const bool wide = a.Cout >= 64 && (long)n_pix_groups >= 2048;
+        const int cbw = wide ? 2 : 1;
+        const int n_cgroups = (a.Cout + cbw * 32 - 1) / (cbw * 32);
+        const long waves = (long)n_pix_groups * n_cgroups;
+        const unsigned grid = (unsigned)((waves + 3) / 4);
+        if (wide) hipLaunchKernelGGL((pw_mfma_kernel<2>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
+        else hipLaunchKernelGGL((pw_mfma_kernel<1>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
+        return true;
+    }
+    if (a.add || (a.stride != 1 && a.stride != 2)) return false;
+    if ((a.Wo & 3) || a.W != a.stride * a.Wo) return false;                           // 4-pixel segments, aligned float4 rows
+    if (a.stride == 1 ? a.H != a.Ho : (a.H + 1) / 2 != a.Ho) return false;
+    if ((reinterpret_cast<uintptr_t>(a.in) & 15) || ((a.H * a.W) & 3)) return false;
+    const long total = (long)a.B * a.Ho * a.Wo;
+    const bool big = a.Wo >= 64 && (a.Wo % 16) == 0 && (a.Ho % 8) == 0;
+    if (a.Cout <= 32) {
+        if (a.Cin == 8) big ? launch_fused<4, 1, 8, 1, true>(a, s) : launch_fused<4, 1, 8, 1, false>(a, s);
+        else if (a.Cin == 16) big ? launch_fused<4, 1, 16, 1, true>(a, s) : launch_fused<4, 1, 16, 1, false>(a, s);
+        else if (a.Cin % 32 == 0) big ? launch_fused<4, 1, 32, 1, true>(a, s) : launch_fused<4, 1, 32, 1, false>(a, s);
+        else return false;
+        return true;
+    }
+    if (a.Cin % 32) return false;
+    if (a.Cout == 64 && total >= 128L * 512) {
+        big ? launch_fused<4, 1, 32, 2, true>(a, s) : launch_fused<4, 1, 32, 2, false>(a, s);
+    } else if (a.Cout == 128 || (a.Cout == 64)) {
+        if (a.Cout == 128) launch_fused<2, 2, 32, 2, false>(a, s);
+        else launch_fused<2, 2, 32, 1, false>(a, s);
+    } else if (a.Cout == 256) {
+        launch_fused<1, 4, 32, 2, false>(a, s);
+    } else {
+        return false;
+    }
+    return true;
+}
