@@ -426,6 +426,7 @@ struct frt_embedder {
     bool se = false;
     std::vector<ArcUnit> units;
     float *in_w, *in_s0, *in_b0, *in_slope, *in_s1, *in_b1;
+    half_t *in_wh = nullptr;
     half_t *wfc;
     float *fc_bias, *bn_s, *bn_b;
     // activations
@@ -476,6 +477,12 @@ void frt_embedder::build(const frt::Blob &b) {
         frt::bn_fold(b, "input_layer.1", 64, sc, bi);
         in_s0 = arena.upload(sc);
         in_b0 = arena.upload(bi);
+        std::vector<uint16_t> wh(64 * 32, 0);  // matrix-core layout (kernels_arc_input.hip): BN folded, bias in tap slot 27
+        for (int co = 0; co < 64; ++co) {
+            for (int k = 0; k < 27; ++k) wh[co * 32 + k] = frt::f32_to_f16(src[co * 27 + k] * sc[co]);
+            wh[co * 32 + 27] = frt::f32_to_f16(bi[co]);
+        }
+        in_wh = reinterpret_cast<half_t *>(arena.upload(wh));
         in_slope = arena.upload(vec_of(b, "input_layer.2.weight", 64));
         frt::bn_fold(b, "body.0.res_layer.0", 64, sc, bi);
         in_s1 = arena.upload(sc);
@@ -560,7 +567,7 @@ void frt_embedder::build(const frt::Blob &b) {
 
 void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s) {
     ProfScope ps(2, "embed_network", flops_per_face * F, s);
-    ArcInputArgs ia{chw_dev, in_w, in_s0, in_b0, in_slope, in_s1, in_b1, Y[0], Z[0], F, 112, 112};
+    ArcInputArgs ia{chw_dev, in_w, in_s0, in_b0, in_slope, in_s1, in_b1, Y[0], Z[0], F, 112, 112, in_wh};
     launch_arc_input(ia, s);
     int cur = 0;
     for (const ArcUnit &u : units) {

@@ -133,8 +133,10 @@ struct ArcInputArgs {
     const float *s1, *b1; // next unit's leading BN
     half_t *y, *z;        // z [F][112][112][64]; y (shortcut of unit 0) only at even positions: [F][56][56][64]
     int F, H, W;
+    const half_t *wh;     // matrix-core path: [64][32] fp16, k < 27: w * s0, k == 27: b0 (multiplies a constant 1), else 0
 };
 void launch_arc_input(const ArcInputArgs &a, hipStream_t s);
+bool launch_arc_input_mfma(const ArcInputArgs &a, hipStream_t s);  // kernels_arc_input.hip; false: shape not covered
 // partial [splits][F][512] -> +bias -> BN1d -> L2 normalise -> out [F][512] fp32; rows with valid[f]==0 become zeros.
 void launch_fc_finalize(const float *partial, int splits, int F, const float *bias, const float *s, const float *b, const int *valid,
                         float *out, hipStream_t s_);

@@ -983,6 +983,11 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
 }
 
 void launch_arc_input(const ArcInputArgs &a, hipStream_t s) {
+    static const bool use_mfma = [] {
+        const char *e = getenv("FRT_ARC_INPUT_MFMA");
+        return !(e && e[0] == '0');
+    }();
+    if (use_mfma && launch_arc_input_mfma(a, s)) return;
     const long total = (long)a.F * a.H * a.W * 8;  // 8 lanes per pixel
     hipLaunchKernelGGL(arc_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }

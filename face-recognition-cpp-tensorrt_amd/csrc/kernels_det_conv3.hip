@@ -11,7 +11,9 @@
 //     workgroups of a CU were always in the same phase.  Now the halo patch of the NEXT chunk (or next tile) is fetched
 //     global -> registers during the 9 taps of the current one and written to the other LDS buffer at the end.
 //   * every wave streaming its own weights L2 -> registers was L2-bound (3.4 TB/s of weight traffic): weights go through a
-//     double-buffered LDS tile shared by the 4 waves, fetched one tap ahead from a host-packed [tap][chunk][Cout][KC] copy.
+//     triple-buffered LDS tile shared by the 4 waves, fetched two taps ahead from a host-packed [tap][chunk][Cout][KC] copy,
+//     so that a tap's LDS operand reads can be issued one tap early, behind the previous tap's MFMAs (PMC: 67 % of the wave
+//     time was s_waitcnt when the reads sat in front of their own MFMAs).
 //   * LDS layouts are channel-fastest ([position][KC] and [cout][KC], rows padded by 16 B): a lane's 16 (KC=32) or 8 (KC=16)
 //     k-values are contiguous, so operands arrive as ds_read_b128 (12 reads per tap instead of 48 ds_read_b32).  k-step j of a
 //     chunk multiplies channels j (lanes 0-31) and j + KC/2 (lanes 32-63) - any pairing is valid as long as A and B agree.
@@ -47,7 +49,7 @@ __device__ __forceinline__ TileGeom tile_geom(const Conv3Mfma &mm, int t) {
 }
 
 template <int CB, int KC>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3Mfma mm, int tiles_per_wg) {
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(Conv3Mfma mm, int tiles_per_wg) {
     constexpr int KH = KC / 2;            // channels per lane half = k-steps per tap-chunk
     constexpr int PST = KC + 4;           // floats per patch position (row + 16 B pad: conflict-free ds_read_b128)
     constexpr int NPOS = 180;             // 10 x 18 halo positions
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3Mfma mm, int til
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *pbuf = smem;                                   // [2][NPOS][PST]
-    float *wbuf = smem + 2 * NPOS * PST;                  // [2][CB*32][PST]
+    float *wbuf = smem + 2 * NPOS * PST;                  // [3][CB*32][PST]
 
     // ---- this workgroup's tiles: wid, wid + nwg, wid + 2 nwg, ...  (wid is XCD-contiguous, so every XCD's L2 sees runs of
     //      nwg/8 neighbouring tiles; the strided walk keeps the per-workgroup tile counts within one of each other)
@@ -78,7 +80,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3Mfma mm, int til
 
     // ---- staging roles
     floatx4 pst[PPT];
+    unsigned pst_ok = 0;  // bit i: item i of pst is inside the image (the zeroing happens at store time, see below)
     auto fetch_patch = [&](int t, int cc) {
+        pst_ok = 0;
         const TileGeom g = tile_geom(mm, t);
         const Conv3Args &a = mm.p[g.lv];
         const long HW = (long)a.H * a.W;
@@ -94,11 +98,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3Mfma mm, int til
             // exec-masked branches with a vmcnt wait per group, which serialised the 24 gathers (45 us per tile, measured)
             const int qq = it < PITEMS ? q : 0;
             const float *src = inb + (long)(4 * qq) * HW + (ok ? iy * a.W + ix : 0);
-            const float v0 = src[0], v1 = src[HW], v2 = src[2 * HW], v3 = src[3 * HW];
-            pst[i][0] = ok ? v0 : 0.f;
-            pst[i][1] = ok ? v1 : 0.f;
-            pst[i][2] = ok ? v2 : 0.f;
-            pst[i][3] = ok ? v3 : 0.f;
+            // ... and the select is deferred to store_patch: a select here would need the data, i.e. a vmcnt(0) wait right
+            // after the loads, in front of the tap's MFMAs (the fetch sits in a branch, the compiler cannot sink it)
+            pst[i][0] = src[0];
+            pst[i][1] = src[HW];
+            pst[i][2] = src[2 * HW];
+            pst[i][3] = src[3 * HW];
+            pst_ok |= ok ? (1u << i) : 0u;
         }
     };
     auto store_patch = [&](float *dst) {
@@ -106,7 +112,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3Mfma mm, int til
         for (int i = 0; i < PPT; ++i) {
             const int it = threadIdx.x + i * 256;
             const int q = it / NPOS, pos = it - q * NPOS;
-            if (it < PITEMS) *reinterpret_cast<floatx4 *>(dst + pos * PST + 4 * q) = pst[i];
+            const bool ok = (pst_ok >> i) & 1u;
+            floatx4 v;
+            v[0] = ok ? pst[i][0] : 0.f;
+            v[1] = ok ? pst[i][1] : 0.f;
+            v[2] = ok ? pst[i][2] : 0.f;
+            v[3] = ok ? pst[i][3] : 0.f;
+            if (it < PITEMS) *reinterpret_cast<floatx4 *>(dst + pos * PST + 4 * q) = v;
         }
     };
     floatx4 wst[WPT];
@@ -127,86 +139,135 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(Conv3Mfma mm, int til
         }
     };
 
-    // ---- prologue: first patch chunk and first weight chunk
-    {
-        const TileGeom g0 = tile_geom(mm, t_lo);
-        fetch_patch(t_lo, 0);
-        fetch_weights(g0.lv, 0, 0);
-        store_patch(pbuf);
-        store_weights(wbuf);
-    }
+    // ---- the work of this workgroup as a flat sequence of steps (round k -> tile, chunk cc, tap); pc = patch buffer of the chunk
+    struct Step {
+        int k, t, cc, tap, pc;
+    };
+    const int k_full = total / nwg, rem_tiles = total - k_full * nwg;
+    auto tile_of = [&](int k) {
+        // full rounds walk XCD-contiguous ids; the last partial round is dealt out in blockIdx order, i.e. round-robin over the
+        // XCDs (dealt by wid, all remainder tiles land on XCD 0 and its CUs finish a whole tile after everybody else)
+        if (k < k_full) return wid + k * nwg;
+        return (k == k_full && (int)blockIdx.x < rem_tiles) ? k_full * nwg + (int)blockIdx.x : total;
+    };
+    auto advance = [&](Step s) {
+        if (++s.tap == 9) {
+            s.tap = 0;
+            s.pc ^= 1;
+            if (++s.cc == ncc) {
+                s.cc = 0;
+                s.t = tile_of(++s.k);
+            }
+        }
+        return s;
+    };
+    auto lv_of = [&](int t) { return t >= mm.base[2] ? 2 : (t >= mm.base[1] ? 1 : 0); };
+    const int lane_pos = (ty * 18 + tx) * PST + hi * KH;
+    auto read_operands = [&](const Step &st, int wslot, floatx4 (&bv)[NV], floatx4 (&av)[CB][NV]) {
+        const int kh = st.tap / 3, kw = st.tap - kh * 3;
+        const float *bp = pbuf + st.pc * NPOS * PST + lane_pos + (kh * 18 + kw) * PST;
+        const float *ap = wbuf + wslot * (CB * 32) * PST + r * PST + hi * KH;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            bv[v] = *reinterpret_cast<const floatx4 *>(bp + 4 * v);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) av[cb][v] = *reinterpret_cast<const floatx4 *>(ap + cb * 32 * PST + 4 * v);
+        }
+    };
+
+    Step s0{0, tile_of(0), 0, 0, 0};
+    if (s0.t >= total) return;
+    Step s1 = advance(s0), s2 = advance(s1);
+
+    // ---- prologue: patch of the first chunk, weights of steps 0 and 1
+    fetch_patch(s0.t, 0);
+    fetch_weights(lv_of(s0.t), 0, 0);
+    store_patch(pbuf);
+    store_weights(wbuf);
+    fetch_weights(lv_of(s1.t), s1.cc, s1.tap);  // a tile has >= 9 steps: s1 is always valid
+    store_weights(wbuf + (CB * 32) * PST);
     __syncthreads();
 
-    int pcur = 0, wcur = 0;
-    for (int t = t_lo; t < t_hi; t += nwg) {
-        const TileGeom g = tile_geom(mm, t);
-        const Conv3Args &a = mm.p[g.lv];
-        floatx16 acc[CB];
+    floatx16 acc[CB];
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+    floatx4 bvA[NV], avA[CB][NV], bvB[NV], avB[CB][NV];
+    read_operands(s0, 0, bvA, avA);
+    int w0 = 0;            // weight slot of s0 (s1: w0+1, s2: w0+2, mod 3)
+    bool has_np = false;   // a next patch chunk is in flight (fetched at tap 0, stored at tap 7)
 
-        for (int cc = 0; cc < ncc; ++cc) {
-            // what comes after this (tile, chunk)?
-            const bool last_cc = cc + 1 == ncc;
-            const bool has_next = !last_cc || t + nwg < t_hi;
-            const int nt = last_cc ? t + nwg : t, ncc_i = last_cc ? 0 : cc + 1;
-            const int nlv = has_next ? tile_geom(mm, nt).lv : g.lv;
-            const float *pb = pbuf + pcur * NPOS * PST + (ty * 18 + tx) * PST + hi * KH;
-#pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap == 0 && has_next) fetch_patch(nt, ncc_i);
-                const bool wnext = tap < 8 || has_next;
-                if (wnext) {
-                    if (tap < 8) fetch_weights(g.lv, cc, tap + 1);
-                    else fetch_weights(nlv, ncc_i, 0);
-                }
-                const int kh = tap / 3, kw = tap - kh * 3;
-                const float *bp = pb + (kh * 18 + kw) * PST;
-                const float *ap = wbuf + wcur * (CB * 32) * PST + r * PST + hi * KH;
-                floatx4 bv[NV], av[CB][NV];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    bv[v] = *reinterpret_cast<const floatx4 *>(bp + 4 * v);
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) av[cb][v] = *reinterpret_cast<const floatx4 *>(ap + cb * 32 * PST + 4 * v);
-                }
-#pragma unroll
-                for (int v = 0; v < NV; ++v)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int cb = 0; cb < CB; ++cb)
-                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][v][j], bv[v][j], acc[cb], 0, 0, 0);
-                if (wnext) store_weights(wbuf + (wcur ^ 1) * (CB * 32) * PST);
-                if (tap == 8 && has_next) store_patch(pbuf + (pcur ^ 1) * NPOS * PST);
-                __syncthreads();
-                wcur ^= 1;
-            }
-            pcur ^= 1;
+    // One step.  Operands of the CURRENT step are already in registers; this step's LDS reads fetch the NEXT step's operands and
+    // its global loads the weights of the step after that, both behind the 16*CB MFMAs.  Returns true after the last step.
+    auto step = [&](floatx4 (&bv)[NV], floatx4 (&av)[CB][NV], floatx4 (&bvn)[NV], floatx4 (&avn)[CB][NV]) -> bool {
+        const bool v1 = s1.t < total, v2 = s2.t < total;
+        if (s0.tap == 0) {
+            Step c = s0;
+            c.tap = 8;
+            c = advance(c);
+            has_np = c.t < total;
+            if (has_np) fetch_patch(c.t, c.cc);
         }
-
-        // ---- epilogue: lane (r, hi) owns pixel r and channels cb*32 + (e&3) + 8*(e>>2) + 4*hi
-        const int oy = g.oy0 + ty, ox = g.ox0 + tx;
-        if (oy < a.Ho && ox < a.Wo) {
+        // The common part is ONE basic block with a pinned order - loads | MFMA group 0 | LDS reads of the next operands | MFMA
+        // groups | LDS writes of the weights | last MFMA group - so that everything that is not an MFMA issues in the shadow
+        // of this wave's own MFMAs.  (With the non-MFMA work behind all MFMAs, the two waves of a SIMD - round-robin on the
+        // matrix pipe - fall into lock-step and do their non-MFMA work at the same time: pipe 65 % busy, measured.)  Invalid
+        // next steps are clamped to this step's own coordinates: the loads stay in bounds, the results are never used.
+        const Step f2 = v2 ? s2 : s0, f1 = v1 ? s1 : s0;
+        const int w1 = w0 == 2 ? 0 : w0 + 1, w2 = w1 == 2 ? 0 : w1 + 1;
+        fetch_weights(lv_of(f2.t), f2.cc, f2.tap);
+        auto mfma_group = [&](int v) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][v][j], bv[v][j], acc[cb], 0, 0, 0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_operands(f1, v1 ? w1 : w0, bvn, avn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 1; v < NV - 1; ++v) mfma_group(v);
+        __builtin_amdgcn_sched_barrier(0);
+        store_weights(wbuf + w2 * (CB * 32) * PST);
+        __builtin_amdgcn_sched_barrier(0);
+        if (NV > 1) mfma_group(NV - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0.tap == 7 && has_np) store_patch(pbuf + (s0.pc ^ 1) * NPOS * PST);
+        if (s0.tap == 8 && s0.cc == ncc - 1) {
+            // ---- tile finished: lane (r, hi) owns pixel r and channels cb*32 + (e&3) + 8*(e>>2) + 4*hi
+            const TileGeom g = tile_geom(mm, s0.t);
+            const Conv3Args &a = mm.p[g.lv];
+            const int oy = g.oy0 + ty, ox = g.ox0 + tx;
+            const bool inside = oy < a.Ho && ox < a.Wo;
             const long HoWo = (long)a.Ho * a.Wo;
-            const long pix = (long)oy * a.Wo + ox;
+            const long pix = inside ? (long)oy * a.Wo + ox : 0;
             float *o1 = a.out + ((long)g.b * a.out_ctotal + a.out_coff) * HoWo + pix;
-            float *o2 = a.out2 ? a.out2 + ((long)g.b * a.out2_ctotal + a.out2_coff - a.split) * HoWo + pix : nullptr;
+            float *o2 = a.out2 ? a.out2 + ((long)g.b * a.out2_ctotal + a.out2_coff - a.split) * HoWo + pix : o1;
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    if (co < a.Cout) {
-                        float v = acc[cb][e] + a.b[co];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (co < a.split) o1[co * HoWo] = v;
-                        else o2[co * HoWo] = v;
-                    }
+                    float v = acc[cb][e] + a.b[co < a.Cout ? co : 0];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (inside && co < a.Cout) (co < a.split ? o1 : o2)[co * HoWo] = v;
+                    acc[cb][e] = 0.f;
                 }
         }
+        if (!v1) return true;
+        __syncthreads();
+        s0 = s1;
+        s1 = s2;
+        s2 = advance(s2);
+        w0 = w1;
+        return false;
+    };
+    for (;;) {
+        if (step(bvA, avA, bvB, avB)) break;
+        if (step(bvB, avB, bvA, avA)) break;
     }
 }
 
@@ -230,6 +291,8 @@ bool launch_conv3x3_mfma(const Conv3Args *a, int n, hipStream_t s) {
     for (int i = n; i < 4; ++i) mm.base[i] = base;  // unused levels start past the end: never selected
     const int cin = a[0].Cin, cout = a[0].Cout;
     const int kc = cin == 16 ? 16 : 32;
+    // 16 -> 16 convs: 8 MFMAs per step cannot hide a step's fixed costs (measured 51 us against 31 us for the scalar kernel)
+    if (cin == 16 && !getenv("FRT_C3_FORCE16")) return false;
     if (cout > 64 || cout < 16 || cin % kc || a[0].wm_kc != kc) return false;
     const int cb = cout > 32 ? 2 : 1;
     if (a[0].wm_cpad != cb * 32) return false;
@@ -240,7 +303,7 @@ bool launch_conv3x3_mfma(const Conv3Args *a, int n, hipStream_t s) {
     int grid = 256 * wg_per_cu;
     if (grid > base) grid = base;
     const int tiles_per_wg = (base + grid - 1) / grid;
-    const size_t lds = (size_t)(2 * 180 + 2 * cb * 32) * (kc + 4) * sizeof(float);
+    const size_t lds = (size_t)(2 * 180 + 3 * cb * 32) * (kc + 4) * sizeof(float);
     if (kc == 16) {
         if (cb == 2) hipLaunchKernelGGL((conv3x3_mfma_kernel<2, 16>), dim3(grid), dim3(256), lds, s, mm, tiles_per_wg);
         else hipLaunchKernelGGL((conv3x3_mfma_kernel<1, 16>), dim3(grid), dim3(256), lds, s, mm, tiles_per_wg);
