@@ -329,6 +329,12 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
     if ((a.Wo & 3) || a.W != a.stride * a.Wo) return false;                           // 4-pixel segments, aligned float4 rows
     if (a.stride == 1 ? a.H != a.Ho : (a.H + 1) / 2 != a.Ho) return false;
     if ((reinterpret_cast<uintptr_t>(a.in) & 15) || ((a.H * a.W) & 3)) return false;
+    // Measured per block at batch 32 (us, scalar fused kernel vs this one): 8->16 @320^2 112 vs 152, 32->32 @160^2 98 vs 118 -
+    // the stride-1 blocks with <= 32 channels are pure stencil + HBM traffic and the per-tile LDS round trip only costs;
+    // everything else is faster here (16->32/2: 145 vs 100, 64->64 @80^2: 169 vs 70, 128->128 @40^2: 77 vs 59).
+    // (A persistent, 3-stage software-pipelined variant of this kernel was also tried: slower on every block - fewer, fatter
+    // waves hide the load latency worse than three small resident workgroups per CU do.)
+    if (a.Cout <= 32 && a.Cin <= 32 && a.stride == 1 && !getenv("FRT_DWPW_FORCE_MFMA")) return false;
     const long total = (long)a.B * a.Ho * a.Wo;
     const bool big = a.Wo >= 64 && (a.Wo % 16) == 0 && (a.Ho % 8) == 0;
     if (a.Cout <= 32) {
