@@ -140,7 +140,9 @@ struct frt_detector {
     float *d_landmarks = nullptr;  // decoded, frame coordinates [B][max_faces][10]
 
     void build(const frt::Blob &b);
-    void forward(int n, hipStream_t s);          // d_input -> d_loc/d_conf
+    void forward(int n, hipStream_t s, int first_op = 0);  // d_input -> d_loc/d_conf (first_op = 1: op 0 already ran)
+    // preprocess + forward; when the letterbox is the identity the first conv reads the u8 frames and d_input is never written
+    void forward_frames(const uint8_t *frames_dev, int n, size_t row_stride, size_t frame_stride, hipStream_t s);
     void postprocess(int n, hipStream_t s);      // d_loc/d_conf -> d_boxes/d_nout
     void preprocess(const uint8_t *frames_dev, int n, size_t row_stride, size_t frame_stride, hipStream_t s);
 };
@@ -373,9 +375,24 @@ void frt_detector::preprocess(const uint8_t *frames_dev, int n, size_t row_strid
     launch_det_preprocess(frames_dev, n, g.frame_h, g.frame_w, row_stride, frame_stride, g.in_h, g.in_w, d_input, s);
 }
 
-void frt_detector::forward(int n, hipStream_t s) {
+void frt_detector::forward_frames(const uint8_t *frames_dev, int n, size_t row_stride, size_t frame_stride, hipStream_t s) {
+    if (g.frame_h == g.in_h && g.frame_w == g.in_w && !ops.empty() && ops[0].type == 1 && ops[0].n == 1) {
+        Conv3Args c = ops[0].c3[0];
+        c.B = n;
+        bool fused;
+        {
+            ProfScope ps(2, "det_preprocess", (double)n * g.frame_h * g.frame_w * 3, s);  // fused into the first conv
+            fused = launch_det_conv1_u8(frames_dev, row_stride, frame_stride, c, s);
+        }
+        if (fused) return forward(n, s, 1);
+    }
+    preprocess(frames_dev, n, row_stride, frame_stride, s);
+    forward(n, s);
+}
+
+void frt_detector::forward(int n, hipStream_t s, int first_op) {
     ProfScope ps(2, "det_network", flops_per_frame * n, s);
-    int skip = 0;
+    int skip = first_op;
     for (Op &o : ops) {
         if (skip > 0) {
             --skip;
@@ -752,8 +769,7 @@ struct frt_pipeline {
             // frames must be valid when the call is made: waiting for all prior work on `s` here would serialise the two streams.
             HIPCHK(hipStreamWaitEvent(ds, ev_in[slot], 0));
         }
-        det->preprocess(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, ds);
-        det->forward(n, ds);
+        det->forward_frames(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, ds);
         det->postprocess(n, ds);
         HIPCHK(hipMemcpyAsync(slot_boxes[slot], det->d_boxes, sizeof(frt_bbox) * F, hipMemcpyDeviceToDevice, ds));
         HIPCHK(hipMemcpyAsync(slot_nout[slot], det->d_nout, sizeof(int) * n, hipMemcpyDeviceToDevice, ds));
@@ -883,8 +899,7 @@ int frt_detector_find_faces_batch(frt_detector *d, const uint8_t *bgr, int n_fra
         for (int f = 0; f < n_frames; ++f)
             HIPCHK(hipMemcpy2DAsync(d->d_frames + (size_t)f * rows * tight, tight, bgr + (size_t)f * frame_stride, row_stride, tight, rows,
                                     hipMemcpyHostToDevice, s));
-        d->preprocess(d->d_frames, n_frames, tight, (size_t)rows * tight, s);
-        d->forward(n_frames, s);
+        d->forward_frames(d->d_frames, n_frames, tight, (size_t)rows * tight, s);
         d->postprocess(n_frames, s);
         HIPCHK(hipMemcpyAsync(out, d->d_boxes, sizeof(frt_bbox) * n_frames * d->g.max_faces, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(n_out, d->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, s));
@@ -909,8 +924,7 @@ int frt_detector_find_faces_landmarks(frt_detector *d, const uint8_t *bgr, int r
         hipStream_t s = d->stream;
         const size_t tight = (size_t)cols * 3;
         HIPCHK(hipMemcpy2DAsync(d->d_frames, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice, s));
-        d->preprocess(d->d_frames, 1, tight, (size_t)rows * tight, s);
-        d->forward(1, s);
+        d->forward_frames(d->d_frames, 1, tight, (size_t)rows * tight, s);
         d->postprocess(1, s);
         HIPCHK(hipMemcpyAsync(out, d->d_boxes, sizeof(frt_bbox) * d->g.max_faces, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(landmarks_out, d->d_landmarks, sizeof(float) * 10 * d->g.max_faces, hipMemcpyDeviceToHost, s));

@@ -220,6 +220,54 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Multi mm) {
     }
 }
 
+// ---------------------------------------------------------------- first conv straight from the u8 frame (identity letterbox only)
+// RetinaFace::preprocess (retinaface.cpp:106-136) followed by body.stage1.0 (net.py:104, conv_bn 3->8, stride 2): when the frame
+// already has the network's input size the letterbox is the identity, preprocessing is "minus (104,117,123)" and the fp32
+// planar input tensor (157 MB per 32 frames, written once and read once) need not exist: every tap is read from the u8 HWC
+// frame, converted, mean-subtracted in a register (the same fp32 value the separate kernel would have stored) and fed to
+// the same FMA chain.  Zero padding applies to the preprocessed tensor, so taps outside the frame contribute 0, not -mean.
+__global__ __launch_bounds__(256) void det_conv1_u8_kernel(const uint8_t *__restrict__ frames, size_t row_stride, size_t frame_stride, Conv3Args a) {
+    const long gp = (long)blockIdx.x * 256 + threadIdx.x;
+    const int HoWo = a.Ho * a.Wo;
+    if (gp >= (long)a.B * HoWo) return;
+    const int b = (int)(gp / HoWo), p = (int)(gp - (long)b * HoWo);
+    const int oh = p / a.Wo, ow = p - oh * a.Wo;
+    const uint8_t *fb = frames + (size_t)b * frame_stride;
+    const float mean[3] = {104.f, 117.f, 123.f};
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    float v[3][9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+            const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            const uint8_t *px = fb + (size_t)(ok ? ih : 0) * row_stride + (size_t)(ok ? iw : 0) * 3;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float raw = (float)px[ci];  // unconditional load, masked afterwards
+                v[ci][kh * 3 + kw] = ok ? raw - mean[ci] : 0.f;
+            }
+        }
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {  // same accumulation order as conv3x3_kernel: ci outer, tap inner
+        const float *w = a.w + ((long)ci * 9) * a.Cout;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[ci][t], w[t * a.Cout + c], acc[c]);
+    }
+    float *ob = a.out + ((long)b * a.out_ctotal + a.out_coff) * HoWo + p;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float o = acc[c] + a.b[c];
+        if (a.relu) o = fmaxf(o, 0.f);
+        ob[(long)c * HoWo] = o;
+    }
+}
+
 // ---------------------------------------------------------------- heads: 1x1 64->8 (bbox) and 64->4 (class) + softmax, NHWC order
 struct HeadMulti {
     HeadArgs p[3];
@@ -359,6 +407,13 @@ void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s) {
 }
 
 void launch_conv3x3(const Conv3Args &a, hipStream_t s) { launch_conv3x3_multi(&a, 1, s); }
+
+bool launch_det_conv1_u8(const uint8_t *frames, size_t row_stride, size_t frame_stride, const Conv3Args &a, hipStream_t s) {
+    if (a.Cin != 3 || a.Cout != 8 || a.stride != 2 || getenv("FRT_DET_NO_FUSED_INPUT")) return false;
+    const long total = (long)a.B * a.Ho * a.Wo;
+    hipLaunchKernelGGL(det_conv1_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, row_stride, frame_stride, a);
+    return true;
+}
 
 void launch_heads_multi(const HeadArgs *a, int n, hipStream_t s) {
     HeadMulti mm;
