@@ -126,6 +126,8 @@ struct ConvMfmaArgs {
     const half_t *zeros;  // >= 16 bytes of zeros (source of padded taps for the LDS-DMA path)
 };
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
+bool conv64_applies(const ConvMfmaArgs &a);                 // kernels_arc_c64.hip: Cin = Cout = 64, 3x3, stride 1
+bool launch_conv64(const ConvMfmaArgs &a, hipStream_t s);
 const char *conv_kernel_label(const ConvMfmaArgs &a);  // kernel symbol (as rocprofv3 prints it) a launch resolves to
 struct ArcInputArgs {
     const float *x;       // [F][3][112][112] planar RGB

@@ -952,11 +952,14 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
                                   "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true>",
                                   "conv_patch_kernel<3, 5, 5, true, 0, false>", "conv_patch_kernel<2, 5, 5, false, 0, false>",
                                   "conv_patch_kernel<2, 6, 4, false, 0, false>"};
+    if (conv64_applies(a))
+        return a.mode == EPI_PRELU ? "conv64_kernel<0>" : (a.mode == EPI_BN ? "conv64_kernel<1>" : "conv64_kernel<2>");
     int R, n_img;
     return names[conv_variant(a, R, n_img)];
 }
 
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
+    if (launch_conv64(a, s)) return;  // dedicated 64 -> 64 stride-1 kernel (kernels_arc_c64.hip)
     int R = 0, n_img = 0;
     const int v = conv_variant(a, R, n_img);
     static const int abl = getenv("FRT_CONV_ABLATE") ? atoi(getenv("FRT_CONV_ABLATE")) : 0;  // timing experiments only
