@@ -72,6 +72,7 @@ ABI = {
     "frt_pipeline_sync": (_i, [_vp]),
     "frt_pipeline_set_stream": (_i, [_vp, _vp]),
     "frt_pipeline_set_overlap": (_i, [_vp, _i]),
+    "frt_pipeline_set_graph": (_i, [_vp, _i]),
     "frt_detector_has_landmarks": (_i, [_vp]),
     "frt_detector_find_faces_landmarks": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _vp]),
     "frt_detector_infer_landmarks": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -422,6 +423,10 @@ class Pipeline:
     def set_overlap(self, enable):
         """Two-stream software pipelining of consecutive calls (detector of call b+1 under embed/match of call b)."""
         _check(lib.frt_pipeline_set_overlap(self._h, 1 if enable else 0))
+
+    def set_graph(self, enable):
+        """hipGraph replay of repeated calls (default on)."""
+        _check(lib.frt_pipeline_set_graph(self._h, 1 if enable else 0))
 
     def set_align(self, enable):
         """Optional 5-point aligned crop instead of the reference's bbox crop (needs a detector blob with LandmarkHead)."""

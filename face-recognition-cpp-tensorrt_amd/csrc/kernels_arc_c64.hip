@@ -7,11 +7,11 @@
 //   * persistent 2-wave workgroups (wave = one 32-cout block); the wave's whole weight slice [32 cout][576 k] lives in 144
 //     VGPRs for the lifetime of the kernel - no weight traffic at all after the first microsecond;
 //   * a work item is a strip of 2 image rows x 56 columns (112 pixels = 3.5 MFMA pixel tiles, 4 accumulators): its halo patch
-//     (4 x 58 pixels x 144-byte rows) is 33 KB, double-buffered in LDS -> two workgroups per CU; the NEXT strip's patch is
-//     fetched global -> registers at the start of a strip and written to the other buffer at its end, so loads, MFMAs and the
-//     previous strip's stores overlap;
-//   * per (tap, 16-channel step) one A fragment from registers and four ds_read_b128 B fragments, prefetched two steps ahead
-//     through a 3-deep register ring; every B address is one per-tile base register plus an immediate;
+//     (4 x 58 pixels x 144-byte rows) is 34 KB, double-buffered in LDS -> two workgroups per CU; the NEXT strip's patch is
+//     DMA'd global -> LDS (global_load_lds, 17 instructions per wave) at the start of a strip, so loads, MFMAs and the
+//     previous strip's stores overlap and staging costs no VGPRs;
+//   * per (tap, 16-channel step) one A fragment from registers and four ds_read_b128 B fragments, prefetched four steps ahead
+//     through a 5-deep register ring; every B address is one per-tile base register plus an immediate;
 //   * epilogue through a wave-private fp32 LDS tile: the lane-owns-a-pixel accumulator becomes 64-byte NHWC half-rows, the
 //     per-channel parameters a lane needs (8 channels) sit in registers; same arithmetic and rounding points as the generic
 //     epilogue (fp32 BN / PReLU / shortcut add, one rounding to fp16 per output).
@@ -24,12 +24,12 @@ namespace {
 constexpr int SW = 56;                 // strip width (pixels)
 constexpr int PW = SW + 2;             // patch width
 constexpr int PROWB = 144;             // bytes per patch pixel (128 data + 16 pad: conflict-free ds_read_b128)
-constexpr int PATCH_B = 4 * PW * PROWB;  // 33408
-constexpr int NSEG = 4 * PW * 8;       // 16-byte segments per patch = 1856
-constexpr int SPT = (NSEG + 127) / 128;  // per thread = 15
+constexpr int NDMA = (4 * PW * 9 + 127) / 128;  // LDS-DMA instructions per wave per patch (2088 16-byte slots / 2 waves / 64 lanes) = 17
+constexpr int PATCH_B = NDMA * 2 * 1024;        // 34816: whole DMA slots
+constexpr int RING = 5;                // B-fragment register ring: fragments are requested RING-1 steps (128 clk each) ahead
 constexpr int EROW = 36;               // floats per pixel row of the epilogue tile (32 + 4 pad)
 
-template <int MODE>
+template <int MODE, int abl = 0>  // abl (measurement only): 1 no B reads, 2 no MFMA, 4 no epilogue
 __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strips) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *patch = smem;                                           // [2][PATCH_B]
@@ -80,46 +80,42 @@ __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strip
         bbase[t] = (row * PW + col) * PROWB + hi * 16;
     }
 
-    // ---- patch staging: segment j = tid + 128 i  ->  patch pixel j / 8, 16-byte part j % 8
-    half8 pst[SPT];
-    unsigned pok = 0;
-    auto fetch_patch = [&](int strip) {
+    // ---- patch staging by LDS-DMA (global_load_lds: no VGPR round trip, no ds_write, completion counted by vmcnt).  The DMA
+    //      writes wave-base + lane*16, so the patch image is slot-linear: slot = pixel*9 + part (part 8 = the 16-byte pad, fed
+    //      from the zero buffer like every out-of-image pixel).  Wave w issues DMA q for slots (2q + w)*64 + lane.  Everything
+    //      that does not depend on the strip is precomputed: rel = offset inside the strip's window, need = which borders the
+    //      slot's pixel touches (bit0 top halo row, bit1 bottom halo row, bit2 left halo column, bit3 right, bit4 always zero).
+    unsigned prel[NDMA];
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) {
+        const int slot = (2 * q + cb) * 64 + lane;
+        const int pix = slot / 9, part = slot - pix * 9;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const bool dead = part == 8 || pix >= 4 * PW;
+        const unsigned need = dead ? 16u : ((pr == 0 ? 1u : 0u) | (pr == 3 ? 2u : 0u) | (pc == 0 ? 4u : 0u) | (pc == PW - 1 ? 8u : 0u));
+        const unsigned rel = dead ? 0u : (unsigned)((pr * W + pc) * 64 + part * 8);  // halves, relative to (y0, x0)
+        prel[q] = rel | (need << 27);
+    }
+    auto issue_patch = [&](int strip, char *dst) {
         const int b = strip / strips_per_img, rem = strip - b * strips_per_img;
         const int sy = rem / strips_x, sx = rem - sy * strips_x;
         const int y0 = sy * 2 - 1, x0 = sx * SW - 1;
-        const half_t *img = p.x + (long)b * H * W * 64;
-        pok = 0;
+        const unsigned edge = 16u | (y0 < 0 ? 1u : 0u) | (y0 + 3 >= H ? 2u : 0u) | (x0 < 0 ? 4u : 0u) | (x0 + PW - 1 >= W ? 8u : 0u);
+        const half_t *win = p.x + ((long)b * H * W + (long)y0 * W + x0) * 64;  // may point before the image: only used with rel of valid pixels
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            const int j = tid + 128 * i;
-            const int pix = j >> 3, part = j & 7;
-            const int pr = pix / PW, pc = pix - pr * PW;
-            const int iy = y0 + pr, ix = x0 + pc;
-            const bool ok = j < NSEG && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            // unconditional load from a clamped address; zeroed at store time (no load behind a branch, no early wait)
-            pst[i] = *reinterpret_cast<const half8 *>(img + ((long)(ok ? iy : 0) * W + (ok ? ix : 0)) * 64 + part * 8);
-            pok |= ok ? (1u << i) : 0u;
-        }
-    };
-    auto store_patch = [&](char *dst) {
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            const int j = tid + 128 * i;
-            const int pix = j >> 3, part = j & 7;
-            half8 v = pst[i];
-            if (!((pok >> i) & 1u)) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
-            }
-            if (j < NSEG) *reinterpret_cast<half8 *>(dst + pix * PROWB + part * 16) = v;
+        for (int q = 0; q < NDMA; ++q) {
+            const bool live = ((prel[q] >> 27) & edge) == 0;
+            const half_t *src = live ? win + (prel[q] & 0x7ffffffu) : p.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + (2 * q + cb) * 1024), 16, 0, 0);
         }
     };
 
     int k = 0;
     int strip = strip_of(0);
     if (strip >= n_strips) return;
-    fetch_patch(strip);
-    store_patch(patch);
+    issue_patch(strip, patch);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
 
@@ -127,7 +123,7 @@ __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strip
     for (;;) {
         const int next = strip_of(k + 1);
         const bool has_next = next < n_strips;
-        if (has_next) fetch_patch(next);
+        if (has_next) issue_patch(next, patch + (cur ^ 1) * PATCH_B);  // that buffer's readers retired at the last barrier
 
         floatx16 acc[4];
 #pragma unroll
@@ -137,7 +133,7 @@ __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strip
 
         const char *pb = patch + cur * PATCH_B;
         // 36 steps (tap, kk); B fragments of step s+2 are requested before the MFMAs of step s
-        half8 bf[3][4];
+        half8 bf[RING][4];
         auto read_b = [&](int s, half8 (&dst)[4]) {
             const int tap = s >> 2, kk = s & 3;
             const int kh = tap / 3, kw = tap - kh * 3;
@@ -145,19 +141,28 @@ __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strip
 #pragma unroll
             for (int t = 0; t < 4; ++t) dst[t] = *reinterpret_cast<const half8 *>(pb + bbase[t] + off);
         };
-        read_b(0, bf[0]);
-        read_b(1, bf[1]);
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s)
+            if (!(abl & 1)) read_b(s, bf[s]);
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
-            if (s + 2 < 36) read_b(s + 2, bf[(s + 2) % 3]);
+            if (s + RING - 1 < 36 && !(abl & 1)) read_b(s + RING - 1, bf[(s + RING - 1) % RING]);
             __builtin_amdgcn_sched_barrier(0);
+            if (!(abl & 2)) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s >> 2][s & 3], bf[s % 3][t], acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s >> 2][s & 3], bf[s % RING][t], acc[t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t][s & 15] += (float)bf[s % RING][t][0] * (float)wreg[s >> 2][s & 3][0];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        // the next patch has had the whole MFMA loop to land; waiting here (not after the epilogue) keeps this strip's
+        // output stores out of the wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ---- epilogue of this strip
-        {
+        if (!(abl & 4)) {
             const int b = strip / strips_per_img, rem = strip - b * strips_per_img;
             const int sy = rem / strips_x, sx = rem - sy * strips_x;
             const long img_base = (long)b * H * W;
@@ -206,7 +211,6 @@ __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strip
             }
         }
         if (!has_next) break;
-        store_patch(patch + (cur ^ 1) * PATCH_B);
         __syncthreads();
         cur ^= 1;
         strip = next;
@@ -236,12 +240,30 @@ bool launch_conv64(const ConvMfmaArgs &a, hipStream_t s) {
     int grid = 512;
     if (grid > n_strips) grid = n_strips;
     const size_t lds = 2 * PATCH_B + 2 * 32 * EROW * sizeof(float);
+    static const int abl = getenv("FRT_C64_ABLATE") ? atoi(getenv("FRT_C64_ABLATE")) : 0;  // measurement only: 1 no B reads, 2 no MFMA, 4 no epilogue
     static bool attr_done = false;
     if (!attr_done) {  // > 64 KB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_PRELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_BN_ADD_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
+    }
+    if (abl && a.mode == EPI_PRELU) {
+        static bool ad = false;
+        if (!ad) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_PRELU, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_PRELU, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_PRELU, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_PRELU, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_PRELU, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ad = true;
+        }
+        if (abl == 1) hipLaunchKernelGGL((conv64_kernel<EPI_PRELU, 1>), dim3(grid), dim3(128), lds, s, a, n_strips);
+        else if (abl == 2) hipLaunchKernelGGL((conv64_kernel<EPI_PRELU, 2>), dim3(grid), dim3(128), lds, s, a, n_strips);
+        else if (abl == 4) hipLaunchKernelGGL((conv64_kernel<EPI_PRELU, 4>), dim3(grid), dim3(128), lds, s, a, n_strips);
+        else if (abl == 5) hipLaunchKernelGGL((conv64_kernel<EPI_PRELU, 5>), dim3(grid), dim3(128), lds, s, a, n_strips);
+        else hipLaunchKernelGGL((conv64_kernel<EPI_PRELU, 7>), dim3(grid), dim3(128), lds, s, a, n_strips);
+        return true;
     }
     switch (a.mode) {
         case EPI_PRELU: hipLaunchKernelGGL((conv64_kernel<EPI_PRELU>), dim3(grid), dim3(128), lds, s, a, n_strips); break;

@@ -162,6 +162,10 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream);
  * internal stream concurrently with crop/embed/match of call b.  Results stay ordered on the pipeline stream.  With
  * overlap on, the frames passed to frt_pipeline_run_dev must already be valid when the call is made. */
 int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
+/* hipGraph replay of a call's ~150 launches (opt-in: env FRT_PIPELINE_GRAPH=1 or this call; measured neutral on one GPU).  A call whose buffers, batch size
+ * and mode repeat is captured on its second occurrence and replayed afterwards; callers that never repeat their buffers stay
+ * on eager launches.  Automatically off while frt_profile_enable() records events. */
+int frt_pipeline_set_graph(frt_pipeline *p, int enable);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Optional 5-point alignment mode (default OFF).  The reference has none: it trims the landmark head off the detector
@@ -190,7 +194,9 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable);
 /* ------------------------------------------------------------------------------------------------------------------
  * Profiling hooks (HIP events on the library's own stream; used by bench.py for the roofline object).
  * ------------------------------------------------------------------------------------------------------------------ */
-/* kinds: 0 = off, 1 = time every launch of the dominant kernel family (conv3x3 MFMA), 2 = time every stage. */
+/* kinds: 0 = off (drops the records), 1 = time every launch of the dominant kernel family (conv3x3 MFMA), 2 = time every stage,
+ * -1 = pause: stop recording but keep the records (bench.py samples ONE step of its timed region: the events around every conv
+ * launch cost 11 % of a step when left on for all of them). */
 int frt_profile_enable(int kind);
 /* Drains recorded events.  names_out: '\n'-separated labels; returns the number of records written (<= cap). */
 int frt_profile_collect(char *names_out, size_t names_cap, double *ms_out, double *work_out, int cap);

@@ -89,3 +89,38 @@ def test_two_stream_overlap_keeps_batches_apart(frt, synth, blobs):
     pipe.close()
     det.close()
     rec.close()
+
+
+def test_graph_replay_matches_eager(frt, synth, blobs):
+    """Opt-in hipGraph replay: same results as eager launches, also after the frame contents / gallery change."""
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 2, 4, 640, 640
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    gal = synth.make_gallery(2048)
+    rec.setGallery(gal)
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    fa, fb = synth.make_frames(B, H, W), synth.make_frames(B, H, W, start=7)
+    ra, ea = pipe.run(fa)
+    rb, eb = pipe.run(fb)
+    pipe.set_graph(True)
+    for i in range(7):  # both box slots: eager sighting, capture, then replays
+        r, e = pipe.run(fa if i % 3 else fb)
+        want_r, want_e = (ra, ea) if i % 3 else (rb, eb)
+        assert np.array_equal(r, want_r) and np.array_equal(e, want_e), i
+    # a new gallery invalidates the captured match part
+    gal2 = synth.make_gallery(4096, seed=11)
+    rec.setGallery(gal2)
+    rec.initMatMul()
+    pipe.set_graph(False)
+    rc, _ = pipe.run(fa)
+    pipe.set_graph(True)
+    for i in range(5):
+        r, _ = pipe.run(fa)
+        assert np.array_equal(r, rc), i
+    assert not np.array_equal(rc["match_idx"], ra["match_idx"])
+    pipe.close()
+    det.close()
+    rec.close()

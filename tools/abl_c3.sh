@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-for A in 1 2; do
-  mkdir -p $GRAFT_REPO_ROOT/gpurun_out/dw$A
-  FRT_DWPW_WG_PER_CU=$A rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/dw$A -o det -- python $GRAFT_REPO_ROOT/tools/prof_det.py 32 2 > /dev/null 2>&1
+for A in 0 1 2 4 5 7; do
+  mkdir -p $GRAFT_REPO_ROOT/gpurun_out/c64_$A
+  FRT_C64_ABLATE=$A rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/c64_$A -o emb -- python $GRAFT_REPO_ROOT/tools/prof_embed.py 128 2 > /dev/null 2>&1
 done
