@@ -186,12 +186,16 @@ def main():
                         "share_of_step_time": round(tot_ms / (1e3 * dt / args.steps), 4),
                         "all_3x3_conv_kernels": {"achieved": round(fam, 2), "frac": round(fam / PEAK_FP16_MFMA_TFLOPS, 4),
                                                  "share_of_step_time": round(fam_ms / (1e3 * dt / args.steps), 4)}}
-            try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_hbm.json)
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
-                    pmc = json.load(f)
-                if pmc.get("kernel") == dom:
-                    roofline["traffic"] = pmc["hbm_bytes_per_launch"]
-                    roofline["traffic_note"] = pmc["note"]
+            try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_profiles.sh)
+                import glob
+                for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
+                    with open(path) as f:
+                        pmc = json.load(f)
+                    ent = pmc.get("per_kernel", {}).get(dom) or (pmc if pmc.get("kernel") == dom else None)
+                    if ent:
+                        roofline["traffic"] = ent["hbm_bytes_per_launch"]
+                        roofline["traffic_note"] = os.path.basename(path) + ": " + pmc["note"]
+                        break
             except (OSError, ValueError, KeyError):
                 pass
 

@@ -953,7 +953,7 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
                                   "conv_patch_kernel<3, 5, 5, true, 0, false>", "conv_patch_kernel<2, 5, 5, false, 0, false>",
                                   "conv_patch_kernel<2, 6, 4, false, 0, false>"};
     if (conv64_applies(a))
-        return a.mode == EPI_PRELU ? "conv64_kernel<0>" : (a.mode == EPI_BN ? "conv64_kernel<1>" : "conv64_kernel<2>");
+        return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
     return names[conv_variant(a, R, n_img)];
 }
