@@ -715,7 +715,7 @@ struct frt_matcher {
             const size_t tiles = ((size_t)N + 127) / 128;
             free_screen_scratch();
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.q16), (size_t)cap * D * sizeof(half_t)));
-            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tilemax), (size_t)cap * tiles * sizeof(float)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tilemax), (size_t)cap * tiles * 4 * sizeof(float)));  // up to 4 coarse entries per tile
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_flags), tiles * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_list), tiles * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.count), sizeof(int)));

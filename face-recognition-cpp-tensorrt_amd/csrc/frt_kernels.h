@@ -23,7 +23,7 @@ int match_top1_blocks(int N, int F);
 // screened top-1: fp16 shadow gallery + coarse MFMA pass + exact re-rank of the few tiles that can hold the maximum
 struct ScreenScratch {
     half_t *q16;       // [F][D]
-    float *tilemax;    // [F][tiles]
+    float *tilemax;    // [F][tiles][sub], sub = 1 or 4 coarse maxima per 128-row tile
     int *tile_flags;   // [tiles]
     int *tile_list;    // [tiles]
     int *count;        // [1]

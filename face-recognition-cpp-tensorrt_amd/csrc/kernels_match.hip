@@ -13,6 +13,8 @@
 // swizzled with (row>>1)&7 so that every 16-lane group of a ds_read_b128 touches 16 distinct 16-byte slots of the 256-byte
 // bank row (conflict-free, MI355X LDS rules).  The k index inside a chunk is permuted consistently for both operands
 // (lane>>5 picks the chunk, the 4 MFMAs of a chunk walk its 4 floats), which leaves every dot product unchanged.
+#include <cstdlib>
+
 #include "frt_kernels.h"
 
 #include <limits.h>
@@ -338,15 +340,98 @@ __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restr
     }
 }
 
+// ---------------------------------------------------------------- coarse pass v2: queries resident in LDS, gallery rows straight to registers
+// v1 moves BOTH operands global -> registers -> LDS every 64-wide k-step (the 128 queries are re-fetched for every gallery tile)
+// and reached 3.2 TB/s on the fp16 shadow gallery.  Here a persistent workgroup (one per CU) keeps the whole fp16 query block
+// [128][D] in LDS (133 KB, rows padded by 16 B: conflict-free ds_read_b128) for its lifetime and streams its gallery tiles -
+// 128 rows, one 32-row MFMA block per wave - straight from HBM into A-fragment registers: lane (row r, half hi) reads the 16-byte
+// pieces of its own row.  The A registers form a ring exactly one tile deep: register ks is consumed by the MFMAs of k-step ks
+// and immediately refilled with the same k-step of the NEXT tile, i.e. every load has a full tile of MFMAs (4096 clk, about the
+// HBM latency under load) to land, with 128 KB per CU in flight.  LDS carries only the query fragments.
+template <int D>
+__global__ __launch_bounds__(256) void match_coarse2_kernel(const half_t *__restrict__ G, int N, const half_t *__restrict__ Q, int F,
+                                                            float *__restrict__ tilemax, int num_tiles) {
+    constexpr int KS = D / 16;   // k-steps
+    constexpr int QP = D + 8;    // halves per query row in LDS
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    half_t *Qs = reinterpret_cast<half_t *>(smem2);                        // [128][QP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int q0 = blockIdx.y * 128;
+    for (int i = tid; i < 128 * (D / 8); i += 256) {
+        const int q = i / (D / 8), c = i - q * (D / 8);
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q0 + q < F) v = *reinterpret_cast<const half8 *>(Q + (long)(q0 + q) * D + c * 8);
+        *reinterpret_cast<half8 *>(Qs + q * QP + c * 8) = v;
+    }
+    int tile = blockIdx.x;
+    if (tile >= num_tiles) return;  // (uniform per workgroup; no barrier has been executed yet)
+    auto row_ptr = [&](int t) {
+        long g = (long)t * 128 + wave * 32 + r;
+        if (g >= N) g = N - 1;  // clamped: excluded from the maximum below
+        return G + g * D + 8 * hi;
+    };
+    half8 areg[KS];
+    {
+        const half_t *gp = row_ptr(tile);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) areg[ks] = *reinterpret_cast<const half8 *>(gp + ks * 16);
+    }
+    __syncthreads();
+    const half_t *qb = Qs + r * QP + 8 * hi;
+    for (; tile < num_tiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const half_t *gn = row_ptr(next < num_tiles ? next : tile);
+        floatx16 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+        half8 bq[2][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bq[0][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bq[(ks + 1) & 1][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP + (ks + 1) * 16);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[ks], bq[ks & 1][n], acc[n], 0, 0, 0);
+            areg[ks] = *reinterpret_cast<const half8 *>(gn + ks * 16);  // refill with the next tile's fragment
+        }
+        // per-query maximum over this wave's 32 gallery rows (rows beyond N are excluded).  Written per WAVE (4 entries per
+        // tile): no cross-wave reduction, hence no barrier in the loop - a barrier per tile stalls the load stream (loads are
+        // only issued from MFMA steps) and cost ~20 % of the bandwidth.
+        __builtin_amdgcn_sched_barrier(0);
+        const int gbase = tile * 128 + wave * 32;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int g = gbase + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (g < N) m = fmaxf(m, acc[n][e]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const int q = q0 + n * 32 + r;
+            if (hi == 0 && q < F) tilemax[((long)q * num_tiles + tile) * 4 + wave] = m;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the iterations apart (without it the scheduler's version needs 512 registers + spills)
+    }
+}
+
 // one workgroup per query: best coarse tile maximum, ||q||, then every tile within 2*delta of the best goes on the list (once)
-__global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ tilemax, int num_tiles, const float *__restrict__ Q, int D,
-                                                           float gmax_norm, int *__restrict__ tile_flags, int *__restrict__ tile_list,
+__global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ tilemax, int num_tiles, int sub, const float *__restrict__ Q,
+                                                           int D, float gmax_norm, int *__restrict__ tile_flags, int *__restrict__ tile_list,
                                                            int *__restrict__ count) {
+    // `sub` coarse entries per 128-row tile (1: match_coarse_kernel, 4: match_coarse2_kernel writes one per wave)
     __shared__ float sm[8];
     const int q = blockIdx.x, tid = threadIdx.x;
-    const float *row = tilemax + (long)q * num_tiles;
+    const int n_ent = num_tiles * sub;
+    const float *row = tilemax + (long)q * n_ent;
     float m = -INFINITY, n2 = 0.f;
-    for (int t = tid; t < num_tiles; t += 256) m = fmaxf(m, row[t]);
+    for (int t = tid; t < n_ent; t += 256) m = fmaxf(m, row[t]);
     for (int k = tid; k < D; k += 256) n2 += Q[(long)q * D + k] * Q[(long)q * D + k];
     for (int off = 32; off > 0; off >>= 1) {
         m = fmaxf(m, __shfl_xor(m, off));
@@ -362,8 +447,8 @@ __global__ __launch_bounds__(256) void match_select_kernel(const float *__restri
     const float delta = 1.2e-3f * qn * gmax_norm;
     // fp16 overflow / non-finite inputs: no valid bound -> take every tile (degenerates to the exact full scan)
     const float thr = (qn < 6.0e4f && gmax_norm < 6.0e4f && m == m && m > -INFINITY && m < INFINITY) ? m - 2.f * delta : -INFINITY;
-    for (int t = tid; t < num_tiles; t += 256)
-        if (!(row[t] < thr) && atomicExch(&tile_flags[t], 1) == 0) tile_list[atomicAdd(count, 1)] = t;
+    for (int t = tid; t < n_ent; t += 256)
+        if (!(row[t] < thr) && atomicExch(&tile_flags[t / sub], 1) == 0) tile_list[atomicAdd(count, 1)] = t / sub;
 }
 
 template <int NQ, bool FULL>
@@ -430,9 +515,26 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 cgrid(tiles < 1024 ? tiles : 1024, (F + 127) / 128);
-    hipLaunchKernelGGL(match_coarse_kernel, cgrid, dim3(256), lds, s, g16, N, D, w.q16, F, w.tilemax, tiles);
-    hipLaunchKernelGGL(match_select_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles, queries, D, gmax_norm, w.tile_flags, w.tile_list, w.count);
+    // Both coarse kernels stream the 1 GB fp16 shadow at 4.0 TB/s (251 vs 258 us at N = 1M, F = 128; the HBM pipe is the limit:
+    // 128 KB per CU in flight for ~8 us).  v1 stays the default, v2 (FRT_MATCH_COARSE_V2=1) is the simpler memory path.
+    static const bool coarse_v2 = getenv("FRT_MATCH_COARSE_V2") != nullptr;
+    int coarse_sub = 1;
+    if (D == 512 && coarse_v2) {
+        coarse_sub = 4;
+        const size_t lds2 = (size_t)128 * (512 + 8) * sizeof(half_t);
+        static bool attr2_done = false;
+        if (!attr2_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            attr2_done = true;
+        }
+        dim3 g2(tiles < 256 ? tiles : 256, (F + 127) / 128);
+        hipLaunchKernelGGL((match_coarse2_kernel<512>), g2, dim3(256), lds2, s, g16, N, w.q16, F, w.tilemax, tiles);
+    } else {
+        dim3 cgrid(tiles < 1024 ? tiles : 1024, (F + 127) / 128);
+        hipLaunchKernelGGL(match_coarse_kernel, cgrid, dim3(256), lds, s, g16, N, D, w.q16, F, w.tilemax, tiles);
+    }
+    hipLaunchKernelGGL(match_select_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles, coarse_sub, queries, D, gmax_norm, w.tile_flags, w.tile_list,
+                       w.count);
     // exact re-rank over the listed tiles (count lives on the device); the partial scratch is [partial_blocks][F]
     if (F <= 32)
         launch_t<1, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
