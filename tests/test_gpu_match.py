@@ -1,4 +1,6 @@
 """HIP cosine-similarity GEMM + fused top-1 vs the NumPy oracle (MatMul::calculate / getOutputs semantics)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -125,3 +127,33 @@ def test_sharded_gallery_merge_equals_single_gallery(frt, synth, N):
     assert wi.tolist() == [7, 7, cut - 1, cut - 1, N - 1, 0]
     for m in (whole, a, b):
         m.close()
+
+
+def test_coarse_kernel_v2_selects_the_same_answers():
+    """The opt-in register-streaming coarse kernel (FRT_MATCH_COARSE_V2=1, read once per process -> subprocess) must leave the
+    screened top-1 bit-identical to the exact scan as well."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import __graft_entry__ as entry
+frt = entry.load_pkg()
+N = 50000 + 13
+g = frt.synth.make_gallery(N)
+g[45000] = g[77]
+q = np.concatenate([frt.synth.make_queries(g, [77, 45000, 12, 49999], noise=0.0),
+                    np.random.default_rng(3).standard_normal((60, 512)).astype(np.float32)])
+m = frt.MatMul(0)
+m.init(g)
+i, s = m.top1(q)
+full = m.calculate(q)
+assert np.array_equal(i, full.argmax(1).astype(np.int32)) and np.array_equal(s, full.max(1)), "mismatch"
+assert i[0] == 77 and i[1] == 77
+print("OK")
+'''
+    env = dict(os.environ, FRT_MATCH_COARSE_V2="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
