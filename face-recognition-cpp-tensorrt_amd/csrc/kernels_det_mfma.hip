@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
     for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
-    const int co_base = wc * CBW * 32;
+    const int co_base = ((int)blockIdx.y * NCW + wc) * CBW * 32;  // blockIdx.y: output-channel group (depthwise part recomputed per group)
     float areg[KS][CBW], anext[KS][CBW];
     auto load_weights = [&](int c0, float (&dst)[KS][CBW]) {
 #pragma unroll
@@ -300,10 +300,12 @@ void launch_fused(const DwPwArgs &a, hipStream_t s) {
         nblocks = ((long)a.B * a.Ho * a.Wo + TP - 1) / TP;
     }
     const size_t lds = ((size_t)a.Cin * 12 + 2 * (size_t)KC * TP) * sizeof(float);
+    const unsigned cgroups = (unsigned)((a.Cout + 32 * NCW * CBW - 1) / (32 * NCW * CBW));
+    const dim3 grid((unsigned)nblocks, cgroups);
     if (a.stride == 1)
-        hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 1, MODE2D>), dim3((unsigned)nblocks), dim3(64 * NPW * NCW), lds, s, a, tiles_x, tiles_y);
+        hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 1, MODE2D>), grid, dim3(64 * NPW * NCW), lds, s, a, tiles_x, tiles_y);
     else
-        hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 2, MODE2D>), dim3((unsigned)nblocks), dim3(64 * NPW * NCW), lds, s, a, tiles_x, tiles_y);
+        hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 2, MODE2D>), grid, dim3(64 * NPW * NCW), lds, s, a, tiles_x, tiles_y);
 }
 
 }  // namespace
@@ -346,12 +348,25 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
     }
     if (a.Cin % 32) return false;
     if (a.Cout == 64 && total >= 128L * 512) {
-        big ? launch_fused<4, 1, 32, 2, true>(a, s) : launch_fused<4, 1, 32, 2, false>(a, s);
+        static const int c64 = getenv("FRT_DWPW_C64") ? atoi(getenv("FRT_DWPW_C64")) : 1;  // measured: 64-px linear tiles, 2x2 waves: 46/60 us vs 54/71 for 8x16 tiles
+        if (c64 == 1) launch_fused<2, 2, 32, 1, false>(a, s);
+        else if (c64 == 2) launch_fused<1, 2, 32, 1, false>(a, s);
+        else if (c64 == 3) big ? launch_fused<4, 1, 16, 2, true>(a, s) : launch_fused<4, 1, 16, 2, false>(a, s);
+        else big ? launch_fused<4, 1, 32, 2, true>(a, s) : launch_fused<4, 1, 32, 2, false>(a, s);
     } else if (a.Cout == 128 || (a.Cout == 64)) {
-        if (a.Cout == 128) launch_fused<2, 2, 32, 2, false>(a, s);
+        if (a.Cout == 128) {
+            static const int small = getenv("FRT_DWPW_SMALL") ? atoi(getenv("FRT_DWPW_SMALL")) : 1;
+            if (small == 1) launch_fused<1, 4, 32, 1, false>(a, s);
+            else if (small == 2) launch_fused<1, 2, 32, 2, false>(a, s);
+            else if (small == 3) launch_fused<1, 2, 32, 1, false>(a, s);
+            else launch_fused<2, 2, 32, 2, false>(a, s);
+        }
         else launch_fused<2, 2, 32, 1, false>(a, s);
     } else if (a.Cout == 256) {
-        launch_fused<1, 4, 32, 2, false>(a, s);
+        static const int small = getenv("FRT_DWPW_SMALL") ? atoi(getenv("FRT_DWPW_SMALL")) : 1;
+        if (small == 2) launch_fused<1, 2, 32, 2, false>(a, s);
+        else if (small == 3) launch_fused<1, 2, 32, 1, false>(a, s);
+        else launch_fused<1, 4, 32, 2, false>(a, s);
     } else {
         return false;
     }
