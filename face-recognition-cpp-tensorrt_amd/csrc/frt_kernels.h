@@ -96,6 +96,9 @@ bool det_mfma_enabled();       // env FRT_DET_MFMA=0 switches the detector back 
 void launch_conv3x3(const Conv3Args &a, hipStream_t s);
 // first detector conv fed by the u8 frames directly (only valid when the letterbox is the identity); false: not applicable
 bool launch_det_conv1_u8(const uint8_t *frames, size_t row_stride, size_t frame_stride, const Conv3Args &a, hipStream_t s);
+// (A fused "stem" kernel - first conv + the two conv_dw blocks behind it with the intermediates in LDS - was tried and removed:
+//  436-840 us against 302 us for the three separate kernels; with ~1150 weights it either spills SGPRs or hoists every LDS weight
+//  read into 290 VGPRs, and the halo recompute plus LDS traffic eat the HBM saving.)
 bool launch_conv3x3_mfma(const Conv3Args *a, int n, hipStream_t s);   // false: shape not covered, use the scalar kernel
 void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s);  // up to 3 same-Cout problems in one launch
 struct HeadArgs {

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvMfmaArgs p) {
 // PAIR (Cout == 64, Cin == 64): one workgroup handles TWO strips; waves (0,1) own the first, waves (2,3) the second, each wave
 // one 32-cout fragment of its strip.  Each half stages its own patch (128 threads per patch image); the whole K loop (9 taps)
 // runs on that single resident patch.
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false>  // PPS patch DMA pieces per thread per step during taps 0..PT-1
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7>  // NT pixel tiles per strip; PPS patch DMA pieces per thread per step during taps 0..PT-1
 __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
     // linear != 0: pixel slots are enumerated over the PADDED row width (slot == patch row of tap (0,0), slots in the two halo
     // columns are dead).  The 32 lanes of a fragment read then touch 32 consecutive patch rows -> no LDS bank conflicts; the
@@ -508,9 +508,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
     //      tile from the LDS write AND read paths - LDS bandwidth (fragment reads + LDS-DMA writes) was the binding resource.
     const half_t *wrow = p.w + (long)(co_base + cow + r) * Ktot + hi * 8;
     // ---- B-fragment base addresses: pixel slot -> patch row of tap (0,0)
-    int pbase[7];
+    int pbase[NT];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < NT; ++j) {
         const int sl = j * 32 + r;
         int pidx = 0;
         if (linear) {
@@ -543,9 +543,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
         }
     };
 
-    floatx16 acc[7];
+    floatx16 acc[NT];
 #pragma unroll
-    for (int j = 0; j < 7; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
@@ -558,13 +558,13 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
     // instruction stream can hide LDS latency, so every MFMA is followed by exactly one ds_read that refills the register it
     // just consumed with the fragment two kk-slots ahead - in the second half of a step that is the NEXT tap's fragment (the
     // patch is resident).  sched_barrier(0) pins the order (left alone hipcc emits "2 reads, lgkmcnt(0), 1 MFMA").
-    half8 bf[2][7];
+    half8 bf[2][NT];
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's patch(0) pieces have landed (younger: the 8 fragment loads)
     __builtin_amdgcn_s_barrier();                     // ... and everybody else's
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-        for (int j = 0; j < 7; ++j) bf[k2][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + k2 * 32);
+        for (int j = 0; j < NT; ++j) bf[k2][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + k2 * 32);
 
     auto step = [&](int c, auto tap_c) {
         constexpr int TAP = decltype(tap_c)::value;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 if (ABL == 2) asm volatile("" ::"v"(areg[AS][kk]), "v"(bf[cur][j]));
                 else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[AS][kk], bf[cur][j], acc[j], 0, 0, 0);
                 if (kk < 2) bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dp + (kk + 2) * 32);
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
     __syncthreads();
     if (ABL == 5) {  // timing ablation: keep the accumulators alive, skip the epilogue
         float sacc = 0.f;
-        for (int j = 0; j < 7; ++j) sacc += acc[j][0];
+        for (int j = 0; j < NT; ++j) sacc += acc[j][0];
         if (sacc == 123.456f) p.out0[0] = (half_t)sacc;
         return;
     }
@@ -653,10 +653,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
         m = m0 + sl;
         return strip_ok && sl < n_valid && m < Mtot;
     };
-    half8 sc8[7][2];
+    half8 sc8[NT][2];
     if (p.mode == EPI_BN_ADD_BN) {  // stride 1: the shortcut has the output's geometry; all 14 loads in flight before the transposes
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int sl = j * 32 + (lane >> 2) + 16 * it;
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
             }
     }
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < NT; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
@@ -882,16 +882,21 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     if (a.mode == EPI_PARTIAL) return false;
     if (a.mode == EPI_BN_ADD_BN && !(a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
     if (a.H * a.W <= 56) {
-        n_img = 224 / (a.H * a.W);
+        // whole small images per strip.  4 images (7 tiles) leave 7x7x512 at 32 strips x 4 cout tiles = 128 workgroups on 256 CUs;
+        // 2 images (4 tiles, NT = 4 instantiation) double the grid for the same total MFMA work
+        static const int small_nt = getenv("FRT_CONV_SMALL_NT") ? atoi(getenv("FRT_CONV_SMALL_NT")) : 4;
+        n_img = (small_nt * 32) / (a.H * a.W);
         R = a.H;
     } else {
         n_img = 1;
         R = 0;
+        static const int lim14 = getenv("FRT_CONV_NT4_14") ? 128 : 224;  // experiment: half-image strips (4 tiles) on the 14x14 layers
+        const int lim = a.H == 14 ? lim14 : 224;
         for (int d = 1; d <= a.H; ++d)
-            if (a.H % d == 0 && d * a.W <= 224) R = d;
+            if (a.H % d == 0 && d * a.W <= lim) R = d;
         if (!R) return false;
     }
-    if (n_img * R * a.W < 160) return false;  // too many dead pixel slots
+    if (n_img * R * a.W < (n_img * R * a.W <= 128 ? 96 : 160)) return false;  // too many dead pixel slots
     const int NP = n_img * (R + 2) * (a.W + 2);
     const int slots = (NP * 9 + 255) / 256;
     single = a.Cin == 64;
@@ -901,20 +906,20 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     return true;
 }
 
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false>
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7>
 void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
     const size_t lds = PAIR ? (size_t)2 * 34 * 2048 : (size_t)(SINGLE ? 1 : 2) * PT * PPS * 4096;  // patch buffers only (weights live in registers)
     static_assert(PAIR || ((SINGLE ? 1 : 2) * PT * PPS * 4096 <= 160 * 1024 && PT * PPS * 4096 >= 4 * 32 * 36 * 4), "LDS budget / epilogue scratch");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     const int strips = ((a.B + n_img - 1) / n_img) * (a.H / R);
     dim3 grid(PAIR ? (strips + 1) / 2 : strips * (a.Cout / 128));
-    const int linear = (n_img == 1 && R * (a.W + 2) <= 224) ? 1 : 0;
-    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR>), grid, dim3(256), lds, s, a, R, n_img, linear);
+    const int linear = (n_img == 1 && R * (a.W + 2) <= NT * 32) ? 1 : 0;
+    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT>), grid, dim3(256), lds, s, a, R, n_img, linear);
 }
 
 int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage (default: 64 KB ring, 2 workgroups per CU), 3 = LDS-DMA 3-stage
@@ -930,7 +935,7 @@ int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage
 }  // namespace
 
 // Which kernel symbol a launch resolves to (also the profiling label, so bench.py / rocprofv3 can be matched by name).
-enum { CV_V1_22, CV_V1_14, CV_G2_22, CV_G2_14, CV_G3_22, CV_G3_14, CV_P_PAIR, CV_P_SINGLE, CV_P_255, CV_P_264 };
+enum { CV_V1_22, CV_V1_14, CV_G2_22, CV_G2_14, CV_G3_22, CV_G3_14, CV_P_PAIR, CV_P_SINGLE, CV_P_255, CV_P_264, CV_P_255_NT4 };
 static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
     const int impl = conv_impl();
     static const int use_patch = getenv("FRT_CONV_PATCH") ? atoi(getenv("FRT_CONV_PATCH")) : 1;
@@ -939,6 +944,7 @@ static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
     if (impl >= 2 && use_patch && patch_geometry(a, R, n_img, slots, single)) {
         if (a.Cout == 64) return CV_P_PAIR;   // pair mode: 2 strips x 68 KB patch
         if (single) return CV_P_SINGLE;       // 15 slots (60 KB)
+        if (n_img * R * a.W <= 128 && slots <= 10) return CV_P_255_NT4;  // 4 pixel tiles per strip (small maps)
         return slots <= 10 ? CV_P_255 : CV_P_264;  // 2 x 40 KB / 2 x 48 KB patch buffers
     }
     const bool wide = a.Cout % 128 == 0;
@@ -949,9 +955,9 @@ static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
 
 const char *conv_kernel_label(const ConvMfmaArgs &a) {
     static const char *names[] = {"conv_mfma_kernel<2, 2>", "conv_mfma_kernel<1, 4>", "conv_glds_kernel<2, 2, 2, 0>", "conv_glds_kernel<1, 4, 2, 0>",
-                                  "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true>",
-                                  "conv_patch_kernel<3, 5, 5, true, 0, false>", "conv_patch_kernel<2, 5, 5, false, 0, false>",
-                                  "conv_patch_kernel<2, 6, 4, false, 0, false>"};
+                                  "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true, 7>",
+                                  "conv_patch_kernel<3, 5, 5, true, 0, false, 7>", "conv_patch_kernel<2, 5, 5, false, 0, false, 7>",
+                                  "conv_patch_kernel<2, 6, 4, false, 0, false, 7>", "conv_patch_kernel<2, 5, 5, false, 0, false, 4>"};
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
@@ -973,6 +979,7 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 5) return launch_patch_t<2, 5, 5, false, 5>(a, R, n_img, s);
             return launch_patch_t<2, 5, 5, false>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
+        case CV_P_255_NT4: return launch_patch_t<2, 5, 5, false, 0, false, 4>(a, R, n_img, s);
         case CV_V1_22: return launch_conv_t<2, 2>(a, s);
         case CV_V1_14: return launch_conv_t<1, 4>(a, s);
         case CV_G2_22:
