@@ -53,6 +53,8 @@ ABI = {
     "frt_detector_infer": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_detector_postprocess": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "frt_crop_faces": (_i, [_vp, _i, _i, _sz, _vp, _i, _i, _i, _vp, _i]),
+    "frt_resize_frame": (_i, [_vp, _i, _i, _sz, _vp, _i, _i, _i]),
+    "frt_resize_frames_dev": (_i, [_vp, _i, _i, _i, _sz, _sz, _vp, _i, _i, _vp]),
     "frt_embedder_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "frt_embedder_destroy": (None, [_vp]),
     "frt_embedder_preprocess_face": (_i, [_vp, _vp, _vp]),
@@ -252,6 +254,14 @@ class RetinaFace:
             self.close()
         except Exception:
             pass
+
+
+def resizeFrame(img, width, height, device=0):
+    """``cv::resize(img, img, Size(width, height))`` (src/app.cpp:166,301: default INTER_LINEAR) on the device -> u8 [height][width][3]."""
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((int(height), int(width), 3), np.uint8)
+    _check(lib.frt_resize_frame(_ptr(img), img.shape[0], img.shape[1], img.strides[0], _ptr(out), int(height), int(width), device))
+    return out
 
 
 def getCroppedFaces(frame, outputBbox, resize_w=112, resize_h=112, device=0):

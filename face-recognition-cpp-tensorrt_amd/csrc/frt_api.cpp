@@ -1069,6 +1069,35 @@ int frt_detector_postprocess(frt_detector *d, const float *loc, const float *con
     });
 }
 
+// -------------------------------------------------------------------------------------------------------- frame ingest
+int frt_resize_frame(const uint8_t *bgr, int rows, int cols, size_t row_stride, uint8_t *out, int out_rows, int out_cols, int device) {
+    return guarded([&] {
+        if (!bgr || !out || rows < 1 || cols < 1 || out_rows < 1 || out_cols < 1) raise(FRT_ERR_INVALID, "resize: bad argument");
+        if (device >= 0) use_device(device);
+        Arena a;
+        struct Guard {
+            Arena &a;
+            ~Guard() { a.release(); }
+        } guard{a};
+        const size_t tight = (size_t)cols * 3, otight = (size_t)out_cols * 3;
+        uint8_t *d_src = a.alloc<uint8_t>((size_t)rows * tight);
+        uint8_t *d_dst = a.alloc<uint8_t>((size_t)out_rows * otight);
+        HIPCHK(hipMemcpy2D(d_src, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice));
+        launch_resize_linear(d_src, 1, rows, cols, tight, 0, d_dst, out_rows, out_cols, otight, 0, nullptr);
+        HIPCHK(hipMemcpy(out, d_dst, (size_t)out_rows * otight, hipMemcpyDeviceToHost));
+    });
+}
+
+int frt_resize_frames_dev(const void *src_dev, int n, int rows, int cols, size_t row_stride, size_t frame_stride, void *dst_dev, int out_rows,
+                          int out_cols, void *hip_stream) {
+    return guarded([&] {
+        if (!src_dev || !dst_dev || n < 0 || rows < 1 || cols < 1 || out_rows < 1 || out_cols < 1) raise(FRT_ERR_INVALID, "resize: bad argument");
+        launch_resize_linear(reinterpret_cast<const uint8_t *>(src_dev), n, rows, cols, row_stride, frame_stride, reinterpret_cast<uint8_t *>(dst_dev),
+                             out_rows, out_cols, (size_t)out_cols * 3, (size_t)out_rows * out_cols * 3, reinterpret_cast<hipStream_t>(hip_stream));
+        HIPCHK(hipGetLastError());
+    });
+}
+
 // ---------------------------------------------------------------------------------------------------------------- crop
 int frt_crop_faces(const uint8_t *bgr, int rows, int cols, size_t row_stride, const frt_bbox *boxes, int n, int out_w, int out_h,
                    uint8_t *crops_out, int device) {

@@ -67,6 +67,9 @@ void launch_det_preprocess(const uint8_t *frames, int n, int frame_h, int frame_
 void launch_crop_faces(const uint8_t *frames, int frame_h, int frame_w, size_t row_stride, size_t frame_stride, const frt_bbox *boxes,
                        const int *n_boxes, int max_faces, int F, int frames_shared, int oh, int ow, uint8_t *crops, float *chw, int *valid,
                        hipStream_t s);
+// n frames u8 HWC [sh][sw][3] -> [dh][dw][3], cv::resize INTER_LINEAR semantics (frame ingest, app.cpp:301)
+void launch_resize_linear(const uint8_t *src, int n, int sh, int sw, size_t sstride, size_t sframe, uint8_t *dst, int dh, int dw, size_t dstride,
+                          size_t dframe, hipStream_t s);
 void launch_face_normalize(const uint8_t *crops, int F, int oh, int ow, float *chw, hipStream_t s);
 
 // ---------------------------------------------------------------- detector network (kernels_det.hip), fp32 NCHW

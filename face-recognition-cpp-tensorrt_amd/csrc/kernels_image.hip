@@ -78,6 +78,52 @@ __global__ void det_preprocess_kernel(const uint8_t *__restrict__ frames, int fr
     for (int c = 0; c < 3; ++c) o[(size_t)c * in_h * in_w] = (float)v[c] - mean[c];
 }
 
+// ---------------------------------------------------------------- frame ingest: cv::resize(img, img, Size(frameW, frameH)), app.cpp:301
+// (default INTER_LINEAR, 8UC3).  Same fixed-point arithmetic as the letterbox resize above; the exact-2x case OpenCV redirects to
+// its INTER_AREA fast path gives identical values ((a+b+c+d+2)>>2), so one code path covers it.
+__global__ void resize_linear_u8_kernel(const uint8_t *__restrict__ src, int sh, int sw, size_t sstride, size_t sframe, uint8_t *__restrict__ dst,
+                                        int dh, int dw, size_t dstride, size_t dframe) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (p >= dh * dw) return;
+    const int dy = p / dw, dx = p - dy * dw;
+    const uint8_t *s = src + (size_t)f * sframe;
+    uint8_t *o = dst + (size_t)f * dframe + (size_t)dy * dstride + (size_t)dx * 3;
+    if (sh == dh && sw == dw) {
+        const uint8_t *q = s + (size_t)dy * sstride + (size_t)dx * 3;
+        o[0] = q[0];
+        o[1] = q[1];
+        o[2] = q[2];
+        return;
+    }
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = floor_i(fx);
+    fx -= sx;
+    if (sx < 0) {
+        fx = 0;
+        sx = 0;
+    }
+    if (sx >= sw - 1) {
+        fx = 0;
+        sx = sw - 1;
+    }
+    const int a0 = sat_short_round((1.f - fx) * COEF_SCALE), a1 = sat_short_round(fx * COEF_SCALE);
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = floor_i(fy);
+    fy -= sy;
+    const int b0 = sat_short_round((1.f - fy) * COEF_SCALE), b1 = sat_short_round(fy * COEF_SCALE);
+    const int y0 = clampi(sy, 0, sh - 1), y1 = clampi(sy + 1, 0, sh - 1);
+    const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+    const uint8_t *s0 = s + (size_t)y0 * sstride, *s1 = s + (size_t)y1 * sstride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int r0 = s0[sx * 3 + c] * a0 + s0[sx1 * 3 + c] * a1;
+        const int r1 = s1[sx * 3 + c] * a0 + s1[sx1 * 3 + c] * a1;
+        o[c] = (uint8_t)(((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2) & 255);
+    }
+}
+
 __device__ __forceinline__ void cubic_coeffs(float x, int *c) {
     const float A = -0.75f;
     float w[4];
@@ -180,6 +226,13 @@ void launch_det_preprocess(const uint8_t *frames, int n, int frame_h, int frame_
     dim3 grid((in_h * in_w + 255) / 256, n);
     hipLaunchKernelGGL(det_preprocess_kernel, grid, dim3(256), 0, s, frames, frame_h, frame_w, row_stride, frame_stride, in_h, in_w, w, h, x,
                        y, out);
+}
+
+void launch_resize_linear(const uint8_t *src, int n, int sh, int sw, size_t sstride, size_t sframe, uint8_t *dst, int dh, int dw, size_t dstride,
+                          size_t dframe, hipStream_t s) {
+    if (n <= 0) return;
+    dim3 grid((dh * dw + 255) / 256, n);
+    hipLaunchKernelGGL(resize_linear_u8_kernel, grid, dim3(256), 0, s, src, sh, sw, sstride, sframe, dst, dh, dw, dstride, dframe);
 }
 
 void launch_crop_faces(const uint8_t *frames, int frame_h, int frame_w, size_t row_stride, size_t frame_stride, const frt_bbox *boxes,

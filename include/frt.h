@@ -168,6 +168,18 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
 int frt_pipeline_set_graph(frt_pipeline *p, int enable);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Frame ingest: the caller's `cv::resize(img, img, Size(frameWidth, frameHeight))` (src/app.cpp:166,301;
+ * default INTER_LINEAR, 8UC3) on the device, bit-identical to the CPU restatement of OpenCV's fixed-point path.  JPEG decode
+ * itself stays with the caller.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* host in, host out; out: out_rows x out_cols x 3, tight rows */
+int frt_resize_frame(const uint8_t *bgr, int rows, int cols, size_t row_stride, uint8_t *out, int out_rows, int out_cols, int device);
+/* device in, device out, asynchronous on hip_stream (null = default stream): n frames of rows x cols -> tight out_rows x out_cols,
+ * e.g. straight into the buffer handed to frt_pipeline_run_dev */
+int frt_resize_frames_dev(const void *src_dev, int n, int rows, int cols, size_t row_stride, size_t frame_stride, void *dst_dev,
+                          int out_rows, int out_cols, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Optional 5-point alignment mode (default OFF).  The reference has none: it trims the landmark head off the detector
  * (conversion/retina/torch2trt.py:7-9, src/retinaface.cpp:58-60) and feeds the embedder a bbox crop + bicubic resize
  * (src/arcface.cpp:3-17).  These entry points exist for accuracy work only and need a detector blob exported WITH

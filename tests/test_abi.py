@@ -85,3 +85,21 @@ def test_synthetic_generators_are_deterministic(synth):
     sd1, sd2 = synth.retinaface_state(1), synth.retinaface_state(1)
     assert all(np.array_equal(sd1[k], sd2[k]) for k in sd1)
     assert sum(v.size for k, v in sd1.items() if "running" not in k) == 422708 - 0  # params incl. BN affine
+
+
+def test_pth_exporter_strips_prefixes_and_unwraps(frt, tmp_path):
+    """weights_io.export_pth (the torch2trt.py replacement): `module.` prefixes and a wrapping {'state_dict': ...} are removed like
+    conversion/retina/torch2trt.py:41-61 does; the blob round-trips bit-exactly."""
+    import torch
+    sd = {"module.body.stage1.0.0.weight": torch.randn(8, 3, 3, 3), "module.body.stage1.0.1.running_var": torch.rand(8) + 0.5,
+          "fpn.output1.0.weight": torch.randn(64, 64, 1, 1)}
+    for wrap in (False, True):
+        pth = tmp_path / ("w%d.pth" % wrap)
+        torch.save({"state_dict": sd} if wrap else sd, pth)
+        out = tmp_path / ("w%d.frtw" % wrap)
+        frt.weights_io.export_pth(str(pth), str(out), frt.weights_io.KIND_RETINAFACE_MNET025)
+        kind, back = frt.weights_io.read_blob(str(out))
+        assert kind == frt.weights_io.KIND_RETINAFACE_MNET025
+        assert set(back) == {"body.stage1.0.0.weight", "body.stage1.0.1.running_var", "fpn.output1.0.weight"}
+        for k, v in sd.items():
+            assert np.array_equal(back[k.replace("module.", "")], v.numpy())

@@ -46,3 +46,27 @@ def test_face_normalise_bit_exact(frt, orc, synth, blobs):
     crop = synth.make_faces(1)[0]
     assert np.array_equal(rec.preprocessFace(crop), orc.face_normalize(crop[None])[0])
     rec.close()
+
+
+@pytest.mark.parametrize("src,dst", [((480, 640), (640, 640)), ((1080, 1920), (480, 640)), ((1280, 1280), (640, 640)), ((97, 131), (640, 480)),
+                                     ((640, 480), (640, 480)), ((333, 500), (112, 112))])
+def test_frame_resize_matches_opencv_restatement(frt, orc, synth, src, dst):
+    """Frame ingest (app.cpp:301): device resize == the CPU restatement of cv::resize INTER_LINEAR, bit for bit (also the exact-2x
+    case OpenCV routes through its area path, which has the same value)."""
+    img = synth.make_frames(1, src[0], src[1])[0]
+    out = frt.resizeFrame(img, dst[1], dst[0])
+    assert out.shape == (dst[0], dst[1], 3)
+    assert np.array_equal(out, orc.resize_linear(img, dst[0], dst[1]))
+
+
+def test_frame_resize_device_batch(frt, orc, synth):
+    import torch
+    fr = synth.make_frames(3, 360, 480)
+    src = torch.from_numpy(fr).cuda()
+    dst = torch.empty((3, 640, 640, 3), dtype=torch.uint8, device="cuda")
+    frt._check(frt.lib.frt_resize_frames_dev(src.data_ptr(), 3, 360, 480, 480 * 3, 360 * 480 * 3, dst.data_ptr(), 640, 640,
+                                             torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], orc.resize_linear(fr[i], 640, 640))
