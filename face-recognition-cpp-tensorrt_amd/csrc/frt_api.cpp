@@ -569,7 +569,7 @@ void frt_embedder::build(const frt::Blob &b) {
     SC = arena.alloc<half_t>(F * 28 * 28 * 128);  // largest conv-shortcut output (56->28, 128 ch)
     if (se) {
         RES = arena.alloc<half_t>(F * 56 * 56 * 64);
-        se_pool = arena.alloc<float>(F * 512);
+        se_pool = arena.alloc<float>(F * 512 * 4);  // SE_SPLIT partial sums per (face, channel)
         se_gate = arena.alloc<float>(F * 512);
     }
     fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);

@@ -158,7 +158,7 @@ struct SeArgs {
     const half_t *sc; int sc_h, sc_w, sc_stride;
     const float *s1, *b1;
     half_t *y, *z;
-    float *pool;         // scratch [F][C]
+    float *pool;         // scratch [4][F][C] (partial sums over pixel ranges)
     float *gate;         // scratch [F][C]
     int F, H, W, C;
 };

@@ -788,22 +788,51 @@ __global__ __launch_bounds__(512) void fc_finalize_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------- SE tail (IR-SE): model_irse.py:22-45
-__global__ __launch_bounds__(256) void se_pool_kernel(const half_t *__restrict__ res, int HW, int C, float *__restrict__ pool) {
-    // grid (C/256 or 1, F); thread = channel; coalesced across channels (NHWC)
-    const int c = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (c >= C) return;
-    const half_t *p = res + (long)f * HW * C + c;
-    float s = 0.f;
-    for (int i = 0; i < HW; ++i) s += (float)p[(long)i * C];
-    pool[(long)f * C + c] = s / (float)HW;
+constexpr int SE_SPLIT = 4;  // pixel ranges per face (partial sums, summed in fixed order by the gate kernel: deterministic)
+__global__ __launch_bounds__(256) void se_pool_kernel(const half_t *__restrict__ res, int HW, int C, int F, float *__restrict__ partial) {
+    // grid (SE_SPLIT, F).  thread = (channel octet, pixel lane): 16-byte loads, consecutive threads read one pixel's contiguous NHWC
+    // row (the first version walked HW serially with one 2-byte load per step per channel: 154 us per call)
+    __shared__ float red[256 * 8];
+    const int f = blockIdx.y, part = blockIdx.x;
+    const int C8 = C >> 3, NP = 256 / C8;          // C in {64, 128, 256, 512}: C8 <= 64
+    const int oct = threadIdx.x % C8, pl = threadIdx.x / C8;
+    const int i0 = (int)((long)HW * part / SE_SPLIT), i1 = (int)((long)HW * (part + 1) / SE_SPLIT);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (pl < NP) {
+        const half_t *p = res + (long)f * HW * C + oct * 8;
+        for (int i = i0 + pl; i < i1; i += NP) {
+            const half8 v = *reinterpret_cast<const half8 *>(p + (long)i * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < C) {  // channel c = octet * 8 + e: sum over the NP pixel lanes in lane order
+        const int c = threadIdx.x, o = c >> 3, e = c & 7;
+        float t = 0.f;
+        for (int q = 0; q < NP; ++q) t += red[(q * C8 + o) * 8 + e];
+        partial[((long)part * F + f) * C + c] = t;
+    }
+    if (C > 256 && threadIdx.x + 256 < C) {
+        const int c = threadIdx.x + 256, o = c >> 3, e = c & 7;
+        float t = 0.f;
+        for (int q = 0; q < NP; ++q) t += red[(q * C8 + o) * 8 + e];
+        partial[((long)part * F + f) * C + c] = t;
+    }
 }
 __global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ pool, const float *__restrict__ w1, const float *__restrict__ w2,
-                                                      int C, float *__restrict__ gate) {
+                                                      int C, int F, int HW, float *__restrict__ gate) {
     // one block per face
     extern __shared__ float sh[];  // [C] pooled + [C/16] hidden
     const int f = blockIdx.x, R = C / 16;
     float *sp = sh, *shid = sh + C;
-    for (int c = threadIdx.x; c < C; c += 256) sp[c] = pool[(long)f * C + c];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int part = 0; part < SE_SPLIT; ++part) t += pool[((long)part * F + f) * C + c];
+        sp[c] = t / (float)HW;
+    }
     __syncthreads();
     for (int h = threadIdx.x; h < R; h += 256) {
         float a = 0.f;
@@ -1008,8 +1037,8 @@ void launch_fc_finalize(const float *partial, int splits, int F, const float *bi
 }
 
 void launch_se(const SeArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(se_pool_kernel, dim3((a.C + 255) / 256, a.F), dim3(256), 0, s, a.res, a.H * a.W, a.C, a.pool);
-    hipLaunchKernelGGL(se_gate_kernel, dim3(a.F), dim3(256), (a.C + a.C / 16) * sizeof(float), s, a.pool, a.w1, a.w2, a.C, a.gate);
+    hipLaunchKernelGGL(se_pool_kernel, dim3(SE_SPLIT, a.F), dim3(256), 0, s, a.res, a.H * a.W, a.C, a.F, a.pool);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(a.F), dim3(256), (a.C + a.C / 16) * sizeof(float), s, a.pool, a.w1, a.w2, a.C, a.F, a.H * a.W, a.gate);
     const long total = (long)a.F * a.H * a.W * (a.C / 8);
     hipLaunchKernelGGL(se_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }

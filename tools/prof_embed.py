@@ -13,7 +13,8 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 s = frt.synth
 tmp = tempfile.mkdtemp()
-path = frt.write_weights(os.path.join(tmp, "rec.frtw"), s.arcface_state(2, "ir", calib=s.load_calibration("ir")), 2)
+MODE = os.environ.get("FRT_PROF_MODE", "ir")
+path = frt.write_weights(os.path.join(tmp, "rec.frtw"), s.arcface_state(2, MODE, calib=s.load_calibration(MODE)), 2 if MODE == "ir" else 3)
 rec = frt.ArcFaceIR50(path, maxBatchSize=F)
 x = np.random.default_rng(0).standard_normal((F, 3, 112, 112)).astype(np.float32) * 0.5
 for _ in range(reps):
