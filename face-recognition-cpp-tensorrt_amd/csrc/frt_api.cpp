@@ -179,6 +179,30 @@ void fold_pw(const frt::Blob &b, const std::string &conv, const std::string &bn,
     bias = bi;
 }
 inline int conv_out(int x, int stride) { return (x + 2 - 3) / stride + 1; }
+// [Cin][9][Cout] fp32 -> fp16 hi/lo split [Cin/16][9][64][hi16 | lo16] (kernels_det_conv3h.hip); empty unless Cin == 64, Cout <= 64
+std::vector<uint16_t> pack_conv3_split(const std::vector<float> &w, int cin, int cout) {
+    if (cin != 64 || cout > 64 || cout < 16) return {};
+    std::vector<uint16_t> o((size_t)4 * 9 * 64 * 32, 0);
+    auto h2f = [](uint16_t h) {  // fp16 -> fp32 (normal / subnormal / zero; no inf/nan expected in weights)
+        const uint32_t sgn = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 31, m = h & 1023;
+        float f;
+        if (e == 0) f = std::ldexp((float)m, -24);
+        else f = std::ldexp((float)(m | 1024), (int)e - 25);
+        return sgn ? -f : f;
+    };
+    for (int c = 0; c < 4; ++c)
+        for (int t = 0; t < 9; ++t)
+            for (int co = 0; co < cout; ++co)
+                for (int k = 0; k < 16; ++k) {
+                    const float x = w[((size_t)(c * 16 + k) * 9 + t) * cout + co];
+                    const uint16_t hi = frt::f32_to_f16(x);
+                    const uint16_t lo = frt::f32_to_f16(x - h2f(hi));
+                    const size_t row = (((size_t)c * 9 + t) * 64 + co) * 32;
+                    o[row + k] = hi;
+                    o[row + 16 + k] = lo;
+                }
+    return o;
+}
 // [Cin][9][Cout] -> matrix-core layout [9][Cin/kc][cpad][kc] (kernels_det_conv3.hip); empty when the shape is not covered
 std::vector<float> pack_conv3_mfma(const std::vector<float> &w, int cin, int cout, int &kc, int &cpad) {
     kc = cin == 16 ? 16 : 32;
@@ -209,6 +233,8 @@ void frt_detector::build(const frt::Blob &b) {
         if (stride == 1) {
             const std::vector<float> pk = pack_conv3_mfma(w, cin, cout, o.c3[0].wm_kc, o.c3[0].wm_cpad);
             if (!pk.empty()) o.c3[0].wm = arena.upload(pk);
+            const std::vector<uint16_t> ph = pack_conv3_split(w, cin, cout);
+            if (!ph.empty()) o.c3[0].wh = reinterpret_cast<const half_t *>(arena.upload(ph));
         }
         ops.push_back(o);
         flops_per_frame += 2.0 * cin * 9 * cout * o.c3[0].Ho * o.c3[0].Wo;
@@ -225,6 +251,8 @@ void frt_detector::build(const frt::Blob &b) {
             o.c3[k] = Conv3Args{in[k], out[k], arena.upload(w), arena.upload(bias), B, cin, hs[k], ws[k], cout, hs[k], ws[k], 1, 1, ctotal, coff};
             const std::vector<float> pk = pack_conv3_mfma(w, cin, cout, o.c3[k].wm_kc, o.c3[k].wm_cpad);
             if (!pk.empty()) o.c3[k].wm = arena.upload(pk);
+            const std::vector<uint16_t> ph = pack_conv3_split(w, cin, cout);
+            if (!ph.empty()) o.c3[k].wh = reinterpret_cast<const half_t *>(arena.upload(ph));
             flops_per_frame += 2.0 * cin * 9 * cout * hs[k] * ws[k];
         }
         ops.push_back(o);
@@ -252,6 +280,8 @@ void frt_detector::build(const frt::Blob &b) {
             const std::vector<float> pk = pack_conv3_mfma(wc, cin, cout, o.c3[k].wm_kc, o.c3[k].wm_cpad);
             if (pk.empty()) raise(FRT_ERR_INVALID, "detector: fused SSH conv shape not covered");
             o.c3[k].wm = arena.upload(pk);
+            const std::vector<uint16_t> ph = pack_conv3_split(wc, cin, cout);
+            if (!ph.empty()) o.c3[k].wh = reinterpret_cast<const half_t *>(arena.upload(ph));
             o.c3[k].out2 = outb[k];
             o.c3[k].split = couta;
             o.c3[k].out2_ctotal = ctotalb;
@@ -400,7 +430,7 @@ void frt_detector::forward(int n, hipStream_t s, int first_op) {
         }
         if (o.type == 3) {
             for (int k = 0; k < o.n; ++k) o.c3[k].B = n;
-            if (det_mfma_enabled() && launch_conv3x3_mfma(o.c3, o.n, s)) skip = 2;  // else: the two separate convs that follow
+            if (det_mfma_enabled() && (launch_conv3x3_split(o.c3, o.n, s) || launch_conv3x3_mfma(o.c3, o.n, s))) skip = 2;  // else: the two separate convs
             continue;
         }
         if (o.type == 0) {

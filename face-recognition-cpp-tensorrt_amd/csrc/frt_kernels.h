@@ -92,6 +92,7 @@ struct Conv3Args {
     // matrix-core path (kernels_det_conv3.hip); all optional
     const float *wm;           // host-packed weights [9][Cin/wm_kc][wm_cpad][wm_kc] (zero rows beyond Cout); null: scalar kernel only
     int wm_kc, wm_cpad;
+    const half_t *wh;          // fp16 hi/lo split weights [Cin/16][9][64][hi16|lo16] (kernels_det_conv3h.hip, Cin == 64); null: n/a
     float *out2;               // channels >= split go to out2 (channel co - split of a [B][out2_ctotal][Ho][Wo] tensor, + out2_coff)
     int split, out2_ctotal, out2_coff;
 };
@@ -102,6 +103,7 @@ bool launch_det_conv1_u8(const uint8_t *frames, size_t row_stride, size_t frame_
 // (A fused "stem" kernel - first conv + the two conv_dw blocks behind it with the intermediates in LDS - was tried and removed:
 //  436-840 us against 302 us for the three separate kernels; with ~1150 weights it either spills SGPRs or hoists every LDS weight
 //  read into 290 VGPRs, and the halo recompute plus LDS traffic eat the HBM saving.)
+bool launch_conv3x3_split(const Conv3Args *a, int n, hipStream_t s);  // fp16 hi/lo split MFMA version (Cin == 64); false: n/a
 bool launch_conv3x3_mfma(const Conv3Args *a, int n, hipStream_t s);   // false: shape not covered, use the scalar kernel
 void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s);  // up to 3 same-Cout problems in one launch
 struct HeadArgs {

@@ -388,6 +388,7 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
 }
 
 void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s) {
+    if (det_mfma_enabled() && launch_conv3x3_split(a, n, s)) return;  // fp16 hi/lo split on the fp16 matrix cores (kernels_det_conv3h.hip)
     if (det_mfma_enabled() && launch_conv3x3_mfma(a, n, s)) return;  // fp32 matrix-core kernel (kernels_det_mfma.hip)
     Conv3Multi mm;
     long max_total = 0;
