@@ -70,3 +70,24 @@ def test_find_face_boxes_match_oracle_pipeline(frt, orc, synth, blobs, geom):
         assert np.abs(got[f]["score"] - want["score"]).max() < CONF_TOL
     assert exact >= total - 2, (exact, total)
     det.close()
+
+
+def test_batch_of_32_equals_frame_by_frame(frt, synth, blobs):
+    """Size-independent property at the benchmark batch: every frame of a 32-frame call gets exactly the boxes (and head outputs)
+    it gets alone - the persistent tile walks / batch indexing of the matrix-core kernels must not leak across frames."""
+    path, _ = blobs("det")
+    h = w = 640
+    det32 = frt.RetinaFace(path, w, h, (3, h, w), 32, 4)
+    det1 = frt.RetinaFace(path, w, h, (3, h, w), 1, 4)
+    frames = synth.make_frames(32, h, w)
+    batch = det32.findFaceBatch(frames)
+    for i in (0, 1, 13, 30, 31):
+        alone = det1.findFace(frames[i])
+        assert np.array_equal(batch[i], alone), i
+    x = np.ascontiguousarray((frames[:32].astype(np.float32) - np.array([104, 117, 123], np.float32)).transpose(0, 3, 1, 2))
+    loc32, conf32 = det32.doInference(x)
+    for i in (0, 17, 31):
+        loc1, conf1 = det1.doInference(x[i:i + 1])
+        assert np.array_equal(loc32[i], loc1[0]) and np.array_equal(conf32[i], conf1[0]), i
+    det32.close()
+    det1.close()

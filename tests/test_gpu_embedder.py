@@ -74,3 +74,18 @@ def test_forward_crops_and_embeds_like_the_oracle(frt, orc, synth, blobs):
     with pytest.raises(frt.FrtError):
         rec.featureMatching()
     rec.close()
+
+
+def test_batch_of_128_equals_small_batches(frt, synth, blobs):
+    """Benchmark batch (128 faces) vs the same faces in batches of 8: identical embeddings (strip walks of the persistent conv
+    kernels, grid-dependent tile variants and the split-K linear must be batch-size independent per face)."""
+    path, _ = blobs("ir")
+    big = frt.ArcFaceIR50(path, maxBatchSize=128)
+    small = frt.ArcFaceIR50(path, maxBatchSize=8)
+    x = np.random.default_rng(11).standard_normal((128, 3, 112, 112)).astype(np.float32) * 0.5
+    e = big.doInference(x)
+    for f0 in (0, 40, 120):
+        es = small.doInference(x[f0:f0 + 8])
+        assert np.abs(e[f0:f0 + 8] - es).max() < 2e-6, (f0, np.abs(e[f0:f0 + 8] - es).max())
+    big.close()
+    small.close()

@@ -124,3 +124,25 @@ def test_graph_replay_matches_eager(frt, synth, blobs):
     pipe.close()
     det.close()
     rec.close()
+
+
+def test_repeated_runs_are_bit_identical_at_the_benchmark_size(frt, synth, blobs):
+    """32 frames x K = 4 (the bench.py step), 12 back-to-back runs with the two-stream overlap on: every run must return the same
+    bytes.  The persistent / double-buffered kernels (conv64, split 3x3, conv_dw) would show hand-over races here as flaky bits."""
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 32, 4, 640, 640
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    rec.setGallery(synth.make_gallery(50000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    frames = synth.make_frames(B, H, W)
+    r0, e0 = pipe.run(frames)
+    assert r0["valid"].sum() >= B * K // 2
+    for i in range(12):
+        r, e = pipe.run(frames)
+        assert np.array_equal(r, r0) and np.array_equal(e, e0), i
+    pipe.close()
+    det.close()
+    rec.close()
