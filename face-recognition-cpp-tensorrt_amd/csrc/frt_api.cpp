@@ -315,8 +315,13 @@ void frt_detector::build(const frt::Blob &b) {
                 fold_pw(b, p + ".3", p + ".4", l.cout, l.cin, w2, bias2);
                 Op o{};
                 o.type = 0;
+                std::vector<float> w12((size_t)l.cin * 12, 0.f);
+                for (int ci = 0; ci < l.cin; ++ci) {
+                    for (int t = 0; t < 9; ++t) w12[(size_t)ci * 12 + t] = w[(size_t)ci * 9 + t];
+                    w12[(size_t)ci * 12 + 9] = bias[ci];
+                }
                 o.dw = DwPwArgs{cur, out, arena.upload(w), arena.upload(bias), arena.upload(w2), arena.upload(bias2), nullptr, 0, 0,
-                                B, l.cin, ch, cw, l.cout, oh, ow, l.stride, 1, d_tmp};
+                                B, l.cin, ch, cw, l.cout, oh, ow, l.stride, 1, d_tmp, arena.upload(w12)};
                 ops.push_back(o);
                 flops_per_frame += 2.0 * oh * ow * (9.0 * l.cin + (double)l.cin * l.cout);
             }

@@ -81,6 +81,7 @@ struct DwPwArgs {
     int add_h, add_w;
     int B, Cin, H, W, Cout, Ho, Wo, stride, relu;
     float *tmp;             // scratch [B][Cin][Ho][Wo] for the split depthwise -> pointwise path (null: always fused)
+    const float *wd12;      // depthwise weights packed [Cin][12] = 9 taps, bias, 2 pad (matrix-core kernel); null: scalar kernels only
 };
 void launch_dwpw(const DwPwArgs &a, hipStream_t s);
 bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s);  // false: shape not covered, use the scalar kernels
