@@ -249,7 +249,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 MFMA convs (fp32 accumulate) + f32 detector + f32 MFMA match",
+            "dtype": "f16 MFMA recogniser convs (fp32 accumulate) + fp32-accurate detector (fp32 MFMA, fp16 hi/lo-split MFMA for the 64-channel 3x3 convs) + f32 MFMA match",
             "data": "synthetic",
             "config": {"workload": "640x640 batch=%d frames/GPU, K=%d faces/frame, %dx512 fp32 gallery replicated per GPU, "
                                    "RetinaFace-mnet0.25 + ArcFace %s" % (B, K, args.gallery, "IR-50" if args.mode == "ir" else "IR-SE-50"),
