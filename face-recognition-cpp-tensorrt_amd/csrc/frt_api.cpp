@@ -777,11 +777,14 @@ struct frt_pipeline {
     frt_matcher *mat;
     int max_frames, max_faces, F_cap;
     hipStream_t stream = nullptr, own_stream = nullptr;
-    // Two-stream software pipeline: the detector (fp32 VALU / latency bound) of call b+1 runs on det_stream while crop + embed
-    // (MFMA bound) + match of call b run on `stream`; the two leave each other's execution units idle, so they overlap on the
-    // same CUs.  Fork/join with events; the boxes of a call live in one of two slots so the next detect cannot clobber them.
-    hipStream_t det_stream = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_det[2] = {nullptr, nullptr};
+    // Three-stage software pipeline over consecutive calls: detector of call b+1 (det_stream), crop + recogniser of call b
+    // (emb_stream), match + pack of call b-1 (match_stream) - three stages with different bottlenecks (latency / MFMA+LDS / HBM)
+    // that overlap on the same CUs.  `stream` (the caller's) only joins.  Fork/join with events; boxes, embeddings and validity
+    // flags of a call live in one of two slots so that a later stage of the previous call can still read them.
+    hipStream_t det_stream = nullptr, emb_stream = nullptr, match_stream = nullptr;
+    hipEvent_t ev_det[2] = {nullptr, nullptr}, ev_emb[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    float *slot_embeds[2] = {nullptr, nullptr};
+    int *slot_valid[2] = {nullptr, nullptr};
     frt_bbox *slot_boxes[2];
     int *slot_nout[2];
     float *slot_landmarks[2] = {nullptr, nullptr};
@@ -865,11 +868,19 @@ struct frt_pipeline {
         const DetGeom &g = det->g;
         const int F = n * max_faces;
         const int slot = (int)(seq++ & 1u);
-        hipStream_t ds = (overlap && g_prof_kind != 2) ? det_stream : s;  // the stage-profiling mode times stages serially on one stream
-        if (ds != s && seq > 2) {
-            // det_stream may overwrite this box slot once the crop/pack that read it two calls ago (on `s`) are done.  NB the
-            // frames must be valid when the call is made: waiting for all prior work on `s` here would serialise the two streams.
-            HIPCHK(hipStreamWaitEvent(ds, ev_in[slot], 0));
+        // Three-stage software pipeline over consecutive calls (stage-profiling mode and overlap off: everything serially on `s`):
+        //   D  detector of call b+1          (fp32 / split-fp16 MFMA + latency-bound stencils)
+        //   E  crop + recogniser of call b   (fp16 MFMA / LDS bound)
+        //   M  match + pack of call b-1      (HBM bound: streams the 1 GB fp16 shadow gallery)
+        // The caller's stream only JOINS: it waits for M of this call, so everything the caller enqueues after the call sees the
+        // results, exactly as if the call had run on that stream.  Boxes, embeddings and validity flags live in two slots.
+        const bool pipe3 = overlap && g_prof_kind != 2;
+        hipStream_t ds = pipe3 ? det_stream : s, es = pipe3 ? emb_stream : s, ms = pipe3 ? match_stream : s;
+        if (pipe3 && seq > 2) {
+            // slot buffers are free again once M of the call two back is done.  NB the frames must be valid when the call is made:
+            // making D wait for prior work on `s` would serialise the stages.
+            HIPCHK(hipStreamWaitEvent(ds, ev_done[slot], 0));
+            HIPCHK(hipStreamWaitEvent(es, ev_done[slot], 0));
         }
         const bool have_gallery = mat && mat->N > 0;
         const unsigned gen = mat ? mat->generation : 0u;
@@ -880,34 +891,45 @@ struct frt_pipeline {
             HIPCHK(hipMemcpyAsync(slot_nout[slot], det->d_nout, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
             if (align) HIPCHK(hipMemcpyAsync(slot_landmarks[slot], det->d_landmarks, sizeof(float) * 10 * F, hipMemcpyDeviceToDevice, st));
         });
-        if (ds != s) {
+        if (pipe3) {
             HIPCHK(hipEventRecord(ev_det[slot], ds));
-            HIPCHK(hipStreamWaitEvent(s, ev_det[slot], 0));
+            HIPCHK(hipStreamWaitEvent(es, ev_det[slot], 0));
         }
         const frt_bbox *boxes = slot_boxes[slot];
         const int *nout = slot_nout[slot];
-        float *emb_out = embeds_dev ? embeds_dev : d_embeds;
-        run_part(GraphKey{1, frames_dev, results_dev, emb_out, n, slot, align ? 1 : 0, gen}, s, [&](hipStream_t st) {
+        float *emb_slot = slot_embeds[slot];
+        int *valid = slot_valid[slot];
+        run_part(GraphKey{1, frames_dev, nullptr, nullptr, n, slot, align ? 1 : 0, 0u}, es, [&](hipStream_t st) {
             if (align) {
                 ProfScope ps(2, "align_faces", (double)F * 112 * 112 * 3, st);
                 launch_align_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, slot_landmarks[slot],
-                                   nout, max_faces, F, 0, nullptr, d_chw, d_valid, st);
+                                   nout, max_faces, F, 0, nullptr, d_chw, valid, st);
             } else {
                 ProfScope ps(2, "crop_faces", (double)F * 112 * 112 * 3, st);
                 launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, boxes, nout, max_faces,
-                                  F, 0, 112, 112, nullptr, d_chw, d_valid, st);
+                                  F, 0, 112, 112, nullptr, d_chw, valid, st);
             }
             for (int f0 = 0; f0 < F; f0 += emb->max_batch) {
                 const int nf = std::min(emb->max_batch, F - f0);
-                emb->forward(d_chw + (size_t)f0 * 3 * 112 * 112, nf, d_valid + f0, emb_out + (size_t)f0 * 512, st);
-            }
-            if (have_gallery) mat->top1_dev(emb_out, F, d_idx, d_sim, st);
-            {
-                ProfScope ps(2, "pack_results", (double)F, st);
-                launch_pack_results(boxes, nout, d_valid, have_gallery ? d_idx : nullptr, have_gallery ? d_sim : nullptr, max_faces, F, results_dev, st);
+                emb->forward(d_chw + (size_t)f0 * 3 * 112 * 112, nf, valid + f0, emb_slot + (size_t)f0 * 512, st);
             }
         });
-        if (ds != s) HIPCHK(hipEventRecord(ev_in[slot], s));  // this slot's boxes are free again after this point of `s`
+        if (pipe3) {
+            HIPCHK(hipEventRecord(ev_emb[slot], es));
+            HIPCHK(hipStreamWaitEvent(ms, ev_emb[slot], 0));
+        }
+        run_part(GraphKey{2, nullptr, results_dev, embeds_dev, n, slot, align ? 1 : 0, gen}, ms, [&](hipStream_t st) {
+            if (have_gallery) mat->top1_dev(emb_slot, F, d_idx, d_sim, st);
+            {
+                ProfScope ps(2, "pack_results", (double)F, st);
+                launch_pack_results(boxes, nout, valid, have_gallery ? d_idx : nullptr, have_gallery ? d_sim : nullptr, max_faces, F, results_dev, st);
+            }
+            if (embeds_dev) HIPCHK(hipMemcpyAsync(embeds_dev, emb_slot, sizeof(float) * 512 * F, hipMemcpyDeviceToDevice, st));
+        });
+        if (pipe3) {
+            HIPCHK(hipEventRecord(ev_done[slot], ms));
+            HIPCHK(hipStreamWaitEvent(s, ev_done[slot], 0));  // the caller's stream joins here
+        }
     }
 };
 
@@ -1478,10 +1500,15 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         HIPCHK(hipStreamCreate(&p->own_stream));
         p->stream = p->own_stream;
         HIPCHK(hipStreamCreate(&p->det_stream));
+        HIPCHK(hipStreamCreate(&p->emb_stream));
+        HIPCHK(hipStreamCreate(&p->match_stream));
         const size_t F = (size_t)p->F_cap;
         for (int i = 0; i < 2; ++i) {
-            HIPCHK(hipEventCreateWithFlags(&p->ev_in[i], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&p->ev_det[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&p->ev_emb[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&p->ev_done[i], hipEventDisableTiming));
+            p->slot_embeds[i] = p->arena.alloc<float>(F * 512);
+            p->slot_valid[i] = p->arena.alloc<int>(F);
             p->slot_boxes[i] = p->arena.alloc<frt_bbox>(F);
             p->slot_nout[i] = p->arena.alloc<int>((size_t)max_frames);
             if (d->has_landmarks) p->slot_landmarks[i] = p->arena.alloc<float>(F * 10);
@@ -1507,13 +1534,18 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     if (!p) return;
     (void)hipSetDevice(p->det->device);
     if (p->det_stream) (void)hipStreamSynchronize(p->det_stream);
+    if (p->emb_stream) (void)hipStreamSynchronize(p->emb_stream);
+    if (p->match_stream) (void)hipStreamSynchronize(p->match_stream);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     p->drop_graphs();
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->det_stream) (void)hipStreamDestroy(p->det_stream);
+    if (p->emb_stream) (void)hipStreamDestroy(p->emb_stream);
+    if (p->match_stream) (void)hipStreamDestroy(p->match_stream);
     for (int i = 0; i < 2; ++i) {
-        if (p->ev_in[i]) (void)hipEventDestroy(p->ev_in[i]);
         if (p->ev_det[i]) (void)hipEventDestroy(p->ev_det[i]);
+        if (p->ev_emb[i]) (void)hipEventDestroy(p->ev_emb[i]);
+        if (p->ev_done[i]) (void)hipEventDestroy(p->ev_done[i]);
     }
     p->arena.release();
     delete p;
@@ -1545,6 +1577,8 @@ int frt_pipeline_sync(frt_pipeline *p) {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
     });
 }
@@ -1554,6 +1588,8 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : p->own_stream;
     });
@@ -1564,6 +1600,8 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable) {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->overlap = enable != 0;
         p->seq = 0;
@@ -1576,6 +1614,8 @@ int frt_pipeline_set_graph(frt_pipeline *p, int enable) {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->use_graphs = enable != 0;
         p->drop_graphs();
@@ -1588,6 +1628,8 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable) {
         if (enable && !p->det->has_landmarks) raise(FRT_ERR_FORMAT, "pipeline: alignment needs a detector blob with the LandmarkHead");
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->align = enable != 0;
     });

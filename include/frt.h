@@ -158,9 +158,11 @@ int frt_pipeline_sync(frt_pipeline *p);
 /* Run on a caller-owned HIP stream (a hipStream_t passed as void*, e.g. PyTorch's current stream, so that RCCL collectives
  * issued by the caller are ordered after the pipeline without a host synchronisation).  NULL restores the private stream. */
 int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream);
-/* Two-stream software pipelining (default on; env FRT_PIPELINE_OVERLAP=0 disables): the detector of call b+1 runs on an
- * internal stream concurrently with crop/embed/match of call b.  Results stay ordered on the pipeline stream.  With
- * overlap on, the frames passed to frt_pipeline_run_dev must already be valid when the call is made. */
+/* Software pipelining across calls (default on; env FRT_PIPELINE_OVERLAP=0 disables): detector of call b+1, crop + recogniser of
+ * call b and match + pack of call b-1 run on three internal streams; the pipeline stream joins at the end of every call, so
+ * results stay ordered on it exactly as if the call had run there.  With overlap on, the frames passed to
+ * frt_pipeline_run_dev must already be valid when the call is made (the internal streams do not wait for earlier work on
+ * the pipeline stream) and must stay unchanged until that call's results are complete on the pipeline stream. */
 int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
 /* hipGraph replay of a call's ~150 launches (opt-in: env FRT_PIPELINE_GRAPH=1 or this call; measured neutral on one GPU).  A call whose buffers, batch size
  * and mode repeat is captured on its second occurrence and replayed afterwards; callers that never repeat their buffers stay
