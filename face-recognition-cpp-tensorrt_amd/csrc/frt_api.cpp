@@ -497,6 +497,29 @@ struct frt_embedder {
     void build(const frt::Blob &b);
     // chw_dev [F][3][112][112] -> out_dev [F][512]; F <= max_batch
     void forward(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s);
+    // second set of activation buffers: lets the pipeline run the recogniser passes of two consecutive calls concurrently on two
+    // streams (forward_alt).  Allocated on demand (288 GB of HBM: 1.2 GB more is not a concern).
+    struct ActSet {
+        half_t *Y[2], *Z[2], *T, *SC, *RES;
+        float *fc_partial, *se_pool, *se_gate;
+    } alt{};
+    bool has_alt = false;
+    void ensure_alt();
+    void swap_alt() {
+        std::swap(Y[0], alt.Y[0]); std::swap(Y[1], alt.Y[1]); std::swap(Z[0], alt.Z[0]); std::swap(Z[1], alt.Z[1]);
+        std::swap(T, alt.T); std::swap(SC, alt.SC); std::swap(RES, alt.RES);
+        std::swap(fc_partial, alt.fc_partial); std::swap(se_pool, alt.se_pool); std::swap(se_gate, alt.se_gate);
+    }
+    void forward_set(int set, const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s) {
+        if (set) swap_alt();  // host-side pointer swap: the launches below capture the alternate buffers
+        try {
+            forward(chw_dev, F, valid_dev, out_dev, s);
+        } catch (...) {
+            if (set) swap_alt();
+            throw;
+        }
+        if (set) swap_alt();
+    }
 };
 
 namespace {
@@ -615,6 +638,27 @@ void frt_embedder::build(const frt::Blob &b) {
     d_lm = arena.alloc<float>((size_t)F * 10);
     zeros = arena.alloc<half_t>(256);
     HIPCHK(hipMemset(zeros, 0, 256 * sizeof(half_t)));
+}
+
+void frt_embedder::ensure_alt() {
+    if (has_alt) return;
+    const size_t F = (size_t)max_batch;
+    const size_t big = F * 112 * 112 * 64;
+    for (int i = 0; i < 2; ++i) {
+        alt.Y[i] = arena.alloc<half_t>(big);
+        alt.Z[i] = arena.alloc<half_t>(big);
+    }
+    alt.T = arena.alloc<half_t>(big);
+    alt.SC = arena.alloc<half_t>(F * 28 * 28 * 128);
+    alt.RES = nullptr;
+    alt.se_pool = alt.se_gate = nullptr;
+    if (se) {
+        alt.RES = arena.alloc<half_t>(F * 56 * 56 * 64);
+        alt.se_pool = arena.alloc<float>(F * 512 * 4);
+        alt.se_gate = arena.alloc<float>(F * 512);
+    }
+    alt.fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);
+    has_alt = true;
 }
 
 void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s) {
@@ -781,7 +825,9 @@ struct frt_pipeline {
     // (emb_stream), match + pack of call b-1 (match_stream) - three stages with different bottlenecks (latency / MFMA+LDS / HBM)
     // that overlap on the same CUs.  `stream` (the caller's) only joins.  Fork/join with events; boxes, embeddings and validity
     // flags of a call live in one of two slots so that a later stage of the previous call can still read them.
-    hipStream_t det_stream = nullptr, emb_stream = nullptr, match_stream = nullptr;
+    hipStream_t det_stream = nullptr, emb_stream = nullptr, emb_stream2 = nullptr, match_stream = nullptr;
+    bool dual_embed = true;   // recogniser passes of consecutive calls on two streams with two activation sets (FRT_PIPELINE_DUAL_EMBED=0: one)
+    float *d_chw2 = nullptr;
     hipEvent_t ev_det[2] = {nullptr, nullptr}, ev_emb[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     float *slot_embeds[2] = {nullptr, nullptr};
     int *slot_valid[2] = {nullptr, nullptr};
@@ -875,7 +921,9 @@ struct frt_pipeline {
         // The caller's stream only JOINS: it waits for M of this call, so everything the caller enqueues after the call sees the
         // results, exactly as if the call had run on that stream.  Boxes, embeddings and validity flags live in two slots.
         const bool pipe3 = overlap && g_prof_kind != 2;
-        hipStream_t ds = pipe3 ? det_stream : s, es = pipe3 ? emb_stream : s, ms = pipe3 ? match_stream : s;
+        const int eset = (pipe3 && dual_embed && F <= emb->max_batch) ? slot : 0;  // activation set / stream of this call's recogniser pass
+        hipStream_t ds = pipe3 ? det_stream : s, es = pipe3 ? (eset ? emb_stream2 : emb_stream) : s, ms = pipe3 ? match_stream : s;
+        float *chw = eset ? d_chw2 : d_chw;
         if (pipe3 && seq > 2) {
             // slot buffers are free again once M of the call two back is done.  NB the frames must be valid when the call is made:
             // making D wait for prior work on `s` would serialise the stages.
@@ -899,19 +947,20 @@ struct frt_pipeline {
         const int *nout = slot_nout[slot];
         float *emb_slot = slot_embeds[slot];
         int *valid = slot_valid[slot];
-        run_part(GraphKey{1, frames_dev, nullptr, nullptr, n, slot, align ? 1 : 0, 0u}, es, [&](hipStream_t st) {
+        // (a pass on activation set k follows the pass two calls back on the same set: ordered by its stream and by ev_done[slot])
+        run_part(GraphKey{1, frames_dev, nullptr, nullptr, n, slot, align ? 1 : 0, (unsigned)eset}, es, [&](hipStream_t st) {
             if (align) {
                 ProfScope ps(2, "align_faces", (double)F * 112 * 112 * 3, st);
                 launch_align_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, slot_landmarks[slot],
-                                   nout, max_faces, F, 0, nullptr, d_chw, valid, st);
+                                   nout, max_faces, F, 0, nullptr, chw, valid, st);
             } else {
                 ProfScope ps(2, "crop_faces", (double)F * 112 * 112 * 3, st);
                 launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, boxes, nout, max_faces,
-                                  F, 0, 112, 112, nullptr, d_chw, valid, st);
+                                  F, 0, 112, 112, nullptr, chw, valid, st);
             }
             for (int f0 = 0; f0 < F; f0 += emb->max_batch) {
                 const int nf = std::min(emb->max_batch, F - f0);
-                emb->forward(d_chw + (size_t)f0 * 3 * 112 * 112, nf, valid + f0, emb_slot + (size_t)f0 * 512, st);
+                emb->forward_set(eset, chw + (size_t)f0 * 3 * 112 * 112, nf, valid + f0, emb_slot + (size_t)f0 * 512, st);
             }
         });
         if (pipe3) {
@@ -1501,6 +1550,15 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         p->stream = p->own_stream;
         HIPCHK(hipStreamCreate(&p->det_stream));
         HIPCHK(hipStreamCreate(&p->emb_stream));
+        HIPCHK(hipStreamCreate(&p->emb_stream2));
+        {
+            const char *de = getenv("FRT_PIPELINE_DUAL_EMBED");
+            p->dual_embed = !(de && de[0] == '0');
+        }
+        if (p->dual_embed) {
+            e->ensure_alt();
+            p->d_chw2 = p->arena.alloc<float>((size_t)max_frames * d->g.max_faces * 3 * 112 * 112);
+        }
         HIPCHK(hipStreamCreate(&p->match_stream));
         const size_t F = (size_t)p->F_cap;
         for (int i = 0; i < 2; ++i) {
@@ -1535,12 +1593,14 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     (void)hipSetDevice(p->det->device);
     if (p->det_stream) (void)hipStreamSynchronize(p->det_stream);
     if (p->emb_stream) (void)hipStreamSynchronize(p->emb_stream);
+    if (p->emb_stream2) (void)hipStreamSynchronize(p->emb_stream2);
     if (p->match_stream) (void)hipStreamSynchronize(p->match_stream);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     p->drop_graphs();
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->det_stream) (void)hipStreamDestroy(p->det_stream);
     if (p->emb_stream) (void)hipStreamDestroy(p->emb_stream);
+    if (p->emb_stream2) (void)hipStreamDestroy(p->emb_stream2);
     if (p->match_stream) (void)hipStreamDestroy(p->match_stream);
     for (int i = 0; i < 2; ++i) {
         if (p->ev_det[i]) (void)hipEventDestroy(p->ev_det[i]);
@@ -1578,6 +1638,7 @@ int frt_pipeline_sync(frt_pipeline *p) {
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream2));
         HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
     });
@@ -1589,6 +1650,7 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream2));
         HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : p->own_stream;
@@ -1601,6 +1663,7 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable) {
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream2));
         HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->overlap = enable != 0;
@@ -1615,6 +1678,7 @@ int frt_pipeline_set_graph(frt_pipeline *p, int enable) {
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream2));
         HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->use_graphs = enable != 0;
@@ -1629,6 +1693,7 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable) {
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream2));
         HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->align = enable != 0;
