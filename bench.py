@@ -131,9 +131,11 @@ def main():
     faces_per_step = int(res["valid"].sum())
 
     profile = not args.no_profile
-    # Per-launch HIP events (roofline object) are recorded for ONE step in the middle of the timed region: left on for every step
-    # they cost ~0.5 ms per step (two event packets around each of ~55 conv launches) - 11 % of the number being measured.
-    sampled_step = args.steps // 2
+    # Per-launch HIP events (roofline object) are recorded for ONE step (the last) of the timed region: left on for every step
+    # they cost ~0.5 ms per step (two event packets around each of ~55 conv launches) - 11 % of the number being measured.  libfrt
+    # runs a profiled call serially on the pipeline stream (no other stage competes for the dispatch), so the bracketed time is the
+    # kernel's own duration - the number rocprofv3 reports; with four streams in flight it was 2.7x that.
+    sampled_step = args.steps - 1  # the LAST step: the pipeline drains at the end of the region anyway, so serialising it costs no refill
     frt.profile_enable(0)
     if use_dist:
         dist.barrier()
@@ -217,9 +219,10 @@ def main():
             roofline["serial_frac"] = round(ach / PEAK_FP16_MFMA_TFLOPS, 4)
             roofline["serial_avg_launch_us"] = round(1e3 * ser[dom][0] / ser[dom][2], 2)
             roofline["note"] = ("achieved/frac/avg_launch_us: live HIP-event durations of every launch of the kernel in ONE step (step %d of %d) "
-                                "inside the timed region (two-stream pipeline: the next batch's detector shares the CUs; events on every step "
-                                "would cost 11 %% of the step time); serial_*: same launches with the overlap switched off (3 extra untimed steps)"
-                                % (sampled_step + 1, args.steps))
+                                "inside the timed region; that call runs serially on the pipeline stream so that the events bracket the kernel "
+                                "alone (events on every step would cost 11 %% of the step time, and under the 4-stream pipeline the bracketed "
+                                "time includes other streams' dispatches); serial_*: same launches again in 3 extra untimed steps with the "
+                                "pipeline switched off" % (sampled_step + 1, args.steps))
 
     if args.stage_profile and rank == 0:  # extra, untimed steps with stage-level HIP events -> a side file (not the JSON line)
         frt.profile_enable(2)

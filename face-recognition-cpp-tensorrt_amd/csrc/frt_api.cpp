@@ -828,6 +828,8 @@ struct frt_pipeline {
     hipStream_t det_stream = nullptr, emb_stream = nullptr, emb_stream2 = nullptr, match_stream = nullptr;
     bool dual_embed = true;   // recogniser passes of consecutive calls on two streams with two activation sets (FRT_PIPELINE_DUAL_EMBED=0: one)
     float *d_chw2 = nullptr;
+    hipEvent_t ev_serial = nullptr;  // end of the last serial (profiled) call while overlap is on
+    bool serial_pending = false;
     static constexpr int NSLOT = 3;  // calls in flight between the start of D and the end of M (2: 32.5k, 3: 33.6k, 4: 33.6k faces/s)
     hipEvent_t ev_det[NSLOT] = {}, ev_emb[NSLOT] = {}, ev_done[NSLOT] = {};
     float *slot_embeds[NSLOT] = {};
@@ -922,7 +924,16 @@ struct frt_pipeline {
         //   M  match + pack of call b-1      (HBM bound: streams the 1 GB fp16 shadow gallery)
         // The caller's stream only JOINS: it waits for M of this call, so everything the caller enqueues after the call sees the
         // results, exactly as if the call had run on that stream.  Boxes, embeddings and validity flags live in two slots.
-        const bool pipe3 = overlap && g_prof_kind != 2;
+        // Profiled calls (frt_profile_enable 1 or 2) run serially on `s`: HIP events around a launch only measure the kernel when
+        // no other stream competes for the dispatch (with four streams in flight the bracketed time was 2.7x the kernel time).
+        const bool pipe3 = overlap && g_prof_kind == 0;
+        if (pipe3 && serial_pending) {  // a serial call used the shared detector / recogniser buffers on `s`: order the stages behind it
+            HIPCHK(hipStreamWaitEvent(det_stream, ev_serial, 0));
+            HIPCHK(hipStreamWaitEvent(emb_stream, ev_serial, 0));
+            HIPCHK(hipStreamWaitEvent(emb_stream2, ev_serial, 0));
+            HIPCHK(hipStreamWaitEvent(match_stream, ev_serial, 0));
+            serial_pending = false;
+        }
         const int eset = (pipe3 && dual_embed && F <= emb->max_batch) ? (int)(call & 1u) : 0;  // activation set / stream of this call's recogniser pass
         hipStream_t ds = pipe3 ? det_stream : s, es = pipe3 ? (eset ? emb_stream2 : emb_stream) : s, ms = pipe3 ? match_stream : s;
         float *chw = eset ? d_chw2 : d_chw;
@@ -980,6 +991,9 @@ struct frt_pipeline {
         if (pipe3) {
             HIPCHK(hipEventRecord(ev_done[slot], ms));
             HIPCHK(hipStreamWaitEvent(s, ev_done[slot], 0));  // the caller's stream joins here
+        } else if (overlap) {
+            HIPCHK(hipEventRecord(ev_serial, s));
+            serial_pending = true;
         }
     }
 };
@@ -1563,6 +1577,7 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         }
         HIPCHK(hipStreamCreate(&p->match_stream));
         const size_t F = (size_t)p->F_cap;
+        HIPCHK(hipEventCreateWithFlags(&p->ev_serial, hipEventDisableTiming));
         for (int i = 0; i < frt_pipeline::NSLOT; ++i) {
             HIPCHK(hipEventCreateWithFlags(&p->ev_det[i], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&p->ev_emb[i], hipEventDisableTiming));
@@ -1604,6 +1619,7 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     if (p->emb_stream) (void)hipStreamDestroy(p->emb_stream);
     if (p->emb_stream2) (void)hipStreamDestroy(p->emb_stream2);
     if (p->match_stream) (void)hipStreamDestroy(p->match_stream);
+    if (p->ev_serial) (void)hipEventDestroy(p->ev_serial);
     for (int i = 0; i < frt_pipeline::NSLOT; ++i) {
         if (p->ev_det[i]) (void)hipEventDestroy(p->ev_det[i]);
         if (p->ev_emb[i]) (void)hipEventDestroy(p->ev_emb[i]);
@@ -1710,7 +1726,7 @@ int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_f
         hipStream_t s = p->stream;
         const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
         // upload on the stream the detector will run on: the crop (pipeline stream) is ordered behind the detector's event
-        hipStream_t cs = (p->overlap && g_prof_kind != 2) ? p->det_stream : s;
+        hipStream_t cs = (p->overlap && g_prof_kind == 0) ? p->det_stream : s;
         HIPCHK(hipMemcpyAsync(p->d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, cs));
         pipeline_lock_run(p, p->d_frames, n_frames, p->d_results, p->d_embeds);
         const int F = n_frames * p->max_faces;
