@@ -912,7 +912,14 @@ struct frt_pipeline {
         HIPCHK(hipGraphLaunch(e->exec, st));
     }
 
+    void ensure_stream() {
+        if (!stream) {
+            if (!own_stream) HIPCHK(hipStreamCreate(&own_stream));
+            stream = own_stream;
+        }
+    }
     void run(const uint8_t *frames_dev, int n, frt_face_result *results_dev, float *embeds_dev) {
+        ensure_stream();
         hipStream_t s = stream;
         const DetGeom &g = det->g;
         const int F = n * max_faces;
@@ -1562,11 +1569,21 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         p->max_frames = max_frames;
         p->max_faces = d->g.max_faces;
         p->F_cap = max_frames * p->max_faces;
-        HIPCHK(hipStreamCreate(&p->own_stream));
-        p->stream = p->own_stream;
-        HIPCHK(hipStreamCreate(&p->det_stream));
-        HIPCHK(hipStreamCreate(&p->emb_stream));
-        HIPCHK(hipStreamCreate(&p->emb_stream2));
+        // the pipeline's own join stream is created on first use: ROCm maps streams onto 4 hardware queues round-robin and streams that
+        // share a queue serialise, so a stream nobody uses (callers usually pass theirs) should not take a slot among the stage streams
+        p->stream = nullptr;
+        // the stage streams are created at the highest stream priority: ROCm keeps a separate hardware-queue pool per priority, so they
+        // never share a queue with the caller's (normal priority) stream, whose queue holds the pending joins of the batches in flight
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        {
+            const char *pe = getenv("FRT_PIPELINE_STREAM_PRIO");
+            if (pe && pe[0] == '0') prio_hi = 0;   // "0": normal priority (stage streams share the caller's queue pool)
+        }
+        auto mk = [&](hipStream_t *st) { HIPCHK(hipStreamCreateWithPriority(st, hipStreamDefault, prio_hi)); };
+        mk(&p->det_stream);
+        mk(&p->emb_stream);
+        mk(&p->emb_stream2);
         {
             const char *de = getenv("FRT_PIPELINE_DUAL_EMBED");
             p->dual_embed = !(de && de[0] == '0');
@@ -1575,7 +1592,7 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
             e->ensure_alt();
             p->d_chw2 = p->arena.alloc<float>((size_t)max_frames * d->g.max_faces * 3 * 112 * 112);
         }
-        HIPCHK(hipStreamCreate(&p->match_stream));
+        mk(&p->match_stream);
         const size_t F = (size_t)p->F_cap;
         HIPCHK(hipEventCreateWithFlags(&p->ev_serial, hipEventDisableTiming));
         for (int i = 0; i < frt_pipeline::NSLOT; ++i) {
@@ -1671,7 +1688,7 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
         HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
-        p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : p->own_stream;
+        p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : p->own_stream;  // null own_stream: created at the next run
     });
 }
 
@@ -1723,6 +1740,7 @@ int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_f
         if (!p || !frames || !results) raise(FRT_ERR_INVALID, "null argument");
         if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
         use_device(p->det->device);
+        p->ensure_stream();
         hipStream_t s = p->stream;
         const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
         // upload on the stream the detector will run on: the crop (pipeline stream) is ordered behind the detector's event
