@@ -454,8 +454,8 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvMfmaArgs p) {
 // PAIR (Cout == 64, Cin == 64): one workgroup handles TWO strips; waves (0,1) own the first, waves (2,3) the second, each wave
 // one 32-cout fragment of its strip.  Each half stages its own patch (128 threads per patch image); the whole K loop (9 taps)
 // runs on that single resident patch.
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7>  // NT pixel tiles per strip; PPS patch DMA pieces per thread per step during taps 0..PT-1
-__global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7, int BFD = 2, int WR = 3>  // WR: weight register ring depth in steps (3 or 9); NT pixel tiles per strip; PPS patch DMA pieces per thread per step during taps 0..PT-1; BFD: depth (kk-slots) of the B fragment ring
+__global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
     // linear != 0: pixel slots are enumerated over the PADDED row width (slot == patch row of tap (0,0), slots in the two halo
     // columns are dead).  The 32 lanes of a fragment read then touch 32 consecutive patch rows -> no LDS bank conflicts; the
     // image-row wrap of the compact enumeration (a 2-row skip) costs ~40 % extra LDS cycles (measured SQ_LDS_BANK_CONFLICT).
@@ -524,7 +524,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
         pbase[j] = pidx * PROW + hi * 16;
     }
 
-    half8 areg[3][4];
+    half8 areg[WR][4];
+    constexpr int LA = WR - 1;  // weight fragments are fetched LA steps ahead
     auto load_w = [&](int c, int tap, auto slot_c) {  // wave-uniform c, tap; clamped at the tail (values unused there)
         constexpr int S = decltype(slot_c)::value;
         const int woff = c < n_chunks ? tap * p.Cin + (c << 6) : 0;
@@ -553,30 +554,38 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
     issue_patch(0, std::integral_constant<int, 0>{}, std::integral_constant<int, NSLOT>{});
     load_w(0, 0, std::integral_constant<int, 0>{});
     load_w(0, 1, std::integral_constant<int, 1>{});
+    if constexpr (WR == 9) {
+        load_w(0, 2, std::integral_constant<int, 2>{});
+        load_w(0, 3, std::integral_constant<int, 3>{});
+        load_w(0, 4, std::integral_constant<int, 4>{});
+        load_w(0, 5, std::integral_constant<int, 5>{});
+        load_w(0, 6, std::integral_constant<int, 6>{});
+        load_w(0, 7, std::integral_constant<int, 7>{});
+    }
 
     // B fragment registers: two kk-deep ring that runs CONTINUOUSLY across steps.  One wave per SIMD means only this wave's own
     // instruction stream can hide LDS latency, so every MFMA is followed by exactly one ds_read that refills the register it
     // just consumed with the fragment two kk-slots ahead - in the second half of a step that is the NEXT tap's fragment (the
     // patch is resident).  sched_barrier(0) pins the order (left alone hipcc emits "2 reads, lgkmcnt(0), 1 MFMA").
-    half8 bf[2][NT];
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's patch(0) pieces have landed (younger: the 8 fragment loads)
+    half8 bf[BFD][NT];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LA) : "memory");  // this wave's patch(0) pieces have landed (younger: the 4*LA fragment loads)
     __builtin_amdgcn_s_barrier();                     // ... and everybody else's
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+    for (int k2 = 0; k2 < BFD; ++k2)
 #pragma unroll
         for (int j = 0; j < NT; ++j) bf[k2][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + k2 * 32);
 
     auto step = [&](int c, auto tap_c) {
         constexpr int TAP = decltype(tap_c)::value;
         constexpr int NTAP = (TAP + 1) % 9;
-        constexpr int AS = TAP % 3;  // register-ring slot of this step's weight fragments (9 taps = 3 x 3: compile time)
+        constexpr int AS = TAP % WR;  // register-ring slot of this step's weight fragments (9 taps = 3 x 3: compile time)
         const int pbuf = SINGLE ? 0 : (c & 1) * PATCH_B;
         const int dp = ((TAP / 3) * Wp + (TAP % 3)) * PROW + pbuf;
         const int dpn = ((NTAP / 3) * Wp + (NTAP % 3)) * PROW + (TAP == 8 ? (SINGLE ? 0 : ((c + 1) & 1) * PATCH_B) : pbuf);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int cur = kk & 1;
-            if (kk == 2 && !SINGLE && TAP == 8) {
+            const int cur = BFD == 2 ? (kk & 1) : 0;
+            if (kk == 4 - BFD && !SINGLE && TAP == 8) {
                 // chunk boundary: from here on the refills read the NEXT chunk's patch buffer.  This wave's pieces (last issued
                 // at tap PT-1; younger: the 4 fragment loads of each later step) have landed, every wave's reads of the buffer
                 // about to be recycled have returned, then everybody meets.
@@ -589,13 +598,14 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(ConvMfmaArgs p, int R, 
             for (int j = 0; j < NT; ++j) {
                 if (ABL == 2) asm volatile("" ::"v"(areg[AS][kk]), "v"(bf[cur][j]));
                 else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[AS][kk], bf[cur][j], acc[j], 0, 0, 0);
-                if (kk < 2) bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dp + (kk + 2) * 32);
-                else bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dpn + (kk - 2) * 32);
-                if (ABL != 1 && ABL != 7 && kk == 0 && j == 1) {  // weight fragments of step t+2 into the slot step t-1 used
-                    constexpr int T2 = TAP + 2;
-                    load_w(T2 < 9 ? c : c + 1, T2 % 9, std::integral_constant<int, T2 % 3>{});
+                if (ABL == 8 || ABL == 9) {
+                } else if (kk + BFD < 4) bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dp + (kk + BFD) * 32);
+                else bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dpn + (kk + BFD - 4) * 32);
+                if (ABL != 1 && ABL != 7 && ABL != 9 && kk == 0 && j == 1) {  // weight fragments of step t+2 into the slot step t-1 used
+                    constexpr int T2 = TAP + LA;
+                    load_w(T2 < 9 ? c : c + 1, T2 % 9, std::integral_constant<int, (T2 % 9) % WR>{});
                 }
-                if (ABL != 1 && ABL != 6 && kk == 1 && j == 1 && !SINGLE && TAP < PT)
+                if (ABL != 1 && ABL != 6 && ABL != 9 && kk == 1 && j == 1 && !SINGLE && TAP < PT)
                     issue_patch(c + 1, std::integral_constant<int, (TAP < PT ? TAP : 0) * PPS>{}, std::integral_constant<int, PPS>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -935,20 +945,20 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     return true;
 }
 
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7>
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7, int BFD = 2, int WR = 3>
 void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
     const size_t lds = PAIR ? (size_t)2 * 34 * 2048 : (size_t)(SINGLE ? 1 : 2) * PT * PPS * 4096;  // patch buffers only (weights live in registers)
     static_assert(PAIR || ((SINGLE ? 1 : 2) * PT * PPS * 4096 <= 160 * 1024 && PT * PPS * 4096 >= 4 * 32 * 36 * 4), "LDS budget / epilogue scratch");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     const int strips = ((a.B + n_img - 1) / n_img) * (a.H / R);
     dim3 grid(PAIR ? (strips + 1) / 2 : strips * (a.Cout / 128));
     const int linear = (n_img == 1 && R * (a.W + 2) <= NT * 32) ? 1 : 0;
-    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT>), grid, dim3(256), lds, s, a, R, n_img, linear);
+    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR>), grid, dim3(256), lds, s, a, R, n_img, linear);
 }
 
 int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage (default: 64 KB ring, 2 workgroups per CU), 3 = LDS-DMA 3-stage
@@ -984,9 +994,9 @@ static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
 
 const char *conv_kernel_label(const ConvMfmaArgs &a) {
     static const char *names[] = {"conv_mfma_kernel<2, 2>", "conv_mfma_kernel<1, 4>", "conv_glds_kernel<2, 2, 2, 0>", "conv_glds_kernel<1, 4, 2, 0>",
-                                  "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true, 7>",
-                                  "conv_patch_kernel<3, 5, 5, true, 0, false, 7>", "conv_patch_kernel<2, 5, 5, false, 0, false, 7>",
-                                  "conv_patch_kernel<2, 6, 4, false, 0, false, 7>", "conv_patch_kernel<2, 5, 5, false, 0, false, 4>"};
+                                  "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true, 7, 2, 3>",
+                                  "conv_patch_kernel<3, 5, 5, true, 0, false, 7, 2, 3>", "conv_patch_kernel<2, 5, 5, false, 0, false, 7, 1, 3>",
+                                  "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<2, 5, 5, false, 0, false, 4, 1, 3>"};
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
@@ -1006,9 +1016,17 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 2) return launch_patch_t<2, 5, 5, false, 2>(a, R, n_img, s);
             if (abl == 4) return launch_patch_t<2, 5, 5, false, 4>(a, R, n_img, s);
             if (abl == 5) return launch_patch_t<2, 5, 5, false, 5>(a, R, n_img, s);
-            return launch_patch_t<2, 5, 5, false>(a, R, n_img, s);
+            if (abl == 6) return launch_patch_t<2, 5, 5, false, 6>(a, R, n_img, s);
+            if (abl == 7) return launch_patch_t<2, 5, 5, false, 7>(a, R, n_img, s);
+            if (abl == 8) return launch_patch_t<2, 5, 5, false, 8>(a, R, n_img, s);
+            if (abl == 9) return launch_patch_t<2, 5, 5, false, 9>(a, R, n_img, s);
+            if (abl == 12) return launch_patch_t<2, 5, 5, false, 0, false, 7, 2, 9>(a, R, n_img, s);
+            if (abl == 11) return launch_patch_t<2, 5, 5, false>(a, R, n_img, s);  // two-deep B ring, one wave per SIMD
+            return launch_patch_t<2, 5, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
-        case CV_P_255_NT4: return launch_patch_t<2, 5, 5, false, 0, false, 4>(a, R, n_img, s);
+        case CV_P_255_NT4:
+            if (abl == 11) return launch_patch_t<2, 5, 5, false, 0, false, 4>(a, R, n_img, s);
+            return launch_patch_t<2, 5, 5, false, 0, false, 4, 1>(a, R, n_img, s);
         case CV_V1_22: return launch_conv_t<2, 2>(a, s);
         case CV_V1_14: return launch_conv_t<1, 4>(a, s);
         case CV_G2_22:
