@@ -71,6 +71,8 @@ ABI = {
     "frt_pipeline_destroy": (None, [_vp]),
     "frt_pipeline_run": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_pipeline_run_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "frt_pipeline_submit": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(ctypes.c_long)]),
+    "frt_pipeline_wait": (_i, [_vp, ctypes.c_long]),
     "frt_pipeline_sync": (_i, [_vp]),
     "frt_pipeline_set_stream": (_i, [_vp, _vp]),
     "frt_pipeline_set_overlap": (_i, [_vp, _i]),
@@ -422,6 +424,24 @@ class Pipeline:
         emb = np.zeros((n * self.max_faces, 512), np.float32) if want_embeds else None
         _check(lib.frt_pipeline_run(self._h, _ptr(frames), n, _ptr(res), _ptr(emb)))
         return res, emb
+
+    def submit(self, frames, results, embeds=None):
+        """Asynchronous host boundary: queue one batch (``frames`` u8 [n, H, W, 3], ``results`` a RESULT_DTYPE array of
+        n*max_faces records, optional ``embeds`` float32 [n*max_faces, 512]; all C-contiguous, ideally pinned) and return a
+        ticket for :meth:`wait`.  The arrays must stay alive and untouched until then."""
+        if not (frames.flags.c_contiguous and frames.dtype == np.uint8):
+            raise ValueError("frames must be a C-contiguous uint8 array")
+        n = frames.shape[0]
+        if results.dtype != RESULT_DTYPE or results.size < n * self.max_faces or not results.flags.c_contiguous:
+            raise ValueError("results must be a C-contiguous RESULT_DTYPE array of n*max_faces records")
+        if embeds is not None and (embeds.dtype != np.float32 or embeds.size < n * self.max_faces * 512 or not embeds.flags.c_contiguous):
+            raise ValueError("embeds must be a C-contiguous float32 [n*max_faces, 512] array")
+        t = ctypes.c_long(-1)
+        _check(lib.frt_pipeline_submit(self._h, _ptr(frames), n, _ptr(results), _ptr(embeds), ctypes.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket):
+        _check(lib.frt_pipeline_wait(self._h, int(ticket)))
 
     def run_dev(self, frames_ptr, n_frames, results_ptr, embeds_ptr=None):
         """Asynchronous; arguments are raw device addresses (e.g. ``torch.Tensor.data_ptr()``)."""

@@ -847,6 +847,34 @@ struct frt_pipeline {
     int32_t *d_idx;
     frt_face_result *d_results;
 
+    // ---- asynchronous host boundary (frt_pipeline_submit / frt_pipeline_wait): NBUF staging sets so that the H2D copy of batch
+    //      b+1 (copy_stream, the SDMA engine) and the D2H of batch b-1 run under the stages of batch b
+    static constexpr int NBUF = 4;
+    struct AsyncBuf {
+        uint8_t *d_frames = nullptr;
+        frt_face_result *d_results = nullptr;
+        float *d_embeds = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_out = nullptr;
+        long ticket = -1;  // ticket whose results ev_out guards; -1: never used
+    };
+    AsyncBuf abuf[NBUF];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_frames = nullptr;  // set by submit for the next run(): the detector stream waits for it
+    long next_ticket = 0;
+    std::mutex async_mu;
+    void ensure_async() {
+        if (copy_stream) return;
+        HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        const size_t F = (size_t)F_cap;
+        for (AsyncBuf &b : abuf) {
+            b.d_frames = arena.alloc<uint8_t>((size_t)max_frames * det->g.frame_h * det->g.frame_w * 3);
+            b.d_results = arena.alloc<frt_face_result>(F);
+            b.d_embeds = arena.alloc<float>(F * 512);
+            HIPCHK(hipEventCreateWithFlags(&b.ev_h2d, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b.ev_out, hipEventDisableTiming));
+        }
+    }
+
     // ---- hipGraph replay.  A step is ~150 dependent launches; eager dispatch costs 3.1 us per dependent kernel on this part,
     //      a graph replay 1.8 us (tools/ubench/launch_gap.hip).  Each call is two graphs - the detector part on det_stream, the
     //      rest on `stream` - so the cross-call overlap of the two streams survives; the fork/join events stay ordinary stream
@@ -949,6 +977,10 @@ struct frt_pipeline {
             // making D wait for prior work on `s` would serialise the stages.
             HIPCHK(hipStreamWaitEvent(ds, ev_done[slot], 0));
             HIPCHK(hipStreamWaitEvent(es, ev_done[slot], 0));
+        }
+        if (ev_frames) {  // frt_pipeline_submit: the frames arrive on the copy stream
+            HIPCHK(hipStreamWaitEvent(ds, ev_frames, 0));
+            ev_frames = nullptr;
         }
         const bool have_gallery = mat && mat->N > 0;
         const unsigned gen = mat ? mat->generation : 0u;
@@ -1637,6 +1669,14 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     if (p->emb_stream2) (void)hipStreamDestroy(p->emb_stream2);
     if (p->match_stream) (void)hipStreamDestroy(p->match_stream);
     if (p->ev_serial) (void)hipEventDestroy(p->ev_serial);
+    if (p->copy_stream) {
+        (void)hipStreamSynchronize(p->copy_stream);
+        (void)hipStreamDestroy(p->copy_stream);
+    }
+    for (frt_pipeline::AsyncBuf &b : p->abuf) {
+        if (b.ev_h2d) (void)hipEventDestroy(b.ev_h2d);
+        if (b.ev_out) (void)hipEventDestroy(b.ev_out);
+    }
     for (int i = 0; i < frt_pipeline::NSLOT; ++i) {
         if (p->ev_det[i]) (void)hipEventDestroy(p->ev_det[i]);
         if (p->ev_emb[i]) (void)hipEventDestroy(p->ev_emb[i]);
@@ -1751,6 +1791,49 @@ int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_f
         HIPCHK(hipMemcpyAsync(results, p->d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
         if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, p->d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_pipeline_submit(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, long *ticket_out) {
+    return guarded([&] {
+        if (!p || !frames || !results || !ticket_out) raise(FRT_ERR_INVALID, "null argument");
+        if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
+        use_device(p->det->device);
+        std::lock_guard<std::mutex> lk(p->async_mu);
+        p->ensure_stream();
+        p->ensure_async();
+        const long ticket = p->next_ticket;
+        frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
+        if (b.ticket >= 0) HIPCHK(hipEventSynchronize(b.ev_out));  // the staging set is free once its previous batch has left
+        hipStream_t s = p->stream;
+        const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
+        HIPCHK(hipMemcpyAsync(b.d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, p->copy_stream));
+        HIPCHK(hipEventRecord(b.ev_h2d, p->copy_stream));
+        p->ev_frames = b.ev_h2d;  // the stage that reads the frames first (detector) waits for the copy; the caller's stream does not
+        pipeline_lock_run(p, b.d_frames, n_frames, b.d_results, embeds_out ? b.d_embeds : nullptr);
+        const int F = n_frames * p->max_faces;
+        HIPCHK(hipMemcpyAsync(results, b.d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
+        if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, b.d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(b.ev_out, s));
+        b.ticket = ticket;
+        p->next_ticket = ticket + 1;
+        *ticket_out = ticket;
+    });
+}
+
+int frt_pipeline_wait(frt_pipeline *p, long ticket) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        use_device(p->det->device);
+        hipEvent_t ev = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(p->async_mu);
+            if (ticket < 0 || ticket >= p->next_ticket) raise(FRT_ERR_INVALID, "pipeline: unknown ticket");
+            frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
+            if (b.ticket > ticket) return;  // its staging set was reused, which submit only does after that batch completed
+            ev = b.ev_out;
+        }
+        HIPCHK(hipEventSynchronize(ev));
     });
 }
 

@@ -151,6 +151,15 @@ void frt_pipeline_destroy(frt_pipeline *p);
 /* frames: host u8 BGR, n_frames contiguous frames.  results[n_frames*max_faces]; embeds_out (may be NULL)
  * [n_frames*max_faces][512]. */
 int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out);
+/* Asynchronous form of frt_pipeline_run for callers that keep several batches in flight (the reference's shell is synchronous,
+ * app.cpp:293-352; this is the entry point a multi-threaded or double-buffered caller binds instead).  submit() queues the
+ * H2D copy of `frames` on the pipeline's copy stream, the stages, and the D2H copies of `results` / `embeds_out`, and returns a
+ * ticket; wait(ticket) blocks until that batch's outputs are in host memory.  All three host buffers must stay valid and
+ * untouched until wait() returns, and should be pinned (hipHostMalloc / hipHostRegister): with pageable memory the copies
+ * degrade to synchronous ones.  Up to 4 batches may be in flight; a 5th submit() first waits for the oldest.  Tickets complete
+ * in order.  Not to be mixed with frt_pipeline_run_dev calls in flight on the same pipeline. */
+int frt_pipeline_submit(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, long *ticket_out);
+int frt_pipeline_wait(frt_pipeline *p, long ticket);
 /* Same with everything resident in HBM: frames_dev u8 [n_frames][rows][cols][3]; results_dev / embeds_dev device
  * buffers (embeds_dev may be NULL).  Asynchronous on the pipeline stream; frt_pipeline_sync() waits. */
 int frt_pipeline_run_dev(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev);

@@ -91,6 +91,47 @@ def test_two_stream_overlap_keeps_batches_apart(frt, synth, blobs):
     rec.close()
 
 
+def test_async_host_boundary_matches_synchronous_calls(frt, synth, blobs):
+    """frt_pipeline_submit / frt_pipeline_wait with more batches than staging sets == frt_pipeline_run one call at a time."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 2, 4, 320, 320
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    rec.setGallery(synth.make_gallery(3000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    n_batches = 11                                             # > 2 rounds of the 4 staging sets, partial last batch below
+    batches = [synth.make_frames(B, H, W, start=7 * i) for i in range(n_batches)]
+    batches[-1] = batches[-1][:1]
+    want = [tuple(a.copy() for a in pipe.run(b)) for b in batches]
+    pinned = [torch.from_numpy(b).pin_memory() for b in batches]
+    res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in batches]
+    emb = [torch.zeros(B * K, 512).pin_memory() for _ in batches]
+    tickets = []
+    for i in range(n_batches):
+        r = res[i].numpy().view(frt.RESULT_DTYPE)
+        tickets.append(pipe.submit(pinned[i].numpy(), r, emb[i].numpy() if i % 2 == 0 else None))
+    assert tickets == list(range(tickets[0], tickets[0] + n_batches))
+    for i in reversed(range(n_batches)):                       # waiting out of order is allowed
+        pipe.wait(tickets[i])
+    for i in range(n_batches):
+        n = len(batches[i]) * K
+        got = res[i].numpy().view(frt.RESULT_DTYPE)[:n]
+        w_res, w_emb = want[i]
+        for k in ("x1", "y1", "x2", "y2", "frame", "match_idx", "valid"):
+            assert np.array_equal(got[k], w_res[k]), (i, k)
+        assert np.abs(got["match_sim"] - w_res["match_sim"]).max() < 1e-6
+        if i % 2 == 0:
+            assert np.abs(emb[i].numpy()[:n] - w_emb).max() < 1e-6
+    with pytest.raises(frt.FrtError):
+        pipe.wait(tickets[-1] + 1)
+    pipe.close()
+    det.close()
+    rec.close()
+
+
 def test_graph_replay_matches_eager(frt, synth, blobs):
     """Opt-in hipGraph replay: same results as eager launches, also after the frame contents / gallery change."""
     dpath, _ = blobs("det")

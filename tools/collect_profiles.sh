@@ -9,7 +9,6 @@ OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/${TAG}_pytest_gpu.log"
-python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.stderr"
 python bench.py --no-cpu-baseline --stage-profile "$OUT/${TAG}_stages.json" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_stats && mkdir -p /tmp/prof_stats
@@ -42,4 +41,7 @@ json.dump({"per_kernel": out,
                    "all launches of a kernel symbol; FETCH_SIZE doubled per MI355X_MICROARCH.md; WRITE_SIZE uncorrected (uncalibrated)"},
           open(sys.argv[1], "w"), indent=1)
 EOF
+cp "$OUT/${TAG}_pmc_hbm.json" "$ROOT/profiles/" 2>/dev/null   # bench.py reads the newest profiles/*_pmc_hbm.json for roofline.traffic
+cd "$ROOT"
+python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.stderr"
 ls -la "$OUT"
