@@ -226,7 +226,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Multi mm) {
 // planar input tensor (157 MB per 32 frames, written once and read once) need not exist: every tap is read from the u8 HWC
 // frame, converted, mean-subtracted in a register (the same fp32 value the separate kernel would have stored) and fed to
 // the same FMA chain.  Zero padding applies to the preprocessed tensor, so taps outside the frame contribute 0, not -mean.
-template <int ABL>
 __global__ __launch_bounds__(256) void det_conv1_u8_kernel(const uint8_t *__restrict__ frames, size_t row_stride, size_t frame_stride, Conv3Args a) {
     const long gp = (long)blockIdx.x * 256 + threadIdx.x;
     const int HoWo = a.Ho * a.Wo;
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(256) void det_conv1_u8_kernel(const uint8_t *__rest
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.f;
     float v[3][9];
-    if (ABL != 1 && ow * 2 + 1 < a.W) {
+    if (ow * 2 + 1 < a.W) {
         // interior columns (all but a right edge that only odd widths have): the 9 bytes of a row's three pixels as two unaligned
         // dword loads + one byte load instead of nine byte loads (the byte loads were the kernel's bottleneck: 91 -> 40 us without them)
 #pragma unroll
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(256) void det_conv1_u8_kernel(const uint8_t *__rest
                 const uint8_t *px = fb + (size_t)(ok ? ih : 0) * row_stride + (size_t)(ok ? iw : 0) * 3;
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
-                    const float raw = ABL == 1 ? (float)(ih + iw + ci) : (float)px[ci];  // unconditional load, masked afterwards
+                    const float raw = (float)px[ci];  // unconditional load, masked afterwards
                     v[ci][kh * 3 + kw] = ok ? raw - mean[ci] : 0.f;
                 }
             }
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(256) void det_conv1_u8_kernel(const uint8_t *__rest
     for (int c = 0; c < 8; ++c) {
         float o = acc[c] + a.b[c];
         if (a.relu) o = fmaxf(o, 0.f);
-        if (ABL != 2 || o == 123.456f) ob[(long)c * HoWo] = o;
+        ob[(long)c * HoWo] = o;
     }
 }
 
@@ -436,10 +435,7 @@ void launch_conv3x3(const Conv3Args &a, hipStream_t s) { launch_conv3x3_multi(&a
 bool launch_det_conv1_u8(const uint8_t *frames, size_t row_stride, size_t frame_stride, const Conv3Args &a, hipStream_t s) {
     if (a.Cin != 3 || a.Cout != 8 || a.stride != 2 || getenv("FRT_DET_NO_FUSED_INPUT")) return false;
     const long total = (long)a.B * a.Ho * a.Wo;
-    static const int abl = getenv("FRT_DET1_ABLATE") ? atoi(getenv("FRT_DET1_ABLATE")) : 0;
-    if (abl == 1) hipLaunchKernelGGL(det_conv1_u8_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, row_stride, frame_stride, a);
-    else if (abl == 2) hipLaunchKernelGGL(det_conv1_u8_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, row_stride, frame_stride, a);
-    else hipLaunchKernelGGL(det_conv1_u8_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, row_stride, frame_stride, a);
+    hipLaunchKernelGGL(det_conv1_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, row_stride, frame_stride, a);
     return true;
 }
 
