@@ -145,6 +145,119 @@ __global__ __launch_bounds__(256) void dwpw_kernel(DwPwArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- fused conv_dw block, stride 1, four output pixels of a row per thread
+// The kernel above issues 9 (exec-masked) scalar loads per pixel and input channel.  With four consecutive pixels per thread
+// a channel costs three rows x (one aligned float4 + the two neighbours) = 9 loads for FOUR pixels, all unconditional from
+// clamped addresses (zeroing deferred to a select), the next channel's nine loads are in flight while the current one is
+// consumed, and the outputs leave as float4 stores.  Same arithmetic and summation order as dwpw_kernel (bit-identical results).
+// Needs W % 4 == 0 (the 320x320 and 160x160 blocks of the 640x640 network).
+template <int CT>
+__global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
+    constexpr int REC = 12 + CT;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    for (int i = threadIdx.x; i < a.Cin * REC; i += 256) {
+        const int ci = i / REC, r = i - ci * REC;
+        float v = 0.f;
+        if (r < 9) v = a.wd[ci * 9 + r];
+        else if (r == 9) v = a.bd[ci];
+        else if (r >= 12) v = a.wp[(long)ci * a.Cout + (r - 12)];
+        wsm[i] = v;
+    }
+    __syncthreads();
+    const int W4 = a.W >> 2, HW = a.H * a.W;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (long)a.B * a.H * W4) return;
+    const int b = (int)(g / (a.H * W4)), rem = (int)(g - (long)b * (a.H * W4));
+    const int oh = rem / W4, ow0 = (rem - oh * W4) * 4;
+    const float *inb = a.in + (long)b * a.Cin * HW;
+    // rows oh-1, oh, oh+1 (clamped; rmask zeroes the ones outside), columns ow0-1 .. ow0+4 (neighbours clamped, masked)
+    int roff[3];
+    float rmask[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh - 1 + kh;
+        const bool ok = ih >= 0 && ih < a.H;
+        roff[kh] = (ok ? ih : oh) * a.W + ow0;
+        rmask[kh] = ok ? 1.f : 0.f;
+    }
+    const bool lok = ow0 > 0, rok = ow0 + 4 < a.W;
+    const int loff = lok ? -1 : 0, roff_r = rok ? 4 : 3;
+
+    float acc[4][CT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[q][c] = 0.f;
+
+    floatx4 mid[2][3];
+    float lft[2][3], rgt[2][3];
+    auto fetch = [&](int ci, int slot) {
+        const float *x = inb + (long)ci * HW;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            mid[slot][kh] = *reinterpret_cast<const floatx4 *>(x + roff[kh]);
+            lft[slot][kh] = x[roff[kh] + loff];
+            rgt[slot][kh] = x[roff[kh] + roff_r];
+        }
+    };
+    fetch(0, 0);
+    for (int ci = 0; ci < a.Cin; ci += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c_ = ci + half;
+            if (c_ >= a.Cin) break;
+            if (c_ + 1 < a.Cin) fetch(c_ + 1, half ^ 1);
+            const float *rec = wsm + c_ * REC;
+            const floatx4 w0 = *reinterpret_cast<const floatx4 *>(rec);
+            const floatx4 w1 = *reinterpret_cast<const floatx4 *>(rec + 4);
+            const floatx4 w2 = *reinterpret_cast<const floatx4 *>(rec + 8);
+            const float wt[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0]};
+            float v[3][6];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                v[kh][0] = lok ? lft[half][kh] * rmask[kh] : 0.f;
+                v[kh][1] = mid[half][kh][0] * rmask[kh];
+                v[kh][2] = mid[half][kh][1] * rmask[kh];
+                v[kh][3] = mid[half][kh][2] * rmask[kh];
+                v[kh][4] = mid[half][kh][3] * rmask[kh];
+                v[kh][5] = rok ? rgt[half][kh] * rmask[kh] : 0.f;
+            }
+            float d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float sacc = w2[1];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) sacc = fmaf(v[t / 3][q + t % 3], wt[t], sacc);
+                d[q] = fmaxf(sacc, 0.f);
+            }
+            const float *wp = rec + 12;
+#pragma unroll
+            for (int c4 = 0; c4 < CT; c4 += 4) {
+                const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + c4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q][c4] = fmaf(d[q], w[0], acc[q][c4]);
+                    acc[q][c4 + 1] = fmaf(d[q], w[1], acc[q][c4 + 1]);
+                    acc[q][c4 + 2] = fmaf(d[q], w[2], acc[q][c4 + 2]);
+                    acc[q][c4 + 3] = fmaf(d[q], w[3], acc[q][c4 + 3]);
+                }
+            }
+        }
+    }
+    float *ob = a.out + (long)b * a.Cout * HW + oh * a.W + ow0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        floatx4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[q][c] + a.bp[c];
+            if (a.relu) v = fmaxf(v, 0.f);
+            o[q] = v;
+        }
+        *reinterpret_cast<floatx4 *>(ob + (long)c * HW) = o;
+    }
+}
+
 // ---------------------------------------------------------------- depthwise 3x3 + bias + ReLU (split path), thread = (b, c, pixel)
 __global__ __launch_bounds__(256) void dw_kernel(DwPwArgs a) {
     const int HoWo = a.Ho * a.Wo;
@@ -384,6 +497,16 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
     if (!a.wd) return launch_pw(a, s);
     const long total = (long)a.B * a.Ho * a.Wo;
     const long blocks = (total + 255) / 256;
+    // stride-1 blocks whose one channel tile covers every output channel: four pixels of a row per thread
+    static const bool row4 = !(getenv("FRT_DWPW_ROW4") && getenv("FRT_DWPW_ROW4")[0] == '0');
+    if (row4 && a.stride == 1 && !a.add && a.H == a.Ho && a.W == a.Wo && a.W % 4 == 0 && (a.Cout == 16 || a.Cout == 32) && a.Cin <= 64) {
+        const long threads = (long)a.B * a.H * (a.W / 4);
+        const dim3 grid((unsigned)((threads + 255) / 256));
+        const size_t lds = (size_t)a.Cin * (12 + a.Cout) * sizeof(float);
+        if (a.Cout == 16) hipLaunchKernelGGL(dwpw_row4_kernel<16>, grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(dwpw_row4_kernel<32>, grid, dim3(256), lds, s, a);
+        return;
+    }
     // fused while one channel tile covers every output channel (no depthwise recompute) ...
     if (a.Cout <= 32 || !a.tmp) {
         if (a.Cout % 32 == 0) {
