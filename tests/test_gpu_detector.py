@@ -72,6 +72,25 @@ def test_find_face_boxes_match_oracle_pipeline(frt, orc, synth, blobs, geom):
     det.close()
 
 
+@pytest.mark.parametrize("hw", [(101, 173), (96, 160), (320, 320)])
+def test_fused_u8_first_conv_equals_the_staged_path(frt, synth, blobs, hw):
+    """findFace on a frame whose size equals the network input runs the fused u8 first conv (dword loads in the interior,
+    byte loads on an odd right edge, 4-pixel conv_dw rows when W % 4 == 0); preprocess -> doInference -> postprocessing runs the
+    separate preprocess kernel and the generic first conv.  Same arithmetic, same summation order: identical boxes and scores."""
+    h, w = hw
+    path, _ = blobs("det")
+    det = frt.RetinaFace(path, w, h, (3, h, w), 1, 8, 0.4, 0.02)
+    for seed in range(3):
+        frame = synth.make_frames(1, h, w, start=seed)[0]
+        fused = det.findFace(frame)
+        loc, conf = det.doInference(det.preprocess(frame)[None])
+        staged = det.postprocessing(loc[0], conf[0])
+        assert len(fused) == len(staged) > 0
+        for k in ("x1", "y1", "x2", "y2", "score"):
+            assert np.array_equal(fused[k], staged[k]), (hw, seed, k)
+    det.close()
+
+
 def test_batch_of_32_equals_frame_by_frame(frt, synth, blobs):
     """Size-independent property at the benchmark batch: every frame of a 32-frame call gets exactly the boxes (and head outputs)
     it gets alone - the persistent tile walks / batch indexing of the matrix-core kernels must not leak across frames."""
