@@ -773,7 +773,7 @@ struct frt_matcher {
     bool screen = false;
     ScreenScratch scr{};
     void free_screen_scratch() {
-        for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list, (void *)scr.count})
+        for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list})  // scr.count lives behind tile_flags
             if (p) (void)hipFree(p);
         scr = ScreenScratch{};
     }
@@ -795,9 +795,9 @@ struct frt_matcher {
             free_screen_scratch();
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.q16), (size_t)cap * D * sizeof(half_t)));
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tilemax), (size_t)cap * tiles * 4 * sizeof(float)));  // up to 4 coarse entries per tile
-            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_flags), tiles * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_flags), (tiles + 1) * sizeof(int)));  // [tiles] flags + the candidate count:
+            scr.count = scr.tile_flags + tiles;                                                           // one contiguous range to clear per call
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_list), tiles * sizeof(int)));
-            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.count), sizeof(int)));
         }
         q_cap = cap;
     }
@@ -1090,6 +1090,7 @@ int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int 
         d->d_conf = d->arena.alloc<float>(B * g.A * 2);
         d->d_cand = d->arena.alloc<Candidate>(B * g.A);
         d->d_cand_count = d->arena.alloc<int>(B);
+        HIPCHK(hipMemset(d->d_cand_count, 0, sizeof(int) * B));  // kept at zero between calls by nms_kernel
         d->d_nout = d->arena.alloc<int>(B);
         d->d_dead = d->arena.alloc<uint8_t>(B * g.A);
         d->d_boxes = d->arena.alloc<frt_bbox>(B * max_faces);

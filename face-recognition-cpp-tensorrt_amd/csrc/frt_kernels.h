@@ -26,7 +26,7 @@ struct ScreenScratch {
     float *tilemax;    // [F][tiles][sub], sub = 1 or 4 coarse maxima per 128-row tile
     int *tile_flags;   // [tiles]
     int *tile_list;    // [tiles]
-    int *count;        // [1]
+    int *count;        // [1], == tile_flags + tiles (cleared together)
 };
 void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int *max_norm2_bits, hipStream_t s);
 void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
@@ -50,7 +50,7 @@ struct Candidate {
     int32_t anchor;
 };
 void launch_decode(const float *loc, const float *conf, int n_frames, const DetGeom &g, Candidate *cand, int *cand_count, hipStream_t s);
-void launch_nms(const Candidate *cand, const int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
+void launch_nms(const Candidate *cand, int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
                 int *kept_anchor, hipStream_t s);
 // landmarks of the kept boxes: raw head output ldm [B][A][10] + kept anchors [B][K] -> frame coordinates (x0,y0,...,x4,y4) [B][K][10]
 void launch_landmark_decode(const float *ldm, const int *kept_anchor, const int *n_out, int n_frames, const DetGeom &g, float *out, hipStream_t s);

@@ -233,8 +233,10 @@ __global__ __launch_bounds__(64) void match_reduce_kernel(const MatchPartial *__
 //      so similarities are bitwise those of the full scan and the first-index tie rule is unchanged.  Extra tiles are harmless.
 constexpr int CBK = 64;  // halfs per k-step of the coarse kernel (128-byte rows)
 
-__global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ in, half_t *__restrict__ out, long n8) {
+// (also clears `nzero` ints at `zero`: the screened search's tile flags + candidate count, which used to be two memset launches)
+__global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ in, half_t *__restrict__ out, long n8, int *__restrict__ zero, long nzero) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nzero) zero[i] = 0;
     if (i >= n8) return;
     const floatx4 a = *reinterpret_cast<const floatx4 *>(in + i * 8), b = *reinterpret_cast<const floatx4 *>(in + i * 8 + 4);
     half8 o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
@@ -497,7 +499,7 @@ void launch_match_full(const float *gallery, int N, int D, const float *queries,
 void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int *max_norm2_bits, hipStream_t s) {
     (void)hipMemsetAsync(max_norm2_bits, 0, sizeof(int), s);
     const long n8 = (long)N * D / 8;
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, gallery, g16, n8);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, gallery, g16, n8, (int *)nullptr, 0L);
     hipLaunchKernelGGL(row_norm_max_kernel, dim3((N + 3) / 4), dim3(256), 0, s, gallery, N, D, max_norm2_bits);
 }
 
@@ -505,10 +507,10 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
                                 const ScreenScratch &w, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
                                 int row_offset, hipStream_t s) {
     const int tiles = (N + BM - 1) / BM;
-    (void)hipMemsetAsync(w.tile_flags, 0, sizeof(int) * (size_t)tiles, s);
-    (void)hipMemsetAsync(w.count, 0, sizeof(int), s);
     const long q8 = (long)F * D / 8;
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((q8 + 255) / 256)), dim3(256), 0, s, queries, w.q16, q8);
+    const long nzero = (long)tiles + 1;  // tile flags + the candidate count behind them (ScreenScratch: count == tile_flags + tiles)
+    const long n_thr = q8 > nzero ? q8 : nzero;
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, queries, w.q16, q8, w.tile_flags, nzero);
     const size_t lds = (size_t)4 * 128 * CBK * sizeof(half_t) + 4 * 128 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

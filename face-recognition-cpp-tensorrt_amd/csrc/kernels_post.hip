@@ -86,7 +86,7 @@ __global__ void decode_kernel(const float *__restrict__ loc, const float *__rest
 
 __device__ __forceinline__ bool cand_better(float s, int a, float bs, int ba) { return (s > bs) || (s == bs && a < ba); }
 
-__global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ cand_all, const int *__restrict__ cand_count, DetGeom g,
+__global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ cand_all, int *__restrict__ cand_count, DetGeom g,
                                                   uint8_t *__restrict__ dead_all, frt_bbox *__restrict__ out, int *__restrict__ n_out,
                                                   int *__restrict__ kept_anchor) {
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ 
         }
         __syncthreads();
     }
-    if (tid == 0) n_out[f] = kept;
+    if (tid == 0) {
+        n_out[f] = kept;
+        cand_count[f] = 0;  // every thread read it before the first barrier; decode_kernel of the next call counts from zero (no memset launch)
+    }
     // zero the unused slots so the results buffer is deterministic
     for (int i = kept + tid; i < g.max_faces; i += 256) {
         frt_bbox z;
@@ -184,12 +187,12 @@ __global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ 
 }  // namespace
 
 void launch_decode(const float *loc, const float *conf, int n_frames, const DetGeom &g, Candidate *cand, int *cand_count, hipStream_t s) {
-    (void)hipMemsetAsync(cand_count, 0, sizeof(int) * n_frames, s);
+    // cand_count is zero here: allocated zeroed, and nms_kernel (always launched after this kernel) resets the entries it consumed
     dim3 grid((g.A + 255) / 256, n_frames);
     hipLaunchKernelGGL(decode_kernel, grid, dim3(256), 0, s, loc, conf, g, cand, cand_count);
 }
 
-void launch_nms(const Candidate *cand, const int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
+void launch_nms(const Candidate *cand, int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
                 int *kept_anchor, hipStream_t s) {
     hipLaunchKernelGGL(nms_kernel, dim3(n_frames), dim3(256), 0, s, cand, cand_count, g, dead, out, n_out, kept_anchor);
 }
