@@ -143,7 +143,7 @@ struct frt_detector {
     void forward(int n, hipStream_t s, int first_op = 0);  // d_input -> d_loc/d_conf (first_op = 1: op 0 already ran)
     // preprocess + forward; when the letterbox is the identity the first conv reads the u8 frames and d_input is never written
     void forward_frames(const uint8_t *frames_dev, int n, size_t row_stride, size_t frame_stride, hipStream_t s);
-    void postprocess(int n, hipStream_t s);      // d_loc/d_conf -> d_boxes/d_nout
+    void postprocess(int n, hipStream_t s, frt_bbox *boxes_out = nullptr, int *nout_out = nullptr, float *landmarks_out = nullptr);  // d_loc/d_conf -> boxes (default: d_boxes/d_nout/d_landmarks)
     void preprocess(const uint8_t *frames_dev, int n, size_t row_stride, size_t frame_stride, hipStream_t s);
 };
 
@@ -451,11 +451,13 @@ void frt_detector::forward(int n, hipStream_t s, int first_op) {
     }
 }
 
-void frt_detector::postprocess(int n, hipStream_t s) {
+void frt_detector::postprocess(int n, hipStream_t s, frt_bbox *boxes_out, int *nout_out, float *landmarks_out) {
     ProfScope ps(2, "det_postprocess", (double)n * g.A, s);
+    frt_bbox *bo = boxes_out ? boxes_out : d_boxes;  // the pipeline passes its slot buffers: no device-to-device copies afterwards
+    int *no = nout_out ? nout_out : d_nout;
     launch_decode(d_loc, d_conf, n, g, d_cand, d_cand_count, s);
-    launch_nms(d_cand, d_cand_count, n, g, d_dead, d_boxes, d_nout, d_kept_anchor, s);
-    if (has_landmarks) launch_landmark_decode(d_ldm, d_kept_anchor, d_nout, n, g, d_landmarks, s);
+    launch_nms(d_cand, d_cand_count, n, g, d_dead, bo, no, d_kept_anchor, s);
+    if (has_landmarks) launch_landmark_decode(d_ldm, d_kept_anchor, no, n, g, landmarks_out ? landmarks_out : d_landmarks, s);
 }
 
 // =====================================================================================================================
@@ -986,10 +988,7 @@ struct frt_pipeline {
         const unsigned gen = mat ? mat->generation : 0u;
         run_part(GraphKey{0, frames_dev, nullptr, nullptr, n, slot, align ? 1 : 0, 0u}, ds, [&](hipStream_t st) {
             det->forward_frames(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, st);
-            det->postprocess(n, st);
-            HIPCHK(hipMemcpyAsync(slot_boxes[slot], det->d_boxes, sizeof(frt_bbox) * F, hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(slot_nout[slot], det->d_nout, sizeof(int) * n, hipMemcpyDeviceToDevice, st));
-            if (align) HIPCHK(hipMemcpyAsync(slot_landmarks[slot], det->d_landmarks, sizeof(float) * 10 * F, hipMemcpyDeviceToDevice, st));
+            det->postprocess(n, st, slot_boxes[slot], slot_nout[slot], slot_landmarks[slot]);  // straight into this call's slot
         });
         if (pipe3) {
             HIPCHK(hipEventRecord(ev_det[slot], ds));
