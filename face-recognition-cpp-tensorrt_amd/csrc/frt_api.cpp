@@ -371,8 +371,31 @@ void frt_detector::build(const frt::Blob &b) {
     add_c3_pair_levels(pyr, cat, "conv3X3", 32, 64, 0, t1, "conv5X5_1", 16, 16, 0, 64, fh, fw);  // type 3: skips the next two ops when it ran
     add_c3_levels(pyr, cat, "conv3X3", 64, 32, fh, fw, 64, 0);
     add_c3_levels(pyr, t1, "conv5X5_1", 64, 16, fh, fw, 16, 0);
-    add_c3_levels(t1, cat, "conv5X5_2", 16, 16, fh, fw, 64, 32);
-    add_c3_levels(t1, t2, "conv7X7_2", 16, 16, fh, fw, 16, 0);
+    {
+        // conv5X5_2 (-> cat[32:48]) and conv7X7_2 (-> t2) read the same 16-channel tensor: one launch with the output channels
+        // concatenated (two channel tiles of the scalar kernel, the second writing to t2); same weights, same summation order
+        Op o{};
+        o.type = 1;
+        o.n = 3;
+        for (int k = 0; k < 3; ++k) {
+            const std::string pa = "ssh" + std::to_string(k + 1) + ".conv5X5_2", pb = "ssh" + std::to_string(k + 1) + ".conv7X7_2";
+            fold_conv3(b, pa + ".0", pa + ".1", 16, 16, w, bias);
+            fold_conv3(b, pb + ".0", pb + ".1", 16, 16, w2, bias2);
+            std::vector<float> wc((size_t)16 * 9 * 32), bc(bias);
+            bc.insert(bc.end(), bias2.begin(), bias2.end());
+            for (size_t row = 0; row < (size_t)16 * 9; ++row) {
+                std::copy(w.begin() + row * 16, w.begin() + (row + 1) * 16, wc.begin() + row * 32);
+                std::copy(w2.begin() + row * 16, w2.begin() + (row + 1) * 16, wc.begin() + row * 32 + 16);
+            }
+            o.c3[k] = Conv3Args{t1[k], cat[k], arena.upload(wc), arena.upload(bc), B, 16, fh[k], fw[k], 32, fh[k], fw[k], 1, 1, 64, 32};
+            o.c3[k].out2 = t2[k];
+            o.c3[k].split = 16;
+            o.c3[k].out2_ctotal = 16;
+            o.c3[k].out2_coff = 0;
+            flops_per_frame += 2.0 * 16 * 9 * 32 * fh[k] * fw[k];
+        }
+        ops.push_back(o);
+    }
     add_c3_levels(t2, cat, "conv7x7_3", 16, 16, fh, fw, 64, 48);
     Op ho{};
     ho.type = 2;

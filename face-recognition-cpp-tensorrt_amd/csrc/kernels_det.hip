@@ -284,6 +284,8 @@ __global__ __launch_bounds__(256) void dw_kernel(DwPwArgs a) {
 
 // ---------------------------------------------------------------- dense 3x3 (pad 1) + bias (+ReLU), writes a channel slice
 // Up to 3 independent problems per launch (blockIdx.z): the pyramid levels of one SSH op.
+// (A four-pixels-per-thread variant with the weights in LDS, the recipe of dwpw_row4_kernel, measured 74 / 50 us against 54 / 32 us
+//  here on the 16-channel SSH convs: a quarter of the threads leaves about one wave per SIMD on these small maps.)
 struct Conv3Multi {
     Conv3Args p[3];
 };
@@ -324,7 +326,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Multi mm) {
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[c] = fmaf(v[t], w[t * a.Cout + c], acc[c]);
     }
-    float *ob = a.out + ((long)b * a.out_ctotal + a.out_coff + co0) * HoWo + p;
+    // channel tiles at or beyond `split` belong to the second output tensor (two convs that share their input, run as one)
+    float *ob = (a.out2 && co0 >= a.split) ? a.out2 + ((long)b * a.out2_ctotal + a.out2_coff + co0 - a.split) * HoWo + p
+                                           : a.out + ((long)b * a.out_ctotal + a.out_coff + co0) * HoWo + p;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         float v = acc[c] + a.b[co0 + c];
@@ -545,7 +549,8 @@ void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s) {
     }
     for (int i = n; i < 3; ++i) mm.p[i] = a[0];
     const unsigned gx = (unsigned)((max_total + 255) / 256);
-    if (cout % 32 == 0 && max_total >= 256L * 256)
+    const bool two_out = a[0].out2 != nullptr;  // the split must fall on a channel-tile boundary: 16-channel tiles
+    if (cout % 32 == 0 && max_total >= 256L * 256 && !(two_out && a[0].split % 32))
         hipLaunchKernelGGL((conv3x3_kernel<32>), dim3(gx, cout / 32, n), dim3(256), 0, s, mm);
     else if (cout % 16 == 0)
         hipLaunchKernelGGL((conv3x3_kernel<16>), dim3(gx, cout / 16, n), dim3(256), 0, s, mm);
