@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long g = (long)tile * 128 + ld_row + 32 * i;
-            ga[i] = g < N ? *reinterpret_cast<const half8 *>(G + g * D + k0 + ld_ch * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+            // streamed once per call: non-temporal, so that the 1 GB scan does not push the recogniser's activations out of L2 / MALL
+            ga[i] = g < N ? __builtin_nontemporal_load(reinterpret_cast<const half8 *>(G + g * D + k0 + ld_ch * 8)) : half8{0, 0, 0, 0, 0, 0, 0, 0};
             const int q = q0 + ld_row + 32 * i;
             qa[i] = q < F ? *reinterpret_cast<const half8 *>(Q + (long)q * D + k0 + ld_ch * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
         }
