@@ -1635,6 +1635,10 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
             const char *pe = getenv("FRT_PIPELINE_STREAM_PRIO");
             if (pe && pe[0] == '0') prio_hi = 0;   // "0": normal priority (stage streams share the caller's queue pool)
         }
+        // hipStreamDefault (blocking), not hipStreamNonBlocking: a gallery reload between calls (hipFree / hipMalloc / synchronous
+        // hipMemcpy on the legacy default stream) is then ordered against the stages still in flight without the caller
+        // synchronising anything (tests/test_gpu_pipeline.py::test_gallery_reload_between_pipelined_calls); non-blocking
+        // streams also measured 1 % slower
         auto mk = [&](hipStream_t *st) { HIPCHK(hipStreamCreateWithPriority(st, hipStreamDefault, prio_hi)); };
         mk(&p->det_stream);
         mk(&p->emb_stream);

@@ -132,6 +132,48 @@ def test_async_host_boundary_matches_synchronous_calls(frt, synth, blobs):
     rec.close()
 
 
+def test_gallery_reload_between_pipelined_calls(frt, synth, blobs):
+    """/reload while calls are in flight (app.cpp:354-365 re-runs initKnownEmbeds + addEmbedding + initMatMul): calls submitted
+    before the reload answer from the old gallery, calls after it from the new one (different size, so the scratch moves)."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 2, 4, 320, 320
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    g_old, g_new = synth.make_gallery(3000), synth.make_gallery(70000)[::-1].copy()
+    batches = [synth.make_frames(B, H, W, start=5 * i) for i in range(4)]
+    pipe = frt.Pipeline(det, rec, B)
+    want = {}
+    for tag, gal in (("old", g_old), ("new", g_new)):
+        rec.setGallery(gal)
+        rec.initMatMul()
+        want[tag] = [pipe.run(b)[0].copy() for b in batches]
+    assert any(not np.array_equal(a["match_idx"], b["match_idx"]) for a, b in zip(want["old"], want["new"]))
+    d_frames = [torch.from_numpy(b).cuda() for b in batches]
+    d_res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    pipe.set_stream(torch.cuda.current_stream().cuda_stream)
+    rec.setGallery(g_old)
+    rec.initMatMul()
+    for i in range(4):
+        pipe.run_dev(d_frames[i].data_ptr(), B, d_res[i].data_ptr(), None)
+    rec.setGallery(g_new)      # no explicit synchronisation by the caller
+    rec.initMatMul()
+    for i in range(4):
+        pipe.run_dev(d_frames[i].data_ptr(), B, d_res[4 + i].data_ptr(), None)
+    torch.cuda.synchronize()
+    for i in range(8):
+        got = np.frombuffer(d_res[i].cpu().numpy().tobytes(), frt.RESULT_DTYPE)
+        w = want["old" if i < 4 else "new"][i % 4]
+        for k in ("x1", "y1", "x2", "y2", "match_idx", "valid"):
+            assert np.array_equal(got[k], w[k]), (i, k)
+        assert np.abs(got["match_sim"] - w["match_sim"]).max() < 1e-6
+    pipe.set_stream(None)
+    pipe.close()
+    det.close()
+    rec.close()
+
+
 def test_graph_replay_matches_eager(frt, synth, blobs):
     """Opt-in hipGraph replay: same results as eager launches, also after the frame contents / gallery change."""
     dpath, _ = blobs("det")
