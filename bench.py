@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--faces", type=int, default=4, help="det_maxFacesPerScene (K)")
     ap.add_argument("--gallery", type=int, default=1_000_000)
+    ap.add_argument("--frame", default="640x640", help="frame size WxH (default 640x640 = the metric; 1920x1080 = BASELINE config 3's "
+                                                       "video frames, letterboxed to the 640x640 detector input). Implies --no-cpu-baseline when not 640x640")
     ap.add_argument("--mode", default="ir", choices=["ir", "ir_se"], help="IR-50 (the reference's network) or IR-SE-50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-every-step", action="store_true",
@@ -101,20 +103,23 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     s = frt.synth
-    B, K, H, W = args.batch, args.faces, 640, 640
+    B, K, H, W = args.batch, args.faces, 640, 640   # detector input
+    FW, FH = (int(v) for v in args.frame.lower().split("x"))
+    if (FW, FH) != (W, H):
+        args.no_cpu_baseline = True
     tmp = tempfile.mkdtemp(prefix="frt_bench_%d_" % rank)
     det_sd = s.retinaface_state(1)
     rec_sd = s.arcface_state(2, args.mode, calib=s.load_calibration(args.mode))
     det_path = frt.write_weights(os.path.join(tmp, "det.frtw"), det_sd, 1)
     rec_path = frt.write_weights(os.path.join(tmp, "rec.frtw"), rec_sd, 2 if args.mode == "ir" else 3)
-    det = frt.RetinaFace(det_path, W, H, (3, H, W), B, K, 0.4, 0.6, device=local_rank)
-    rec = frt.ArcFaceIR50(rec_path, W, H, (3, 112, 112), 512, B * K, K, 0.65, device=local_rank)
+    det = frt.RetinaFace(det_path, FW, FH, (3, H, W), B, K, 0.4, 0.6, device=local_rank)
+    rec = frt.ArcFaceIR50(rec_path, FW, FH, (3, 112, 112), 512, B * K, K, 0.65, device=local_rank)
     gallery = s.make_gallery(args.gallery)
     rec.setGallery(gallery)  # bulk initKnownEmbeds + addEmbedding x N (2 GB: no per-row copies)
     rec.initMatMul()
     pipe = frt.Pipeline(det, rec, B)
 
-    frames = s.make_frames(B, H, W, start=rank * B)  # weak scaling: every rank has its own 32 frames
+    frames = s.make_frames(B, FH, FW, start=rank * B)  # weak scaling: every rank has its own 32 frames
     d_frames = torch.from_numpy(frames).cuda()
     F = B * K
     d_res = torch.zeros(F * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
@@ -288,8 +293,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f16 MFMA recogniser convs (fp32 accumulate) + fp32-accurate detector (fp32 MFMA, fp16 hi/lo-split MFMA for the 64-channel 3x3 convs) + f32 MFMA match",
             "data": "synthetic",
-            "config": {"workload": "640x640 batch=%d frames/GPU, K=%d faces/frame, %dx512 fp32 gallery replicated per GPU, "
-                                   "RetinaFace-mnet0.25 + ArcFace %s" % (B, K, args.gallery, "IR-50" if args.mode == "ir" else "IR-SE-50"),
+            "config": {"workload": "%dx%d frames (640x640 detector input) batch=%d frames/GPU, K=%d faces/frame, %dx512 fp32 gallery replicated per GPU, "
+                                   "RetinaFace-mnet0.25 + ArcFace %s" % (FW, FH, B, K, args.gallery, "IR-50" if args.mode == "ir" else "IR-SE-50"),
                        "frames_per_step_per_gpu": B, "faces_per_frame": K, "faces_per_step": total_faces_per_step,
                        "gallery_rows": args.gallery, "parallelism": "frames sharded dp%d, no data-path collective, RCCL all-gather of results after the timed region" % world},
             "roofline": roofline,
