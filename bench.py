@@ -64,8 +64,8 @@ def cpu_baseline(frt, det_sd, rec_sd, gallery, frames, K, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--faces", type=int, default=4, help="det_maxFacesPerScene (K)")
     ap.add_argument("--gallery", type=int, default=1_000_000)
