@@ -832,22 +832,16 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const half_t *__restrict__
         partial[((long)part * F + f) * C + c] = t;
     }
 }
-__global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ pool, const float *__restrict__ w1, const float *__restrict__ w2,
-                                                      int C, int F, int HW, float *__restrict__ gate) {
-    // one block per face
-    extern __shared__ float sh[];  // [C] pooled + [C/16] hidden
-    const int f = blockIdx.x, R = C / 16;
-    float *sp = sh, *shid = sh + C;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float t = 0.f;
-        for (int part = 0; part < SE_SPLIT; ++part) t += pool[((long)part * F + f) * C + c];
-        sp[c] = t / (float)HW;
-    }
-    __syncthreads();
-    for (int h = threadIdx.x; h < R; h += 256) {
+// fc1 -> ReLU -> fc2 -> sigmoid on the pooled vector sp[C] (LDS): a wave per hidden unit (lanes stride over the channels, shuffle
+// reduction in a fixed order), then a thread per output channel
+__device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const float *__restrict__ w1, const float *__restrict__ w2, int C, int f,
+                                           float *__restrict__ gate) {
+    const int R = C / 16, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int h = wave; h < R; h += 4) {
         float a = 0.f;
-        for (int c = 0; c < C; ++c) a = fmaf(w1[(long)h * C + c], sp[c], a);
-        shid[h] = fmaxf(a, 0.f);
+        for (int c = lane; c < C; c += 64) a = fmaf(w1[(long)h * C + c], sp[c], a);
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        if (lane == 0) shid[h] = fmaxf(a, 0.f);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -856,6 +850,21 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ 
         gate[(long)f * C + c] = 1.f / (1.f + expf(-a));
     }
 }
+__global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ pool, const float *__restrict__ w1, const float *__restrict__ w2,
+                                                      int C, int F, int HW, float *__restrict__ gate) {
+    // one block per face
+    extern __shared__ float sh[];  // [C] pooled + [C/16] hidden
+    const int f = blockIdx.x;
+    float *sp = sh, *shid = sh + C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int part = 0; part < SE_SPLIT; ++part) t += pool[((long)part * F + f) * C + c];
+        sp[c] = t / (float)HW;
+    }
+    __syncthreads();
+    se_fc_gate(sp, shid, w1, w2, C, f, gate);
+}
+// (pool + gate fused into one block per face measured 18.6 us against 6.0 + 5.0 us: 128 blocks walking 100 KB each are latency-bound)
 __global__ __launch_bounds__(256) void se_apply_kernel(SeArgs a) {
     // thread = 8 channels of one pixel
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
