@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     constexpr int LA = WR - 1;  // weight fragments are fetched LA steps ahead
     auto load_w = [&](int c, int tap, auto slot_c) {  // wave-uniform c, tap; clamped at the tail (values unused there)
         constexpr int S = decltype(slot_c)::value;
-        const int woff = c < n_chunks ? tap * p.Cin + (c << 6) : 0;
+        const int woff = (ABL == 13) ? 0 : (c < n_chunks ? tap * p.Cin + (c << 6) : 0);  // 13: every step re-reads the same fragments (cache hits)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) areg[S][kk] = *reinterpret_cast<const half8 *>(wrow + woff + kk * 16);
     };
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
         char *pl = patch + (SINGLE ? 0 : (c & 1) * PATCH_B) + (PAIR ? (wave & 1) : wave) * 1024;
 #pragma unroll
         for (int q = Q0; q < Q0 + NQ; ++q) {
-            const half_t *src = (real && poff[q] >= 0) ? p.x + (unsigned)(poff[q] + (c << 6)) : p.zeros;
+            const half_t *src = (ABL != 14 && real && poff[q] >= 0) ? p.x + (unsigned)(poff[q] + (c << 6)) : p.zeros;  // 14: all pieces from the zero buffer
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(pl + q * (PAIR ? 2048 : 4096)), 16, 0, 0);
         }
@@ -563,6 +563,8 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
         load_w(0, 7, std::integral_constant<int, 7>{});
     }
 
+    // (An L2 warm-up - every workgroup of an XCD pulling a different slice of the cout tile's weights through L2 at kernel start,
+    //  LDS-DMA into the still unused second patch buffer - measured 45.1 us against 44.4 us without: not kept.)
     // B fragment registers: two kk-deep ring that runs CONTINUOUSLY across steps.  One wave per SIMD means only this wave's own
     // instruction stream can hide LDS latency, so every MFMA is followed by exactly one ds_read that refills the register it
     // just consumed with the fragment two kk-slots ahead - in the second half of a step that is the NEXT tap's fragment (the
@@ -1029,6 +1031,9 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 7) return launch_patch_t<2, 5, 5, false, 7>(a, R, n_img, s);
             if (abl == 8) return launch_patch_t<2, 5, 5, false, 8>(a, R, n_img, s);
             if (abl == 9) return launch_patch_t<2, 5, 5, false, 9>(a, R, n_img, s);
+            if (abl == 13) return launch_patch_t<2, 5, 5, false, 13, false, 7, 1>(a, R, n_img, s);
+            if (abl == 14) return launch_patch_t<2, 5, 5, false, 14, false, 7, 1>(a, R, n_img, s);
+            if (abl == 15) return launch_patch_t<2, 5, 5, false, 1, false, 7, 1>(a, R, n_img, s);
             if (abl == 12) return launch_patch_t<2, 5, 5, false, 0, false, 7, 2, 9>(a, R, n_img, s);
             if (abl == 11) return launch_patch_t<2, 5, 5, false>(a, R, n_img, s);  // two-deep B ring, one wave per SIMD
             return launch_patch_t<2, 5, 5, false, 0, false, 7, 1>(a, R, n_img, s);
