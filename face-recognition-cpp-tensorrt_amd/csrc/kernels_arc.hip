@@ -1006,8 +1006,8 @@ static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
 const char *conv_kernel_label(const ConvMfmaArgs &a) {
     static const char *names[] = {"conv_mfma_kernel<2, 2>", "conv_mfma_kernel<1, 4>", "conv_glds_kernel<2, 2, 2, 0>", "conv_glds_kernel<1, 4, 2, 0>",
                                   "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true, 7, 2, 3>",
-                                  "conv_patch_kernel<3, 5, 5, true, 0, false, 7, 2, 3>", "conv_patch_kernel<2, 5, 5, false, 0, false, 7, 1, 3>",
-                                  "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<2, 5, 5, false, 0, false, 4, 1, 3>"};
+                                  "conv_patch_kernel<3, 5, 5, true, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 7, 1, 3>",
+                                  "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3>"};
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
@@ -1031,16 +1031,19 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 7) return launch_patch_t<2, 5, 5, false, 7>(a, R, n_img, s);
             if (abl == 8) return launch_patch_t<2, 5, 5, false, 8>(a, R, n_img, s);
             if (abl == 9) return launch_patch_t<2, 5, 5, false, 9>(a, R, n_img, s);
+            if (abl == 18) return launch_patch_t<5, 2, 5, false, 0, false, 7, 1>(a, R, n_img, s);
             if (abl == 13) return launch_patch_t<2, 5, 5, false, 13, false, 7, 1>(a, R, n_img, s);
             if (abl == 14) return launch_patch_t<2, 5, 5, false, 14, false, 7, 1>(a, R, n_img, s);
             if (abl == 15) return launch_patch_t<2, 5, 5, false, 1, false, 7, 1>(a, R, n_img, s);
             if (abl == 12) return launch_patch_t<2, 5, 5, false, 0, false, 7, 2, 9>(a, R, n_img, s);
             if (abl == 11) return launch_patch_t<2, 5, 5, false>(a, R, n_img, s);  // two-deep B ring, one wave per SIMD
-            return launch_patch_t<2, 5, 5, false, 0, false, 7, 1>(a, R, n_img, s);
+            if (abl == 19) return launch_patch_t<2, 5, 5, false, 0, false, 7, 1>(a, R, n_img, s);  // patch pieces spread over taps 0-4
+            return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
         case CV_P_255_NT4:
             if (abl == 11) return launch_patch_t<2, 5, 5, false, 0, false, 4>(a, R, n_img, s);
-            return launch_patch_t<2, 5, 5, false, 0, false, 4, 1>(a, R, n_img, s);
+            if (abl == 19) return launch_patch_t<2, 5, 5, false, 0, false, 4, 1>(a, R, n_img, s);
+            return launch_patch_t<10, 1, 5, false, 0, false, 4, 1>(a, R, n_img, s);
         case CV_V1_22: return launch_conv_t<2, 2>(a, s);
         case CV_V1_14: return launch_conv_t<1, 4>(a, s);
         case CV_G2_22:
