@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvMfmaArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
             *reinterpret_cast<half8 *>(p.out0 + (long)m * p.Cout + c) = o;
-            if (p.mode == EPI_BN_ADD_BN && p.out1) {
+            if (p.mode == EPI_BN_ADD_BN && p.out1 && ABL != 20) {  // 20 (measurement): what would dropping the BN'd copy save?
                 half8 z;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) z[e] = (half_t)(v[e] * q2[e >> 2][e & 3] + q3[e >> 2][e & 3]);
@@ -1038,6 +1038,10 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 12) return launch_patch_t<2, 5, 5, false, 0, false, 7, 2, 9>(a, R, n_img, s);
             if (abl == 11) return launch_patch_t<2, 5, 5, false>(a, R, n_img, s);  // two-deep B ring, one wave per SIMD
             if (abl == 19) return launch_patch_t<2, 5, 5, false, 0, false, 7, 1>(a, R, n_img, s);  // patch pieces spread over taps 0-4
+            if (abl == 20) return launch_patch_t<10, 1, 5, false, 20, false, 7, 1>(a, R, n_img, s);
+            if (abl == 22) return launch_patch_t<10, 1, 5, false, 2, false, 7, 1>(a, R, n_img, s);
+            if (abl == 24) return launch_patch_t<10, 1, 5, false, 4, false, 7, 1>(a, R, n_img, s);
+            if (abl == 29) return launch_patch_t<10, 1, 5, false, 9, false, 7, 1>(a, R, n_img, s);
             return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
         case CV_P_255_NT4:
