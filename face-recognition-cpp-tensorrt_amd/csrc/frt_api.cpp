@@ -203,6 +203,25 @@ std::vector<uint16_t> pack_conv3_split(const std::vector<float> &w, int cin, int
                 }
     return o;
 }
+// pointwise weights [Cin][Cout] fp32 -> fp16 hi/lo split [Cout][Cin/16][hi16 | lo16] (dwpw_mfma_kernel / pw_mfma_kernel); empty unless Cin % 16 == 0
+std::vector<uint16_t> pack_pw_split(const std::vector<float> &w, int cin, int cout) {
+    if (cin % 16) return {};
+    auto h2f = [](uint16_t h) {
+        const uint32_t sgn = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 31, m = h & 1023;
+        const float f = e == 0 ? std::ldexp((float)m, -24) : std::ldexp((float)(m | 1024), (int)e - 25);
+        return sgn ? -f : f;
+    };
+    std::vector<uint16_t> o((size_t)cout * cin * 2, 0);
+    for (int co = 0; co < cout; ++co)
+        for (int k = 0; k < cin; ++k) {
+            const float x = w[(size_t)k * cout + co];
+            const uint16_t hi = frt::f32_to_f16(x);
+            const size_t row = ((size_t)co * (cin / 16) + k / 16) * 32;
+            o[row + k % 16] = hi;
+            o[row + 16 + k % 16] = frt::f32_to_f16(x - h2f(hi));
+        }
+    return o;
+}
 // [Cin][9][Cout] -> matrix-core layout [9][Cin/kc][cpad][kc] (kernels_det_conv3.hip); empty when the shape is not covered
 std::vector<float> pack_conv3_mfma(const std::vector<float> &w, int cin, int cout, int &kc, int &cpad) {
     kc = cin == 16 ? 16 : 32;
@@ -321,7 +340,11 @@ void frt_detector::build(const frt::Blob &b) {
                     w12[(size_t)ci * 12 + 9] = bias[ci];
                 }
                 o.dw = DwPwArgs{cur, out, arena.upload(w), arena.upload(bias), arena.upload(w2), arena.upload(bias2), nullptr, 0, 0,
-                                B, l.cin, ch, cw, l.cout, oh, ow, l.stride, 1, d_tmp, arena.upload(w12)};
+                                B, l.cin, ch, cw, l.cout, oh, ow, l.stride, 1, d_tmp, arena.upload(w12), nullptr};
+                {
+                    const std::vector<uint16_t> ph = pack_pw_split(w2, l.cin, l.cout);
+                    if (!ph.empty()) o.dw.wph = reinterpret_cast<const half_t *>(arena.upload(ph));
+                }
                 ops.push_back(o);
                 flops_per_frame += 2.0 * oh * ow * (9.0 * l.cin + (double)l.cin * l.cout);
             }
@@ -346,7 +369,11 @@ void frt_detector::build(const frt::Blob &b) {
         Op o{};
         o.type = 0;
         o.dw = DwPwArgs{feat[k], lat[k], nullptr, nullptr, arena.upload(w2), arena.upload(bias2), addsrc, ah, aw,
-                        B, cins[k], fh[k], fw[k], 64, fh[k], fw[k], 1, 1, nullptr};
+                        B, cins[k], fh[k], fw[k], 64, fh[k], fw[k], 1, 1, nullptr, nullptr, nullptr};
+        {
+            const std::vector<uint16_t> ph = pack_pw_split(w2, cins[k], 64);
+            if (!ph.empty()) o.dw.wph = reinterpret_cast<const half_t *>(arena.upload(ph));
+        }
         ops.push_back(o);
         flops_per_frame += 2.0 * fh[k] * fw[k] * cins[k] * 64;
     };

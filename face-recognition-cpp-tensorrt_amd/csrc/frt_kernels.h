@@ -82,6 +82,7 @@ struct DwPwArgs {
     int B, Cin, H, W, Cout, Ho, Wo, stride, relu;
     float *tmp;             // scratch [B][Cin][Ho][Wo] for the split depthwise -> pointwise path (null: always fused)
     const float *wd12;      // depthwise weights packed [Cin][12] = 9 taps, bias, 2 pad (matrix-core kernel); null: scalar kernels only
+    const half_t *wph;      // pointwise weights as fp16 hi/lo split [Cout][Cin/16][hi16 | lo16] (Cin % 16 == 0); null: fp32 MFMA path
 };
 void launch_dwpw(const DwPwArgs &a, hipStream_t s);
 bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s);  // false: shape not covered, use the scalar kernels

@@ -65,7 +65,10 @@ __device__ __forceinline__ int xcd_logical_tile(int nblocks) {
     return (xcd < brem ? xcd * (bq + 1) : brem * (bq + 1) + (xcd - brem) * bq) + slot;
 }
 
-template <int NPW, int NCW, int KC, int CBW, int STRIDE, bool MODE2D>
+// SPLIT: the pointwise product runs on the fp16 matrix cores at fp32 accuracy (x = hi + lo, three v_mfma_f32_32x32x16_f16 per 16
+// channels = 96 matrix-pipe clocks against 512 for v_mfma_f32_32x32x2f32; same idea and error analysis as kernels_det_conv3h.hip):
+// the depthwise stage stores its output split into LDS rows [pixel][KC hi | KC lo | pad], weights come pre-split from the host.
+template <int NPW, int NCW, int KC, int CBW, int STRIDE, bool MODE2D, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, int tiles_x, int tiles_y) {
     constexpr int T = 64 * NPW * NCW;       // threads
     constexpr int TP = 32 * NPW;            // pixels per workgroup tile
@@ -80,6 +83,8 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
     // Staging them in LDS first cost every workgroup a load -> store -> barrier phase (~2 us of a ~13 us workgroup lifetime).
     const float *wsm = a.wd12;
     float *buf = smem;                       // [2][KC][TP]
+    constexpr int ROWH = 2 * KC + 8;         // SPLIT: halves per pixel row (80 / 144 bytes: conflict-free ds_read_b128)
+    half_t *hbuf = reinterpret_cast<half_t *>(smem);  // SPLIT: [2][TP][ROWH]
 
     const int lid = xcd_logical_tile(gridDim.x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -138,7 +143,17 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
-            *reinterpret_cast<floatx4 *>(dst + cl * TP + seg * 4) = o;
+            if (SPLIT) {
+                half_t *hd = reinterpret_cast<half_t *>(dst);  // dst = this chunk's buffer (byte offset chosen by the caller)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const half_t xh = (half_t)o[j];
+                    hd[(seg * 4 + j) * ROWH + cl] = xh;
+                    hd[(seg * 4 + j) * ROWH + KC + cl] = (half_t)(o[j] - (float)xh);
+                }
+            } else {
+                *reinterpret_cast<floatx4 *>(dst + cl * TP + seg * 4) = o;
+            }
         }
     };
 
@@ -149,6 +164,58 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
     const int co_base = ((int)blockIdx.y * NCW + wc) * CBW * 32;  // blockIdx.y: output-channel group (depthwise part recomputed per group)
+    const int nchunk = a.Cin / KC;
+    if constexpr (SPLIT) {
+        constexpr int KK = KC / 16;
+        half8 ah[KK][CBW], al[KK][CBW], ahn[KK][CBW], aln[KK][CBW];
+        auto load_weights_h = [&](int c0, half8 (&dh)[KK][CBW], half8 (&dl)[KK][CBW]) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) {
+                    const int co = co_base + cb * 32 + r;
+                    const half_t *row = a.wph + ((long)(co < a.Cout ? co : 0) * (a.Cin / 16) + (c0 / 16 + kk)) * 32 + 8 * hi;
+                    dh[kk][cb] = *reinterpret_cast<const half8 *>(row);
+                    dl[kk][cb] = *reinterpret_cast<const half8 *>(row + 16);
+                    if (co >= a.Cout) {
+                        dh[kk][cb] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                        dl[kk][cb] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                }
+        };
+        auto hb = [&](int c) { return reinterpret_cast<float *>(hbuf + (c & 1) * TP * ROWH); };
+        load_weights_h(0, ah, al);
+        depthwise_chunk(0, hb(0));
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            const half_t *cur = hbuf + (c & 1) * TP * ROWH + (wp * 32 + r) * ROWH + 8 * hi;
+            if (c + 1 < nchunk) {
+                load_weights_h((c + 1) * KC, ahn, aln);
+                depthwise_chunk((c + 1) * KC, hb(c + 1));
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const half8 bh = *reinterpret_cast<const half8 *>(cur + kk * 16);
+                const half8 bl = *reinterpret_cast<const half8 *>(cur + KC + kk * 16);
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) {
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][cb], bh, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][cb], bl, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk][cb], bh, acc[cb], 0, 0, 0);
+                }
+            }
+            if (c + 1 < nchunk) {
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int cb = 0; cb < CBW; ++cb) {
+                        ah[kk][cb] = ahn[kk][cb];
+                        al[kk][cb] = aln[kk][cb];
+                    }
+            }
+            __syncthreads();
+        }
+    } else {
     float areg[KS][CBW], anext[KS][CBW];
     auto load_weights = [&](int c0, float (&dst)[KS][CBW]) {
 #pragma unroll
@@ -160,7 +227,6 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
             }
     };
 
-    const int nchunk = a.Cin / KC;
     load_weights(0, areg);
     depthwise_chunk(0, buf);
     __syncthreads();
@@ -184,6 +250,7 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
         }
         __syncthreads();
     }
+    }
 
     // ---- epilogue: lane (r, hi) owns pixel r and channels cb*32 + (e&3) + 8*(e>>2) + 4*hi
     const PixMap mo = map_pixel<MODE2D, TP>(lid, wp * 32 + r, a.B, a.Ho, a.Wo, tiles_x, tiles_y);
@@ -204,7 +271,7 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
 }
 
 // ---------------------------------------------------------------- plain 1x1 conv, one wave = 32 pixels x CBW*32 output channels
-template <int CBW>
+template <int CBW, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_groups) {
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave id
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
@@ -226,6 +293,56 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
 
+    if constexpr (SPLIT) {
+        // fp16 hi/lo split (see dwpw_mfma_kernel): per 16 input channels a lane fetches its 8 channel values of the pixel (the same
+        // 8 scalar loads the fp32 path spends on 8 k-steps), splits them, and three fp16 MFMAs replace eight fp32 ones
+        const float *xs = a.in + (long)b * a.Cin * HW + p + (long)(8 * hi) * HW;
+        const int ngroups = a.Cin / 16;
+        float bxs[8], nbx[8];
+        half8 ah[CBW], al[CBW], nah[CBW], nal[CBW];
+        auto load_g = [&](int g, float (&bxv)[8], half8 (&dh)[CBW], half8 (&dl)[CBW]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bxv[e] = (ok && g < ngroups) ? xs[(long)(16 * g + e) * HW] : 0.f;
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                const int co = co_base + cb * 32 + r;
+                const bool wok = g < ngroups && co < a.Cout;
+                const half_t *row = a.wph + ((long)(wok ? co : 0) * ngroups + (wok ? g : 0)) * 32 + 8 * hi;
+                dh[cb] = *reinterpret_cast<const half8 *>(row);
+                dl[cb] = *reinterpret_cast<const half8 *>(row + 16);
+                if (!wok) {
+                    dh[cb] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    dl[cb] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+        };
+        load_g(0, bxs, ah, al);
+        for (int g = 0; g < ngroups; ++g) {
+            if (g + 1 < ngroups) load_g(g + 1, nbx, nah, nal);
+            half8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const half_t xh = (half_t)bxs[e];
+                bh[e] = xh;
+                bl[e] = (half_t)(bxs[e] - (float)xh);
+            }
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bh, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh, acc[cb], 0, 0, 0);
+            }
+            if (g + 1 < ngroups) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bxs[e] = nbx[e];
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) {
+                    ah[cb] = nah[cb];
+                    al[cb] = nal[cb];
+                }
+            }
+        }
+    } else {
     constexpr int U = 8;  // k-steps in flight
     const int ksteps = a.Cin / 2;
     float bx[U], aw[U][CBW];
@@ -253,6 +370,7 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(caw[u][cb], cbx[u], acc[cb], 0, 0, 0);
+    }
     }
 
     if (!ok) return;
@@ -295,9 +413,20 @@ void launch_fused(const DwPwArgs &a, hipStream_t s) {
     } else {
         nblocks = ((long)a.B * a.Ho * a.Wo + TP - 1) / TP;
     }
-    const size_t lds = (2 * (size_t)KC * TP) * sizeof(float);
     const unsigned cgroups = (unsigned)((a.Cout + 32 * NCW * CBW - 1) / (32 * NCW * CBW));
     const dim3 grid((unsigned)nblocks, cgroups);
+    static const bool split = !(getenv("FRT_DET_PW_SPLIT") && getenv("FRT_DET_PW_SPLIT")[0] == '0');
+    if constexpr (KC == 32) {  // (the 16-channel block with 128-pixel tiles measured slower split: 113 vs 108 us, scattered 2-byte LDS stores)
+        if (split && a.wph) {  // pointwise product on the fp16 matrix cores (hi/lo split, fp32-class accuracy)
+            const size_t ldsh = (size_t)2 * TP * (2 * KC + 8) * sizeof(half_t);
+            if (a.stride == 1)
+                hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 1, MODE2D, true>), grid, dim3(64 * NPW * NCW), ldsh, s, a, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 2, MODE2D, true>), grid, dim3(64 * NPW * NCW), ldsh, s, a, tiles_x, tiles_y);
+            return;
+        }
+    }
+    const size_t lds = (2 * (size_t)KC * TP) * sizeof(float);
     if (a.stride == 1)
         hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 1, MODE2D>), grid, dim3(64 * NPW * NCW), lds, s, a, tiles_x, tiles_y);
     else
@@ -319,6 +448,12 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
         const int n_cgroups = (a.Cout + cbw * 32 - 1) / (cbw * 32);
         const long waves = (long)n_pix_groups * n_cgroups;
         const unsigned grid = (unsigned)((waves + 3) / 4);
+        static const bool split = !(getenv("FRT_DET_PW_SPLIT") && getenv("FRT_DET_PW_SPLIT")[0] == '0');
+        if (split && a.wph && a.Cin % 16 == 0) {
+            if (wide) hipLaunchKernelGGL((pw_mfma_kernel<2, true>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
+            else hipLaunchKernelGGL((pw_mfma_kernel<1, true>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
+            return true;
+        }
         if (wide) hipLaunchKernelGGL((pw_mfma_kernel<2>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
         else hipLaunchKernelGGL((pw_mfma_kernel<1>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
         return true;
