@@ -64,6 +64,12 @@ ABI = {
     "frt_matcher_destroy": (None, [_vp]),
     "frt_matcher_init": (_i, [_vp, _vp, _i, _i]),
     "frt_matcher_set_row_offset": (_i, [_vp, _i]),
+    "frt_matcher_set_storage": (_i, [_vp, _i]),
+    "frt_matcher_gallery_begin": (_i, [_vp, _i, _i]),
+    "frt_matcher_gallery_append": (_i, [_vp, _vp, _i]),
+    "frt_matcher_gallery_commit": (_i, [_vp]),
+    "frt_matcher_num_rows": (_i, [_vp]),
+    "frt_matcher_top1_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "frt_matcher_calculate": (_i, [_vp, _vp, _i, _vp]),
     "frt_matcher_top1": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_merge_top1": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -71,6 +77,8 @@ ABI = {
     "frt_pipeline_destroy": (None, [_vp]),
     "frt_pipeline_run": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_pipeline_run_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "frt_pipeline_run_dev_after": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "frt_pipeline_set_input_sync": (_i, [_vp, _i]),
     "frt_pipeline_submit": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(ctypes.c_long)]),
     "frt_pipeline_wait": (_i, [_vp, ctypes.c_long]),
     "frt_pipeline_sync": (_i, [_vp]),
@@ -132,6 +140,33 @@ class MatMul:
         numCol = g.shape[1] if numCol is None else numCol
         _check(lib.frt_matcher_init(self._h, _ptr(g), int(numRow), int(numCol)))
         self.m, self.k = int(numRow), int(numCol)
+
+    def setStorage(self, fp16):
+        """Rows of the NEXT init / galleryBegin are stored as fp16 on the device (BASELINE config 5) when ``fp16`` is true."""
+        _check(lib.frt_matcher_set_storage(self._h, 1 if fp16 else 0))
+
+    # streaming load == initKnownEmbeds / addEmbedding x n / initMatMul (src/db.cpp:316-346)
+    def galleryBegin(self, rowCapacity, numCol=512):
+        _check(lib.frt_matcher_gallery_begin(self._h, int(rowCapacity), int(numCol)))
+        self._pending_k = int(numCol)
+
+    def galleryAppend(self, rows):
+        """``rows``: float32 array [n, numCol] or a bytes-like blob of raw little-endian float32 rows (SQLite's EMBEDDING column)."""
+        if isinstance(rows, (bytes, bytearray, memoryview)):
+            a = np.frombuffer(rows, dtype="<f4")
+        else:
+            a = np.ascontiguousarray(rows, np.float32).reshape(-1)
+        if a.size % self._pending_k:
+            raise ValueError("galleryAppend: %d floats is not a whole number of %d-float rows" % (a.size, self._pending_k))
+        _check(lib.frt_matcher_gallery_append(self._h, _ptr(a), a.size // self._pending_k))
+
+    def galleryCommit(self):
+        _check(lib.frt_matcher_gallery_commit(self._h))
+        self.m, self.k = int(lib.frt_matcher_num_rows(self._h)), self._pending_k
+
+    def top1_dev(self, embeds_ptr, n, idx_ptr, sim_ptr, hip_stream=None):
+        """Asynchronous, raw device addresses (queries fp32 [n][k], idx int32 [n], sim fp32 [n])."""
+        _check(lib.frt_matcher_top1_dev(self._h, _vp(embeds_ptr), int(n), _vp(idx_ptr), _vp(sim_ptr), _vp(hip_stream) if hip_stream else None))
 
     def setRowOffset(self, row_offset):
         """Sharded gallery: local row 0 is global row ``row_offset`` (top-1 indices become global)."""
@@ -443,9 +478,18 @@ class Pipeline:
     def wait(self, ticket):
         _check(lib.frt_pipeline_wait(self._h, int(ticket)))
 
-    def run_dev(self, frames_ptr, n_frames, results_ptr, embeds_ptr=None):
-        """Asynchronous; arguments are raw device addresses (e.g. ``torch.Tensor.data_ptr()``)."""
-        _check(lib.frt_pipeline_run_dev(self._h, _vp(frames_ptr), int(n_frames), _vp(results_ptr), _vp(embeds_ptr) if embeds_ptr else None))
+    def run_dev(self, frames_ptr, n_frames, results_ptr, embeds_ptr=None, ready_event=None):
+        """Asynchronous; arguments are raw device addresses (e.g. ``torch.Tensor.data_ptr()``).  ``ready_event``: raw hipEvent_t the
+        producer of the frames recorded (``torch.cuda.Event.cuda_event``) - the stages wait for it on the device."""
+        if ready_event:
+            _check(lib.frt_pipeline_run_dev_after(self._h, _vp(frames_ptr), int(n_frames), _vp(results_ptr), _vp(embeds_ptr) if embeds_ptr else None,
+                                                  _vp(ready_event)))
+        else:
+            _check(lib.frt_pipeline_run_dev(self._h, _vp(frames_ptr), int(n_frames), _vp(results_ptr), _vp(embeds_ptr) if embeds_ptr else None))
+
+    def set_input_sync(self, enable):
+        """Safe mode: order every run_dev call behind the work already queued on the pipeline stream (see include/frt.h)."""
+        _check(lib.frt_pipeline_set_input_sync(self._h, 1 if enable else 0))
 
     def sync(self):
         _check(lib.frt_pipeline_sync(self._h))

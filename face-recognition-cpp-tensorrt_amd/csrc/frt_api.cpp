@@ -114,6 +114,14 @@ struct frt_detector {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
+    // The pipeline's detector stage keeps running on the pipeline's stream after frt_pipeline_run_dev / submit returned (the
+    // object mutex is only held while work is enqueued).  Object-level entry points share d_input, the activations and the
+    // candidate buffers with it: they order their stream behind the end of the last such stage (one event wait).
+    hipEvent_t ev_busy = nullptr;
+    bool busy = false;
+    void wait_idle(hipStream_t s) {
+        if (busy) HIPCHK(hipStreamWaitEvent(s, ev_busy, 0));
+    }
     Arena arena;
     DetGeom g{};
     int max_batch = 1;
@@ -499,6 +507,7 @@ void frt_detector::forward(int n, hipStream_t s, int first_op) {
             launch_heads_multi(o.hd, o.n, s);
         }
     }
+    HIPCHK(hipGetLastError());  // a failed launch (e.g. the dynamic-LDS opt-in missing on this device) must not pass silently
 }
 
 void frt_detector::postprocess(int n, hipStream_t s, frt_bbox *boxes_out, int *nout_out, float *landmarks_out) {
@@ -508,6 +517,7 @@ void frt_detector::postprocess(int n, hipStream_t s, frt_bbox *boxes_out, int *n
     launch_decode(d_loc, d_conf, n, g, d_cand, d_cand_count, s);
     launch_nms(d_cand, d_cand_count, n, g, d_dead, bo, no, d_kept_anchor, s);
     if (has_landmarks) launch_landmark_decode(d_ldm, d_kept_anchor, no, n, g, landmarks_out ? landmarks_out : d_landmarks, s);
+    HIPCHK(hipGetLastError());
 }
 
 // =====================================================================================================================
@@ -525,6 +535,13 @@ struct frt_embedder {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
+    // end of the last pipeline recogniser pass on each activation set (see frt_detector::wait_idle)
+    hipEvent_t ev_busy[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    void wait_idle(hipStream_t s) {
+        for (int i = 0; i < 2; ++i)
+            if (busy[i]) HIPCHK(hipStreamWaitEvent(s, ev_busy[i], 0));
+    }
     Arena arena;
     int max_batch = 1;
     bool se = false;
@@ -799,6 +816,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
         launch_conv_mfma(a, s);
         launch_fc_finalize(fc_partial, FC_SPLITS, F, fc_bias, bn_s, bn_b, valid_dev, out_dev, s);
     }
+    HIPCHK(hipGetLastError());
 }
 
 // =====================================================================================================================
@@ -809,7 +827,9 @@ struct frt_matcher {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
-    float *d_gallery = nullptr;
+    hipEvent_t ev_busy = nullptr;  // end of the last pipeline match stage that used this object's scratch (see wait_idle)
+    bool busy = false;
+    float *d_gallery = nullptr;  // fp32 rows [N][D]; null when the gallery is STORED as fp16 (store16)
     int N = 0, D = 0;
     int row_offset = 0;  // global index of local row 0 (sharded galleries)
     // scratch (grown on demand)
@@ -819,8 +839,11 @@ struct frt_matcher {
     int q_cap = 0;
     size_t full_cap = 0;
     int blocks = 0;
-    // screened top-1 (fp16 shadow gallery; see kernels_match.hip).  Off for small galleries and with FRT_MATCH_SCREEN=0.
-    half_t *d_g16 = nullptr;
+    // screened top-1 (fp16 shadow gallery; see kernels_match.hip).  Off for small galleries, for D % 64 != 0 (the coarse kernel
+    // walks K in steps of 64) and with FRT_MATCH_SCREEN=0.
+    half_t *d_g16 = nullptr;   // fp16 shadow of d_gallery, or the fp16-STORED gallery itself
+    bool store16 = false;      // current gallery is fp16-stored
+    bool want16 = false;       // storage mode of the NEXT init / gallery_begin (frt_matcher_set_storage)
     float gmax_norm = 0.f;
     bool screen = false;
     ScreenScratch scr{};
@@ -828,6 +851,162 @@ struct frt_matcher {
         for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list})  // scr.count lives behind tile_flags
             if (p) (void)hipFree(p);
         scr = ScreenScratch{};
+    }
+    // Object-level entry points share the scratch buffers with the pipeline's match stage, which keeps running on the pipeline's
+    // stream after frt_pipeline_run_dev / submit returned: order this object's stream behind it (one event wait, no host sync).
+    void wait_idle(hipStream_t s) {
+        if (busy) HIPCHK(hipStreamWaitEvent(s, ev_busy, 0));
+    }
+
+    // ---- streaming gallery load (frt_matcher_gallery_begin / append / commit == initKnownEmbeds / addEmbedding / initMatMul,
+    //      src/db.cpp:316-346): rows are copied into pinned staging chunks as they arrive (the caller's pointer may be SQLite's
+    //      blob buffer) and every full chunk goes to the device with an asynchronous copy while the next one fills.  The previous
+    //      gallery stays live (and searchable) until commit swaps the pointers.
+    struct Load {
+        static constexpr int NCH = 3;
+        static constexpr int CH_ROWS = 4096;   // x 512 floats = 8 MB per chunk
+        bool active = false;
+        bool f16 = false;
+        int cap = 0, D = 0, rows = 0, fill = 0, cur = 0;
+        float *d_new32 = nullptr;
+        half_t *d_new16 = nullptr;
+        float *h_stage[NCH] = {};
+        float *d_stage[NCH] = {};   // fp16 storage only: fp32 landing buffers in front of the conversion kernel
+        hipEvent_t ev[NCH] = {};
+        bool pending[NCH] = {};
+        size_t stage_floats = 0;
+        hipStream_t s = nullptr;
+    } ld;
+    void load_release_staging() {
+        for (int i = 0; i < Load::NCH; ++i) {
+            if (ld.h_stage[i]) (void)hipHostFree(ld.h_stage[i]);
+            if (ld.d_stage[i]) (void)hipFree(ld.d_stage[i]);
+            if (ld.ev[i]) (void)hipEventDestroy(ld.ev[i]);
+            ld.h_stage[i] = ld.d_stage[i] = nullptr;
+            ld.ev[i] = nullptr;
+            ld.pending[i] = false;
+        }
+        ld.stage_floats = 0;
+    }
+    void load_abort() {
+        if (ld.s) (void)hipStreamSynchronize(ld.s);
+        if (ld.d_new32) (void)hipFree(ld.d_new32);
+        if (ld.d_new16) (void)hipFree(ld.d_new16);
+        ld.d_new32 = nullptr;
+        ld.d_new16 = nullptr;
+        ld.active = false;
+    }
+    void load_begin(int cap, int cols) {
+        if (ld.active) load_abort();
+        if (!ld.s) HIPCHK(hipStreamCreateWithFlags(&ld.s, hipStreamNonBlocking));
+        const size_t need = (size_t)Load::CH_ROWS * cols;
+        if (ld.stage_floats != need) {
+            load_release_staging();
+            for (int i = 0; i < Load::NCH; ++i) {
+                HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ld.h_stage[i]), need * sizeof(float), hipHostMallocDefault));
+                HIPCHK(hipEventCreateWithFlags(&ld.ev[i], hipEventDisableTiming));
+            }
+            ld.stage_floats = need;
+        }
+        ld.f16 = want16;
+        ld.cap = cap;
+        ld.D = cols;
+        ld.rows = ld.fill = ld.cur = 0;
+        if (cap > 0) {
+            if (ld.f16) {
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&ld.d_new16), (size_t)cap * cols * sizeof(half_t)));
+                for (int i = 0; i < Load::NCH; ++i)
+                    if (!ld.d_stage[i]) HIPCHK(hipMalloc(reinterpret_cast<void **>(&ld.d_stage[i]), need * sizeof(float)));
+            } else {
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&ld.d_new32), (size_t)cap * cols * sizeof(float)));
+            }
+        }
+        ld.active = true;
+    }
+    void load_flush() {  // current chunk -> device
+        if (!ld.fill) return;
+        const int c = ld.cur;
+        const size_t off = (size_t)(ld.rows - ld.fill) * ld.D, n = (size_t)ld.fill * ld.D;
+        if (ld.f16) {
+            HIPCHK(hipMemcpyAsync(ld.d_stage[c], ld.h_stage[c], n * sizeof(float), hipMemcpyHostToDevice, ld.s));
+            launch_rows_to_half(ld.d_stage[c], ld.d_new16 + off, (long)(n / 8), ld.s);
+        } else {
+            HIPCHK(hipMemcpyAsync(ld.d_new32 + off, ld.h_stage[c], n * sizeof(float), hipMemcpyHostToDevice, ld.s));
+        }
+        HIPCHK(hipEventRecord(ld.ev[c], ld.s));
+        ld.pending[c] = true;
+        ld.cur = (c + 1) % Load::NCH;
+        ld.fill = 0;
+        if (ld.pending[ld.cur]) {  // the chunk about to be refilled must have left the host (and its landing buffer)
+            HIPCHK(hipEventSynchronize(ld.ev[ld.cur]));
+            ld.pending[ld.cur] = false;
+        }
+    }
+    void load_append(const float *rows, int n) {
+        if (!ld.active) raise(FRT_ERR_INVALID, "gallery_append: no load in progress (call frt_matcher_gallery_begin first)");
+        if (n < 0 || (n > 0 && !rows)) raise(FRT_ERR_INVALID, "gallery_append: bad argument");
+        if ((long)ld.rows + n > ld.cap) raise(FRT_ERR_CAPACITY, "gallery_append: more rows than gallery_begin reserved (initKnownEmbeds)");
+        while (n > 0) {
+            const int take = std::min(n, Load::CH_ROWS - ld.fill);
+            std::memcpy(ld.h_stage[ld.cur] + (size_t)ld.fill * ld.D, rows, (size_t)take * ld.D * sizeof(float));
+            ld.fill += take;
+            ld.rows += take;
+            rows += (size_t)take * ld.D;
+            n -= take;
+            if (ld.fill == Load::CH_ROWS) load_flush();
+        }
+    }
+    // make the loaded rows THE gallery: swap pointers, rebuild the screening data, free the previous gallery
+    void load_commit() {
+        if (!ld.active) raise(FRT_ERR_INVALID, "gallery_commit: no load in progress");
+        load_flush();
+        HIPCHK(hipStreamSynchronize(ld.s));
+        for (bool &p : ld.pending) p = false;
+        HIPCHK(hipStreamSynchronize(stream));
+        if (busy) HIPCHK(hipEventSynchronize(ev_busy));
+        float *old32 = d_gallery;
+        half_t *old16 = d_g16;
+        ++generation;
+        N = ld.rows;
+        D = ld.D;
+        store16 = ld.f16;
+        d_gallery = ld.rows > 0 ? ld.d_new32 : nullptr;
+        d_g16 = ld.rows > 0 ? ld.d_new16 : nullptr;
+        if (ld.rows == 0) {  // empty gallery: nothing to keep
+            if (ld.d_new32) (void)hipFree(ld.d_new32);
+            if (ld.d_new16) (void)hipFree(ld.d_new16);
+        }
+        ld.d_new32 = nullptr;
+        ld.d_new16 = nullptr;
+        ld.active = false;
+        if (old32) (void)hipFree(old32);  // (hipFree waits for the device: stages of earlier pipeline calls have finished with it)
+        if (old16) (void)hipFree(old16);
+        blocks = match_top1_blocks(N, 0);
+        const char *scr_env = getenv("FRT_MATCH_SCREEN");
+        screen = N >= 32768 && D % 64 == 0 && !(scr_env && scr_env[0] == '0');
+        gmax_norm = 0.f;
+        if (N > 0 && (screen || store16)) {  // fp16 shadow copy (fp32 storage) + the largest row norm (rounding bound of the screening pass)
+            int *d_bits = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_bits), sizeof(int)));
+            if (store16) {
+                launch_gallery_norm16(d_g16, N, D, d_bits, stream);
+            } else {
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_g16), (size_t)N * D * sizeof(half_t)));
+                launch_gallery_shadow(d_gallery, N, D, d_g16, d_bits, stream);
+            }
+            int bits = 0;
+            HIPCHK(hipMemcpyAsync(&bits, d_bits, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            (void)hipFree(d_bits);
+            float n2;
+            std::memcpy(&n2, &bits, 4);
+            gmax_norm = std::sqrt(n2);
+        }
+        q_cap = 0;  // partial scratch depends on `blocks`
+        if (d_partial) {
+            (void)hipFree(d_partial);
+            d_partial = nullptr;
+        }
     }
 
     void ensure_queries(int F) {
@@ -857,10 +1036,13 @@ struct frt_matcher {
     void top1_dev(const float *queries_dev, int F, int32_t *idx_dev, float *sim_dev, hipStream_t s) {
         ProfScope ps(2, "match_top1", 2.0 * D * (double)N * F, s);
         // the partial scratch is [blocks][F]
-        if (screen)
+        if (screen)  // (d_gallery == nullptr with fp16 storage: the exact re-rank then reads the stored fp16 rows)
             launch_match_top1_screened(d_gallery, d_g16, N, D, queries_dev, F, gmax_norm, scr, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
+        else if (store16)
+            launch_match_top1_h(d_g16, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
         else
             launch_match_top1(d_gallery, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
+        HIPCHK(hipGetLastError());
     }
 };
 
@@ -893,11 +1075,12 @@ struct frt_pipeline {
     unsigned seq = 0;
     bool overlap = true;
     Arena arena;
-    uint8_t *d_frames;
-    float *d_chw, *d_embeds, *d_sim;
-    int *d_valid;
+    float *d_chw, *d_sim;
     int32_t *d_idx;
-    frt_face_result *d_results;
+    std::mutex run_mu;               // serialises run(): stream selection, slot counters and the stage enqueue order are per-call state
+    bool input_sync = false;         // frt_pipeline_set_input_sync: order every run_dev call behind the work queued on `stream` so far
+    hipEvent_t ev_input = nullptr;   // ... recorded on `stream` at the call
+    hipEvent_t ev_ready = nullptr;   // caller's "frames are ready" event of frt_pipeline_run_dev_after (borrowed, one call)
 
     // ---- asynchronous host boundary (frt_pipeline_submit / frt_pipeline_wait): NBUF staging sets so that the H2D copy of batch
     //      b+1 (copy_stream, the SDMA engine) and the D2H of batch b-1 run under the stages of batch b
@@ -1031,8 +1214,16 @@ struct frt_pipeline {
             HIPCHK(hipStreamWaitEvent(es, ev_done[slot], 0));
         }
         if (ev_frames) {  // frt_pipeline_submit: the frames arrive on the copy stream
-            HIPCHK(hipStreamWaitEvent(ds, ev_frames, 0));
+            HIPCHK(hipStreamWaitEvent(ds, ev_frames, 0));  // (crop + recogniser follow the detector through ev_det[slot])
             ev_frames = nullptr;
+        }
+        if (ev_ready) {  // frt_pipeline_run_dev_after: the caller's producer (upload / decode / resize on any stream) signals this event
+            HIPCHK(hipStreamWaitEvent(ds, ev_ready, 0));
+            ev_ready = nullptr;
+        }
+        if (input_sync && pipe3) {  // safe mode: everything queued on the caller's stream before this call happens-before the stages
+            HIPCHK(hipEventRecord(ev_input, s));
+            HIPCHK(hipStreamWaitEvent(ds, ev_input, 0));
         }
         const bool have_gallery = mat && mat->N > 0;
         const unsigned gen = mat ? mat->generation : 0u;
@@ -1040,6 +1231,8 @@ struct frt_pipeline {
             det->forward_frames(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, st);
             det->postprocess(n, st, slot_boxes[slot], slot_nout[slot], slot_landmarks[slot]);  // straight into this call's slot
         });
+        HIPCHK(hipEventRecord(det->ev_busy, ds));  // object-level detector calls wait for this (frt_detector::wait_idle)
+        det->busy = true;
         if (pipe3) {
             HIPCHK(hipEventRecord(ev_det[slot], ds));
             HIPCHK(hipStreamWaitEvent(es, ev_det[slot], 0));
@@ -1064,6 +1257,8 @@ struct frt_pipeline {
                 emb->forward_set(eset, chw + (size_t)f0 * 3 * 112 * 112, nf, valid + f0, emb_slot + (size_t)f0 * 512, st);
             }
         });
+        HIPCHK(hipEventRecord(emb->ev_busy[eset], es));
+        emb->busy[eset] = true;
         if (pipe3) {
             HIPCHK(hipEventRecord(ev_emb[slot], es));
             HIPCHK(hipStreamWaitEvent(ms, ev_emb[slot], 0));
@@ -1076,6 +1271,10 @@ struct frt_pipeline {
             }
             if (embeds_dev) HIPCHK(hipMemcpyAsync(embeds_dev, emb_slot, sizeof(float) * 512 * F, hipMemcpyDeviceToDevice, st));
         });
+        if (mat) {
+            HIPCHK(hipEventRecord(mat->ev_busy, ms));
+            mat->busy = true;
+        }
         if (pipe3) {
             HIPCHK(hipEventRecord(ev_done[slot], ms));
             HIPCHK(hipStreamWaitEvent(s, ev_done[slot], 0));  // the caller's stream joins here
@@ -1132,6 +1331,7 @@ int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int 
         g.bbox_thr = bbox_threshold;
         g.max_faces = max_faces;
         HIPCHK(hipStreamCreate(&d->stream));
+        HIPCHK(hipEventCreateWithFlags(&d->ev_busy, hipEventDisableTiming));
         const size_t B = (size_t)max_batch;
         d->d_frames = d->arena.alloc<uint8_t>(B * frame_h * frame_w * 3);
         d->d_input = d->arena.alloc<float>(B * 3 * in_h * in_w);
@@ -1163,6 +1363,7 @@ void frt_detector_destroy(frt_detector *d) {
         (void)hipStreamSynchronize(d->stream);
         (void)hipStreamDestroy(d->stream);
     }
+    if (d->ev_busy) (void)hipEventDestroy(d->ev_busy);
     d->arena.release();
     delete d;
 }
@@ -1178,6 +1379,7 @@ int frt_detector_find_faces_batch(frt_detector *d, const uint8_t *bgr, int n_fra
         std::lock_guard<std::mutex> lk(d->mu);
         use_device(d->device);
         hipStream_t s = d->stream;
+        d->wait_idle(s);
         const size_t tight = (size_t)cols * 3;
         for (int f = 0; f < n_frames; ++f)
             HIPCHK(hipMemcpy2DAsync(d->d_frames + (size_t)f * rows * tight, tight, bgr + (size_t)f * frame_stride, row_stride, tight, rows,
@@ -1205,6 +1407,7 @@ int frt_detector_find_faces_landmarks(frt_detector *d, const uint8_t *bgr, int r
         std::lock_guard<std::mutex> lk(d->mu);
         use_device(d->device);
         hipStream_t s = d->stream;
+        d->wait_idle(s);
         const size_t tight = (size_t)cols * 3;
         HIPCHK(hipMemcpy2DAsync(d->d_frames, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice, s));
         d->forward_frames(d->d_frames, 1, tight, (size_t)rows * tight, s);
@@ -1223,6 +1426,7 @@ int frt_detector_preprocess(frt_detector *d, const uint8_t *bgr, int rows, int c
         std::lock_guard<std::mutex> lk(d->mu);
         use_device(d->device);
         hipStream_t s = d->stream;
+        d->wait_idle(s);
         const size_t tight = (size_t)cols * 3;
         HIPCHK(hipMemcpy2DAsync(d->d_frames, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice, s));
         d->preprocess(d->d_frames, 1, tight, (size_t)rows * tight, s);
@@ -1238,6 +1442,7 @@ int frt_detector_infer(frt_detector *d, const float *chw, int batch, float *loc_
         std::lock_guard<std::mutex> lk(d->mu);
         use_device(d->device);
         hipStream_t s = d->stream;
+        d->wait_idle(s);
         const size_t in_elems = (size_t)3 * d->g.in_h * d->g.in_w;
         HIPCHK(hipMemcpyAsync(d->d_input, chw, sizeof(float) * in_elems * batch, hipMemcpyHostToDevice, s));
         d->forward(batch, s);
@@ -1255,6 +1460,7 @@ int frt_detector_infer_landmarks(frt_detector *d, const float *chw, int batch, f
         std::lock_guard<std::mutex> lk(d->mu);
         use_device(d->device);
         hipStream_t s = d->stream;
+        d->wait_idle(s);
         const size_t in_elems = (size_t)3 * d->g.in_h * d->g.in_w;
         HIPCHK(hipMemcpyAsync(d->d_input, chw, sizeof(float) * in_elems * batch, hipMemcpyHostToDevice, s));
         d->forward(batch, s);
@@ -1271,6 +1477,7 @@ int frt_detector_postprocess(frt_detector *d, const float *loc, const float *con
         std::lock_guard<std::mutex> lk(d->mu);
         use_device(d->device);
         hipStream_t s = d->stream;
+        d->wait_idle(s);
         HIPCHK(hipMemcpyAsync(d->d_loc, loc, sizeof(float) * (size_t)d->g.A * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(d->d_conf, conf, sizeof(float) * (size_t)d->g.A * 2, hipMemcpyHostToDevice, s));
         d->postprocess(1, s);
@@ -1363,6 +1570,8 @@ int frt_embedder_create(const char *weights_path, int in_c, int in_h, int in_w, 
         e->max_batch = max_batch;
         e->se = blob.kind == 3;
         HIPCHK(hipStreamCreate(&e->stream));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_busy[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_busy[1], hipEventDisableTiming));
         e->build(blob);
         HIPCHK(hipDeviceSynchronize());
         *out = e.release();
@@ -1377,6 +1586,8 @@ void frt_embedder_destroy(frt_embedder *e) {
         (void)hipStreamDestroy(e->stream);
     }
     if (e->d_frame) (void)hipFree(e->d_frame);
+    for (hipEvent_t ev : e->ev_busy)
+        if (ev) (void)hipEventDestroy(ev);
     e->arena.release();
     delete e;
 }
@@ -1387,6 +1598,7 @@ int frt_embedder_preprocess_face(frt_embedder *e, const uint8_t *bgr_crop, float
         std::lock_guard<std::mutex> lk(e->mu);
         use_device(e->device);
         hipStream_t s = e->stream;
+        e->wait_idle(s);
         HIPCHK(hipMemcpyAsync(e->d_crops, bgr_crop, 112 * 112 * 3, hipMemcpyHostToDevice, s));
         launch_face_normalize(e->d_crops, 1, 112, 112, e->d_in, s);
         HIPCHK(hipMemcpyAsync(chw_out, e->d_in, sizeof(float) * 3 * 112 * 112, hipMemcpyDeviceToHost, s));
@@ -1400,6 +1612,7 @@ int frt_embedder_infer(frt_embedder *e, const float *chw, int batch, float *embe
         std::lock_guard<std::mutex> lk(e->mu);
         use_device(e->device);
         hipStream_t s = e->stream;
+        e->wait_idle(s);
         const size_t in_elems = (size_t)3 * 112 * 112;
         for (int f0 = 0; f0 < batch; f0 += e->max_batch) {
             const int nf = std::min(e->max_batch, batch - f0);
@@ -1419,6 +1632,7 @@ int frt_embedder_forward(frt_embedder *e, const uint8_t *bgr, int rows, int cols
         std::lock_guard<std::mutex> lk(e->mu);
         use_device(e->device);
         hipStream_t s = e->stream;
+        e->wait_idle(s);
         const size_t tight = (size_t)cols * 3, need = (size_t)rows * tight;
         if (need > e->frame_cap) {
             if (e->d_frame) (void)hipFree(e->d_frame);
@@ -1479,6 +1693,7 @@ int frt_embedder_forward_aligned(frt_embedder *e, const uint8_t *bgr, int rows, 
         std::lock_guard<std::mutex> lk(e->mu);
         use_device(e->device);
         hipStream_t s = e->stream;
+        e->wait_idle(s);
         const size_t tight = (size_t)cols * 3, need = (size_t)rows * tight;
         if (need > e->frame_cap) {
             if (e->d_frame) (void)hipFree(e->d_frame);
@@ -1513,6 +1728,7 @@ int frt_matcher_create(int device, frt_matcher **out) {
         std::unique_ptr<frt_matcher> m(new frt_matcher);
         m->device = device;
         HIPCHK(hipStreamCreate(&m->stream));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_busy, hipEventDisableTiming));
         *out = m.release();
     });
 }
@@ -1524,53 +1740,82 @@ void frt_matcher_destroy(frt_matcher *m) {
         (void)hipStreamSynchronize(m->stream);
         (void)hipStreamDestroy(m->stream);
     }
+    m->load_abort();
+    m->load_release_staging();
+    if (m->ld.s) (void)hipStreamDestroy(m->ld.s);
+    if (m->ev_busy) (void)hipEventDestroy(m->ev_busy);
     for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full, (void *)m->d_g16})
         if (p) (void)hipFree(p);
     m->free_screen_scratch();
     delete m;
 }
 
+static void check_gallery_shape(int num_row, int num_col) {
+    if (num_row < 0) raise(FRT_ERR_INVALID, "MatMul::init: bad argument");
+    if (num_col < 32 || num_col % 32) raise(FRT_ERR_INVALID, "MatMul::init: numCol must be a multiple of 32");
+}
+
+int frt_matcher_set_storage(frt_matcher *m, int fp16) {
+    return guarded([&] {
+        if (!m) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->want16 = fp16 != 0;
+    });
+}
+
 int frt_matcher_init(frt_matcher *m, const float *gallery, int num_row, int num_col) {
     return guarded([&] {
-        if (!m || (num_row > 0 && !gallery) || num_row < 0) raise(FRT_ERR_INVALID, "MatMul::init: bad argument");
-        if (num_col < 32 || num_col % 32) raise(FRT_ERR_INVALID, "MatMul::init: numCol must be a multiple of 32");
+        if (!m || (num_row > 0 && !gallery)) raise(FRT_ERR_INVALID, "MatMul::init: bad argument");
+        check_gallery_shape(num_row, num_col);
         std::lock_guard<std::mutex> lk(m->mu);
         use_device(m->device);
-        HIPCHK(hipStreamSynchronize(m->stream));
-        ++m->generation;
-        if (m->d_gallery) (void)hipFree(m->d_gallery);  // idempotent re-init (the reference leaks here on /reload)
-        m->d_gallery = nullptr;
-        m->N = num_row;
-        m->D = num_col;
-        if (num_row > 0) {
-            HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_gallery), (size_t)num_row * num_col * sizeof(float)));
-            HIPCHK(hipMemcpy(m->d_gallery, gallery, (size_t)num_row * num_col * sizeof(float), hipMemcpyHostToDevice));
-        }
-        m->blocks = match_top1_blocks(num_row, 0);
-        if (m->d_g16) (void)hipFree(m->d_g16);
-        m->d_g16 = nullptr;
-        const char *scr_env = getenv("FRT_MATCH_SCREEN");
-        m->screen = num_row >= 32768 && !(scr_env && scr_env[0] == '0');
-        if (m->screen) {  // fp16 shadow copy + the largest row norm (for the rounding bound of the screening pass)
-            int *d_bits = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_g16), (size_t)num_row * num_col * sizeof(half_t)));
-            HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_bits), sizeof(int)));
-            launch_gallery_shadow(m->d_gallery, num_row, num_col, m->d_g16, d_bits, m->stream);
-            int bits = 0;
-            HIPCHK(hipMemcpyAsync(&bits, d_bits, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-            HIPCHK(hipStreamSynchronize(m->stream));
-            (void)hipFree(d_bits);
-            float n2;
-            std::memcpy(&n2, &bits, 4);
-            m->gmax_norm = std::sqrt(n2);
-        }
-        m->q_cap = 0;  // partial scratch depends on `blocks`
-        if (m->d_partial) {
-            (void)hipFree(m->d_partial);
-            m->d_partial = nullptr;
+        // one path for every gallery load: pinned staging chunks + asynchronous copies (idempotent: the previous device copy is
+        // freed at commit - the reference leaks it on every /reload)
+        m->load_begin(num_row, num_col);
+        try {
+            m->load_append(gallery, num_row);
+            m->load_commit();
+        } catch (...) {
+            m->load_abort();
+            throw;
         }
     });
 }
+
+int frt_matcher_gallery_begin(frt_matcher *m, int row_capacity, int num_col) {
+    return guarded([&] {
+        if (!m) raise(FRT_ERR_INVALID, "null argument");
+        check_gallery_shape(row_capacity, num_col);
+        std::lock_guard<std::mutex> lk(m->mu);
+        use_device(m->device);
+        m->load_begin(row_capacity, num_col);
+    });
+}
+
+int frt_matcher_gallery_append(frt_matcher *m, const void *rows, int n_rows) {
+    return guarded([&] {
+        if (!m) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        use_device(m->device);
+        m->load_append(reinterpret_cast<const float *>(rows), n_rows);
+    });
+}
+
+int frt_matcher_gallery_commit(frt_matcher *m) {
+    return guarded([&] {
+        if (!m) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        use_device(m->device);
+        try {
+            m->load_commit();
+        } catch (...) {
+            m->load_abort();
+            throw;
+        }
+    });
+}
+
+int frt_matcher_num_rows(const frt_matcher *m) { return m ? m->N : 0; }
 
 int frt_matcher_set_row_offset(frt_matcher *m, int row_offset) {
     return guarded([&] {
@@ -1588,6 +1833,7 @@ int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, 
         if (m->N <= 0 || embed_count <= 0) raise(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found");
         use_device(m->device);
         hipStream_t s = m->stream;
+        m->wait_idle(s);
         m->ensure_queries(embed_count);
         const size_t need = (size_t)embed_count * m->N;
         if (need > m->full_cap) {
@@ -1599,8 +1845,12 @@ int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, 
         HIPCHK(hipMemcpyAsync(m->d_q, embeds, sizeof(float) * (size_t)embed_count * m->D, hipMemcpyHostToDevice, s));
         for (int f0 = 0; f0 < embed_count; f0 += 128) {
             const int nf = std::min(128, embed_count - f0);
-            launch_match_full(m->d_gallery, m->N, m->D, m->d_q + (size_t)f0 * m->D, nf, m->d_full + (size_t)f0 * m->N, s);
+            if (m->store16)
+                launch_match_full_h(m->d_g16, m->N, m->D, m->d_q + (size_t)f0 * m->D, nf, m->d_full + (size_t)f0 * m->N, s);
+            else
+                launch_match_full(m->d_gallery, m->N, m->D, m->d_q + (size_t)f0 * m->D, nf, m->d_full + (size_t)f0 * m->N, s);
         }
+        HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(outputs, m->d_full, need * sizeof(float), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     });
@@ -1613,12 +1863,29 @@ int frt_matcher_top1(frt_matcher *m, const float *embeds, int embed_count, int32
         if (m->N <= 0 || embed_count <= 0) raise(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found");
         use_device(m->device);
         hipStream_t s = m->stream;
+        m->wait_idle(s);
         m->ensure_queries(embed_count);
         HIPCHK(hipMemcpyAsync(m->d_q, embeds, sizeof(float) * (size_t)embed_count * m->D, hipMemcpyHostToDevice, s));
         m->top1_dev(m->d_q, embed_count, m->d_idx, m->d_sim, s);
         HIPCHK(hipMemcpyAsync(idx_out, m->d_idx, sizeof(int32_t) * embed_count, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(sim_out, m->d_sim, sizeof(float) * embed_count, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+/* device-resident queries (sharded-gallery path, dist.py: the all-gathered embeddings never visit the host) */
+int frt_matcher_top1_dev(frt_matcher *m, const void *embeds_dev, int embed_count, void *idx_dev, void *sim_dev, void *hip_stream) {
+    return guarded([&] {
+        if (!m || !embeds_dev || !idx_dev || !sim_dev) raise(FRT_ERR_INVALID, "top1_dev: null argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (m->N <= 0 || embed_count <= 0) raise(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found");
+        use_device(m->device);
+        hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+        m->wait_idle(s);
+        m->ensure_queries(embed_count);
+        m->top1_dev(reinterpret_cast<const float *>(embeds_dev), embed_count, reinterpret_cast<int32_t *>(idx_dev), reinterpret_cast<float *>(sim_dev), s);
+        HIPCHK(hipEventRecord(m->ev_busy, s));  // the scratch stays in use until this call has run
+        m->busy = true;
     });
 }
 
@@ -1697,13 +1964,10 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
             const char *gph = getenv("FRT_PIPELINE_GRAPH");
             p->use_graphs = gph && gph[0] == '1';  // opt-in: measured no gain on this workload (see the note at run_part)
         }
-        p->d_frames = p->arena.alloc<uint8_t>((size_t)max_frames * d->g.frame_h * d->g.frame_w * 3);
+        HIPCHK(hipEventCreateWithFlags(&p->ev_input, hipEventDisableTiming));
         p->d_chw = p->arena.alloc<float>(F * 3 * 112 * 112);
-        p->d_embeds = p->arena.alloc<float>(F * 512);
         p->d_sim = p->arena.alloc<float>(F);
         p->d_idx = p->arena.alloc<int32_t>(F);
-        p->d_valid = p->arena.alloc<int>(F);
-        p->d_results = p->arena.alloc<frt_face_result>(F);
         *out = p.release();
     });
 }
@@ -1723,6 +1987,7 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     if (p->emb_stream2) (void)hipStreamDestroy(p->emb_stream2);
     if (p->match_stream) (void)hipStreamDestroy(p->match_stream);
     if (p->ev_serial) (void)hipEventDestroy(p->ev_serial);
+    if (p->ev_input) (void)hipEventDestroy(p->ev_input);
     if (p->copy_stream) {
         (void)hipStreamSynchronize(p->copy_stream);
         (void)hipStreamDestroy(p->copy_stream);
@@ -1740,6 +2005,7 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     delete p;
 }
 
+// Caller holds p->run_mu.
 static void pipeline_lock_run(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev) {
     if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
     std::lock_guard<std::mutex> l1(p->det->mu);
@@ -1757,7 +2023,31 @@ int frt_pipeline_run_dev(frt_pipeline *p, const void *frames_dev, int n_frames, 
     return guarded([&] {
         if (!p || !frames_dev || !results_dev) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
+        std::lock_guard<std::mutex> lk(p->run_mu);
         pipeline_lock_run(p, frames_dev, n_frames, results_dev, embeds_dev);
+    });
+}
+
+int frt_pipeline_run_dev_after(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev, void *ready_event) {
+    return guarded([&] {
+        if (!p || !frames_dev || !results_dev) raise(FRT_ERR_INVALID, "null argument");
+        use_device(p->det->device);
+        std::lock_guard<std::mutex> lk(p->run_mu);
+        p->ev_ready = reinterpret_cast<hipEvent_t>(ready_event);
+        try {
+            pipeline_lock_run(p, frames_dev, n_frames, results_dev, embeds_dev);
+        } catch (...) {
+            p->ev_ready = nullptr;
+            throw;
+        }
+    });
+}
+
+int frt_pipeline_set_input_sync(frt_pipeline *p, int enable) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(p->run_mu);
+        p->input_sync = enable != 0;
     });
 }
 
@@ -1776,6 +2066,7 @@ int frt_pipeline_sync(frt_pipeline *p) {
 int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
@@ -1789,6 +2080,7 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
 int frt_pipeline_set_overlap(frt_pipeline *p, int enable) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
@@ -1804,6 +2096,7 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable) {
 int frt_pipeline_set_graph(frt_pipeline *p, int enable) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
@@ -1819,6 +2112,7 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         if (enable && !p->det->has_landmarks) raise(FRT_ERR_FORMAT, "pipeline: alignment needs a detector blob with the LandmarkHead");
+        std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
@@ -1829,65 +2123,72 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable) {
     });
 }
 
+// queue one batch through a staging set; caller holds neither mutex
+static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out) {
+    if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
+    use_device(p->det->device);
+    std::lock_guard<std::mutex> lk(p->async_mu);   // staging sets + ticket order
+    std::lock_guard<std::mutex> lr(p->run_mu);     // the stage enqueue itself (shared with frt_pipeline_run_dev)
+    p->ensure_stream();
+    p->ensure_async();
+    const long ticket = p->next_ticket;
+    frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
+    if (b.ticket >= 0) HIPCHK(hipEventSynchronize(b.ev_out));  // the staging set is free once its previous batch has left
+    hipStream_t s = p->stream;
+    const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
+    HIPCHK(hipMemcpyAsync(b.d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, p->copy_stream));
+    HIPCHK(hipEventRecord(b.ev_h2d, p->copy_stream));
+    p->ev_frames = b.ev_h2d;  // the stages that read the frames (detector, crop) wait for the copy; the caller's stream does not
+    try {
+        pipeline_lock_run(p, b.d_frames, n_frames, b.d_results, embeds_out ? b.d_embeds : nullptr);
+    } catch (...) {
+        p->ev_frames = nullptr;
+        throw;
+    }
+    const int F = n_frames * p->max_faces;
+    HIPCHK(hipMemcpyAsync(results, b.d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
+    if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, b.d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(b.ev_out, s));
+    b.ticket = ticket;
+    p->next_ticket = ticket + 1;
+    return ticket;
+}
+
+static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
+    use_device(p->det->device);
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(p->async_mu);
+        if (ticket < 0 || ticket >= p->next_ticket) raise(FRT_ERR_INVALID, "pipeline: unknown ticket");
+        frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
+        if (b.ticket > ticket) return;  // its staging set was reused, which submit only does after that batch completed
+        ev = b.ev_out;
+    }
+    HIPCHK(hipEventSynchronize(ev));
+}
+
+// Synchronous host entry point.  Thread-safe: every call takes its own staging set (device frames / results / embeddings) under the
+// pipeline's mutexes, so concurrent callers (the reference's Crow server is .multithreaded(), src/app.cpp:367) never share a buffer;
+// with several threads calling, their batches overlap in the stage pipeline exactly like submit()/wait() batches do.
 int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out) {
     return guarded([&] {
         if (!p || !frames || !results) raise(FRT_ERR_INVALID, "null argument");
-        if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
-        use_device(p->det->device);
-        p->ensure_stream();
-        hipStream_t s = p->stream;
-        const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
-        // upload on the stream the detector will run on: the crop (pipeline stream) is ordered behind the detector's event
-        hipStream_t cs = (p->overlap && g_prof_kind == 0) ? p->det_stream : s;
-        HIPCHK(hipMemcpyAsync(p->d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, cs));
-        pipeline_lock_run(p, p->d_frames, n_frames, p->d_results, p->d_embeds);
-        const int F = n_frames * p->max_faces;
-        HIPCHK(hipMemcpyAsync(results, p->d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
-        if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, p->d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        const long t = pipeline_submit_impl(p, frames, n_frames, results, embeds_out);
+        pipeline_wait_impl(p, t);
     });
 }
 
 int frt_pipeline_submit(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, long *ticket_out) {
     return guarded([&] {
         if (!p || !frames || !results || !ticket_out) raise(FRT_ERR_INVALID, "null argument");
-        if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
-        use_device(p->det->device);
-        std::lock_guard<std::mutex> lk(p->async_mu);
-        p->ensure_stream();
-        p->ensure_async();
-        const long ticket = p->next_ticket;
-        frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
-        if (b.ticket >= 0) HIPCHK(hipEventSynchronize(b.ev_out));  // the staging set is free once its previous batch has left
-        hipStream_t s = p->stream;
-        const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
-        HIPCHK(hipMemcpyAsync(b.d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, p->copy_stream));
-        HIPCHK(hipEventRecord(b.ev_h2d, p->copy_stream));
-        p->ev_frames = b.ev_h2d;  // the stage that reads the frames first (detector) waits for the copy; the caller's stream does not
-        pipeline_lock_run(p, b.d_frames, n_frames, b.d_results, embeds_out ? b.d_embeds : nullptr);
-        const int F = n_frames * p->max_faces;
-        HIPCHK(hipMemcpyAsync(results, b.d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
-        if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, b.d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipEventRecord(b.ev_out, s));
-        b.ticket = ticket;
-        p->next_ticket = ticket + 1;
-        *ticket_out = ticket;
+        *ticket_out = pipeline_submit_impl(p, frames, n_frames, results, embeds_out);
     });
 }
 
 int frt_pipeline_wait(frt_pipeline *p, long ticket) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
-        use_device(p->det->device);
-        hipEvent_t ev = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(p->async_mu);
-            if (ticket < 0 || ticket >= p->next_ticket) raise(FRT_ERR_INVALID, "pipeline: unknown ticket");
-            frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
-            if (b.ticket > ticket) return;  // its staging set was reused, which submit only does after that batch completed
-            ev = b.ev_out;
-        }
-        HIPCHK(hipEventSynchronize(ev));
+        pipeline_wait_impl(p, ticket);
     });
 }
 

@@ -11,6 +11,27 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// A/B switches of the kernels (environment variables, read once per process).  They exist for measurements
+// and are compiled in only with `make TUNING=1` (-DFRT_TUNING -DFRT_ABLATE); the default library ignores them and contains none
+// of the timing-ablation kernel variants (which produce wrong results by design).
+#ifdef FRT_TUNING
+#include <stdlib.h>
+inline const char *frt_tuning_env(const char *name) { return getenv(name); }
+#else
+inline const char *frt_tuning_env(const char *) { return nullptr; }
+#endif
+
+// One-time per-DEVICE setup of a kernel (hipFuncSetAttribute for > 64 KB of dynamic LDS is per device, not per process).
+constexpr int FRT_MAX_DEVICES = 32;
+inline bool frt_first_use_on_device(bool (&done)[FRT_MAX_DEVICES]) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= FRT_MAX_DEVICES - 1;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+}
+
 // ---------------------------------------------------------------- match (kernels_match.hip)
 struct MatchPartial {  // one per (workgroup, query)
     float sim;
@@ -34,6 +55,13 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
                                 int row_offset, hipStream_t s);
 // full matrix: out[F][N]
 void launch_match_full(const float *gallery, int N, int D, const float *queries, int F, float *out, hipStream_t s);
+// fp16-STORED gallery (BASELINE config 5): same kernels, rows widened exactly to fp32 while they are staged.  For the screened
+// top-1 pass gallery == nullptr and g16 = the stored rows.
+void launch_match_top1_h(const half_t *g16, int N, int D, const float *queries, int F, MatchPartial *partial, int partial_blocks,
+                         int32_t *idx_out, float *sim_out, int row_offset, hipStream_t s);
+void launch_match_full_h(const half_t *g16, int N, int D, const float *queries, int F, float *out, hipStream_t s);
+void launch_gallery_norm16(const half_t *g16, int N, int D, int *max_norm2_bits, hipStream_t s);
+void launch_rows_to_half(const float *in, half_t *out, long n8, hipStream_t s);
 
 // ---------------------------------------------------------------- post-processing (kernels_post.hip)
 struct DetGeom {

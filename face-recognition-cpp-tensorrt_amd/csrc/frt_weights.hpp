@@ -33,6 +33,11 @@ class Blob {
         std::fseek(f, 0, SEEK_END);
         long sz = std::ftell(f);
         std::fseek(f, 0, SEEK_SET);
+        if (sz < 0) {  // not seekable (directory, pipe): ftell failed
+            std::fclose(f);
+            err = "weight blob: bad magic / truncated file";
+            return 3;
+        }
         buf.resize((size_t)sz);
         size_t rd = std::fread(buf.data(), 1, (size_t)sz, f);
         std::fclose(f);
@@ -65,7 +70,7 @@ class Blob {
             std::memcpy(&off, buf.data() + p, 8);
             std::memcpy(&ne, buf.data() + p + 8, 8);
             p += 16;
-            if (off + ne * 4 > buf.size() || (off & 3)) return bad(err);
+            if ((off & 3) || off > buf.size() || ne > (buf.size() - off) / 4) return bad(err);  // (no uint64 wrap: ne is checked against the room left)
             x.data = reinterpret_cast<const float *>(buf.data() + off);
             x.numel = (size_t)ne;
             t[name] = x;

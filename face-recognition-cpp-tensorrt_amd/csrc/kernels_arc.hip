@@ -895,10 +895,9 @@ template <int WCO, int WPX>
 void launch_conv_t(const ConvMfmaArgs &a, hipStream_t s) {
     constexpr int BCO = WCO * 64, BPX = WPX * 64;
     const size_t lds = (size_t)2 * (BCO + BPX) * 64 * sizeof(half_t);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<WCO, WPX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     const int M = a.B * a.Ho * a.Wo;
     const int px_tiles = (M + BPX - 1) / BPX;
@@ -911,11 +910,10 @@ void launch_glds_t(const ConvMfmaArgs &a, hipStream_t s) {
     constexpr int BCO = WCO * 64, BPX = WPX * 64;
     const size_t lds = (size_t)NSTAGE * (BCO + BPX) * 64 * sizeof(half_t);
     static_assert(NSTAGE * (BCO + BPX) * 64 * 2 >= 4 * 32 * 68 * 4, "ring must hold the epilogue transpose buffer");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_kernel<WCO, WPX, NSTAGE, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_done = true;
     }
     const int M = a.B * a.Ho * a.Wo;
     const int px_tiles = (M + BPX - 1) / BPX;
@@ -934,13 +932,13 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     if (a.H * a.W <= 56) {
         // whole small images per strip.  4 images (7 tiles) leave 7x7x512 at 32 strips x 4 cout tiles = 128 workgroups on 256 CUs;
         // 2 images (4 tiles, NT = 4 instantiation) double the grid for the same total MFMA work
-        static const int small_nt = getenv("FRT_CONV_SMALL_NT") ? atoi(getenv("FRT_CONV_SMALL_NT")) : 4;
+        static const int small_nt = frt_tuning_env("FRT_CONV_SMALL_NT") ? atoi(frt_tuning_env("FRT_CONV_SMALL_NT")) : 4;
         n_img = (small_nt * 32) / (a.H * a.W);
         R = a.H;
     } else {
         n_img = 1;
         R = 0;
-        static const int lim14 = getenv("FRT_CONV_NT4_14") ? 128 : 224;  // experiment: half-image strips (4 tiles) on the 14x14 layers
+        static const int lim14 = frt_tuning_env("FRT_CONV_NT4_14") ? 128 : 224;  // experiment: half-image strips (4 tiles) on the 14x14 layers
         const int lim = a.H == 14 ? lim14 : 224;
         for (int d = 1; d <= a.H; ++d)
             if (a.H % d == 0 && d * a.W <= lim) R = d;
@@ -960,11 +958,10 @@ template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, 
 void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
     const size_t lds = PAIR ? (size_t)2 * 34 * 2048 : (size_t)(SINGLE ? 1 : 2) * PT * PPS * 4096;  // patch buffers only (weights live in registers)
     static_assert(PAIR || ((SINGLE ? 1 : 2) * PT * PPS * 4096 <= 160 * 1024 && PT * PPS * 4096 >= 4 * 32 * 36 * 4), "LDS budget / epilogue scratch");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_done = true;
     }
     const int strips = ((a.B + n_img - 1) / n_img) * (a.H / R);
     dim3 grid(PAIR ? (strips + 1) / 2 : strips * (a.Cout / 128));
@@ -975,7 +972,7 @@ void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
 int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage (default: 64 KB ring, 2 workgroups per CU), 3 = LDS-DMA 3-stage
     static int impl = -1;
     if (impl < 0) {
-        const char *e = getenv("FRT_CONV_IMPL");
+        const char *e = frt_tuning_env("FRT_CONV_IMPL");
         impl = e ? atoi(e) : 2;
         if (impl < 1 || impl > 3) impl = 2;
     }
@@ -988,7 +985,7 @@ int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage
 enum { CV_V1_22, CV_V1_14, CV_G2_22, CV_G2_14, CV_G3_22, CV_G3_14, CV_P_PAIR, CV_P_SINGLE, CV_P_255, CV_P_264, CV_P_255_NT4 };
 static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
     const int impl = conv_impl();
-    static const int use_patch = getenv("FRT_CONV_PATCH") ? atoi(getenv("FRT_CONV_PATCH")) : 1;
+    static const int use_patch = frt_tuning_env("FRT_CONV_PATCH") ? atoi(frt_tuning_env("FRT_CONV_PATCH")) : 1;
     int slots;
     bool single;
     if (impl >= 2 && use_patch && patch_geometry(a, R, n_img, slots, single)) {
@@ -1018,11 +1015,14 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
     if (launch_conv64(a, s)) return;  // dedicated 64 -> 64 stride-1 kernel (kernels_arc_c64.hip)
     int R = 0, n_img = 0;
     const int v = conv_variant(a, R, n_img);
-    static const int abl = getenv("FRT_CONV_ABLATE") ? atoi(getenv("FRT_CONV_ABLATE")) : 0;  // timing experiments only
+#ifdef FRT_ABLATE
+    static const int abl = frt_tuning_env("FRT_CONV_ABLATE") ? atoi(frt_tuning_env("FRT_CONV_ABLATE")) : 0;  // timing experiments only (make TUNING=1)
+#endif
     switch (v) {
         case CV_P_PAIR: return launch_patch_t<3, 5, 5, true, 0, true>(a, R, n_img, s);
         case CV_P_SINGLE: return launch_patch_t<3, 5, 5, true>(a, R, n_img, s);
         case CV_P_255:
+#ifdef FRT_ABLATE
             if (abl == 1) return launch_patch_t<2, 5, 5, false, 1>(a, R, n_img, s);
             if (abl == 2) return launch_patch_t<2, 5, 5, false, 2>(a, R, n_img, s);
             if (abl == 4) return launch_patch_t<2, 5, 5, false, 4>(a, R, n_img, s);
@@ -1042,17 +1042,22 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 22) return launch_patch_t<10, 1, 5, false, 2, false, 7, 1>(a, R, n_img, s);
             if (abl == 24) return launch_patch_t<10, 1, 5, false, 4, false, 7, 1>(a, R, n_img, s);
             if (abl == 29) return launch_patch_t<10, 1, 5, false, 9, false, 7, 1>(a, R, n_img, s);
+#endif
             return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
         case CV_P_255_NT4:
+#ifdef FRT_ABLATE
             if (abl == 11) return launch_patch_t<2, 5, 5, false, 0, false, 4>(a, R, n_img, s);
             if (abl == 19) return launch_patch_t<2, 5, 5, false, 0, false, 4, 1>(a, R, n_img, s);
+#endif
             return launch_patch_t<10, 1, 5, false, 0, false, 4, 1>(a, R, n_img, s);
         case CV_V1_22: return launch_conv_t<2, 2>(a, s);
         case CV_V1_14: return launch_conv_t<1, 4>(a, s);
         case CV_G2_22:
+#ifdef FRT_ABLATE
             if (abl == 1) return launch_glds_t<2, 2, 2, 1>(a, s);
             if (abl == 2) return launch_glds_t<2, 2, 2, 2>(a, s);
+#endif
             return launch_glds_t<2, 2, 2>(a, s);
         case CV_G2_14: return launch_glds_t<1, 4, 2>(a, s);
         case CV_G3_22: return launch_glds_t<2, 2, 3>(a, s);
@@ -1062,7 +1067,7 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
 
 void launch_arc_input(const ArcInputArgs &a, hipStream_t s) {
     static const bool use_mfma = [] {
-        const char *e = getenv("FRT_ARC_INPUT_MFMA");
+        const char *e = frt_tuning_env("FRT_ARC_INPUT_MFMA");
         return !(e && e[0] == '0');
     }();
     if (use_mfma && launch_arc_input_mfma(a, s)) return;

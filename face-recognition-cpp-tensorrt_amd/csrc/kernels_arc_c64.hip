@@ -241,7 +241,7 @@ bool conv64_applies(const ConvMfmaArgs &a) {
     if (a.Cin != 64 || a.Cout != 64 || a.ks != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if ((a.H & 1) || a.W % SW || a.mode == EPI_PARTIAL) return false;
     if (a.mode == EPI_BN_ADD_BN && !(a.sc && a.sc_stride == 1 && a.sc_h == a.H && a.sc_w == a.W)) return false;
-    static const bool off = getenv("FRT_CONV64") && getenv("FRT_CONV64")[0] == '0';
+    static const bool off = frt_tuning_env("FRT_CONV64") && frt_tuning_env("FRT_CONV64")[0] == '0';
     return !off;
 }
 
@@ -250,20 +250,22 @@ bool launch_conv64(const ConvMfmaArgs &a, hipStream_t s) {
     if (a.Cin != 64 || a.Cout != 64 || a.ks != 3 || a.stride != 1 || a.pad != 1 || a.Ho != a.H || a.Wo != a.W) return false;
     if ((a.H & 1) || a.W % SW || a.mode == EPI_PARTIAL) return false;
     if (a.mode == EPI_BN_ADD_BN && !(a.sc && a.sc_stride == 1 && a.sc_h == a.H && a.sc_w == a.W)) return false;
-    static const bool off = getenv("FRT_CONV64") && getenv("FRT_CONV64")[0] == '0';
+    static const bool off = frt_tuning_env("FRT_CONV64") && frt_tuning_env("FRT_CONV64")[0] == '0';
     if (off) return false;
     const int n_strips = a.B * (a.H / 2) * (a.W / SW);
     int grid = 512;
     if (grid > n_strips) grid = n_strips;
     const size_t lds = 2 * PATCH_B + 2 * 32 * EROW * sizeof(float);
-    static const int abl = getenv("FRT_C64_ABLATE") ? atoi(getenv("FRT_C64_ABLATE")) : 0;  // measurement only: 1 no B reads, 2 no MFMA, 4 no epilogue
-    static bool attr_done = false;
-    if (!attr_done) {  // > 64 KB of dynamic LDS needs the opt-in
+#ifdef FRT_ABLATE
+    static const int abl = frt_tuning_env("FRT_C64_ABLATE") ? atoi(frt_tuning_env("FRT_C64_ABLATE")) : 0;  // measurement only: 1 no B reads, 2 no MFMA, 4 no epilogue
+#endif
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done)) {  // > 64 KB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_PRELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv64_kernel<EPI_BN_ADD_BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
+#ifdef FRT_ABLATE
     if (abl && a.mode == EPI_PRELU) {
         static bool ad = false;
         if (!ad) {
@@ -281,6 +283,7 @@ bool launch_conv64(const ConvMfmaArgs &a, hipStream_t s) {
         else hipLaunchKernelGGL((conv64_kernel<EPI_PRELU, 7>), dim3(grid), dim3(128), lds, s, a, n_strips);
         return true;
     }
+#endif
     switch (a.mode) {
         case EPI_PRELU: hipLaunchKernelGGL((conv64_kernel<EPI_PRELU>), dim3(grid), dim3(128), lds, s, a, n_strips); break;
         case EPI_BN: hipLaunchKernelGGL((conv64_kernel<EPI_BN>), dim3(grid), dim3(128), lds, s, a, n_strips); break;

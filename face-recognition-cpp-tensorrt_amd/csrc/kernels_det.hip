@@ -490,7 +490,7 @@ void launch_pw(const DwPwArgs &a, hipStream_t s) {
 
 bool det_mfma_enabled() {
     static const bool use_mfma = [] {
-        const char *e = getenv("FRT_DET_MFMA");
+        const char *e = frt_tuning_env("FRT_DET_MFMA");
         return !(e && e[0] == '0');
     }();
     return use_mfma;
@@ -502,7 +502,7 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
     const long total = (long)a.B * a.Ho * a.Wo;
     const long blocks = (total + 255) / 256;
     // stride-1 blocks whose one channel tile covers every output channel: four pixels of a row per thread
-    static const bool row4 = !(getenv("FRT_DWPW_ROW4") && getenv("FRT_DWPW_ROW4")[0] == '0');
+    static const bool row4 = !(frt_tuning_env("FRT_DWPW_ROW4") && frt_tuning_env("FRT_DWPW_ROW4")[0] == '0');
     if (row4 && a.stride == 1 && !a.add && a.H == a.Ho && a.W == a.Wo && a.W % 4 == 0 && (a.Cout == 16 || a.Cout == 32) && a.Cin <= 64) {
         const long threads = (long)a.B * a.H * (a.W / 4);
         const dim3 grid((unsigned)((threads + 255) / 256));
@@ -561,7 +561,7 @@ void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s) {
 void launch_conv3x3(const Conv3Args &a, hipStream_t s) { launch_conv3x3_multi(&a, 1, s); }
 
 bool launch_det_conv1_u8(const uint8_t *frames, size_t row_stride, size_t frame_stride, const Conv3Args &a, hipStream_t s) {
-    if (a.Cin != 3 || a.Cout != 8 || a.stride != 2 || getenv("FRT_DET_NO_FUSED_INPUT")) return false;
+    if (a.Cin != 3 || a.Cout != 8 || a.stride != 2 || frt_tuning_env("FRT_DET_NO_FUSED_INPUT")) return false;
     const long total = (long)a.B * a.Ho * a.Wo;
     hipLaunchKernelGGL(det_conv1_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, row_stride, frame_stride, a);
     return true;

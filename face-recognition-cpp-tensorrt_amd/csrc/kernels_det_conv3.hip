@@ -292,12 +292,12 @@ bool launch_conv3x3_mfma(const Conv3Args *a, int n, hipStream_t s) {
     const int cin = a[0].Cin, cout = a[0].Cout;
     const int kc = cin == 16 ? 16 : 32;
     // 16 -> 16 convs: 8 MFMAs per step cannot hide a step's fixed costs (measured 51 us against 31 us for the scalar kernel)
-    if (cin == 16 && !getenv("FRT_C3_FORCE16")) return false;
+    if (cin == 16 && !frt_tuning_env("FRT_C3_FORCE16")) return false;
     if (cout > 64 || cout < 16 || cin % kc || a[0].wm_kc != kc) return false;
     const int cb = cout > 32 ? 2 : 1;
     if (a[0].wm_cpad != cb * 32) return false;
     static const int wg_per_cu = [] {
-        const char *e = getenv("FRT_C3_WG_PER_CU");
+        const char *e = frt_tuning_env("FRT_C3_WG_PER_CU");
         return e ? atoi(e) : 2;
     }();
     int grid = 256 * wg_per_cu;

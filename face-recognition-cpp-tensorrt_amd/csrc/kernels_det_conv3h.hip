@@ -245,9 +245,9 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
 
 // Up to 3 same-shaped stride-1 problems with Cin == 64 in one launch.  false: shape not covered / split weights absent.
 bool launch_conv3x3_split(const Conv3Args *a, int n, hipStream_t s) {
-    static const bool off = getenv("FRT_DET_SPLIT") && getenv("FRT_DET_SPLIT")[0] == '0';
+    static const bool off = frt_tuning_env("FRT_DET_SPLIT") && frt_tuning_env("FRT_DET_SPLIT")[0] == '0';
     if (off || n < 1 || n > 3) return false;
-    static const int pbw = getenv("FRT_DET_SPLIT_PBW") ? atoi(getenv("FRT_DET_SPLIT_PBW")) : 1;
+    static const int pbw = frt_tuning_env("FRT_DET_SPLIT_PBW") ? atoi(frt_tuning_env("FRT_DET_SPLIT_PBW")) : 1;
     const int th = 8 * pbw;
     Conv3H mm;
     int base = 0;
@@ -263,11 +263,10 @@ bool launch_conv3x3_split(const Conv3Args *a, int n, hipStream_t s) {
     }
     for (int i = n; i < 4; ++i) mm.base[i] = base;
     const size_t lds = (size_t)(2 * (th + 2) * PS * ROWH + WCH_H) * sizeof(half_t);  // 75 KB (two workgroups per CU) / 98 KB
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        attr_done = true;
     }
     int grid = pbw == 1 ? 512 : 256;
     if (grid > base) grid = base;

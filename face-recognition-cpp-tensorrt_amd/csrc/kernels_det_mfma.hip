@@ -415,7 +415,7 @@ void launch_fused(const DwPwArgs &a, hipStream_t s) {
     }
     const unsigned cgroups = (unsigned)((a.Cout + 32 * NCW * CBW - 1) / (32 * NCW * CBW));
     const dim3 grid((unsigned)nblocks, cgroups);
-    static const bool split = !(getenv("FRT_DET_PW_SPLIT") && getenv("FRT_DET_PW_SPLIT")[0] == '0');
+    static const bool split = !(frt_tuning_env("FRT_DET_PW_SPLIT") && frt_tuning_env("FRT_DET_PW_SPLIT")[0] == '0');
     if constexpr (KC == 32) {  // (the 16-channel block with 128-pixel tiles measured slower split: 113 vs 108 us, scattered 2-byte LDS stores)
         if (split && a.wph) {  // pointwise product on the fp16 matrix cores (hi/lo split, fp32-class accuracy)
             const size_t ldsh = (size_t)2 * TP * (2 * KC + 8) * sizeof(half_t);
@@ -448,7 +448,7 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
         const int n_cgroups = (a.Cout + cbw * 32 - 1) / (cbw * 32);
         const long waves = (long)n_pix_groups * n_cgroups;
         const unsigned grid = (unsigned)((waves + 3) / 4);
-        static const bool split = !(getenv("FRT_DET_PW_SPLIT") && getenv("FRT_DET_PW_SPLIT")[0] == '0');
+        static const bool split = !(frt_tuning_env("FRT_DET_PW_SPLIT") && frt_tuning_env("FRT_DET_PW_SPLIT")[0] == '0');
         if (split && a.wph && a.Cin % 16 == 0) {
             if (wide) hipLaunchKernelGGL((pw_mfma_kernel<2, true>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
             else hipLaunchKernelGGL((pw_mfma_kernel<1, true>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
@@ -467,7 +467,7 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
     // everything else is faster here (16->32/2: 145 vs 100, 64->64 @80^2: 169 vs 70, 128->128 @40^2: 77 vs 59).
     // (A persistent, 3-stage software-pipelined variant of this kernel was also tried: slower on every block - fewer, fatter
     // waves hide the load latency worse than three small resident workgroups per CU do.)
-    if (a.Cout <= 32 && a.Cin <= 32 && a.stride == 1 && !getenv("FRT_DWPW_FORCE_MFMA")) return false;
+    if (a.Cout <= 32 && a.Cin <= 32 && a.stride == 1 && !frt_tuning_env("FRT_DWPW_FORCE_MFMA")) return false;
     const long total = (long)a.B * a.Ho * a.Wo;
     const bool big = a.Wo >= 64 && (a.Wo % 16) == 0 && (a.Ho % 8) == 0;
     if (a.Cout <= 32) {
@@ -479,14 +479,14 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
     }
     if (a.Cin % 32) return false;
     if (a.Cout == 64 && total >= 128L * 512) {
-        static const int c64 = getenv("FRT_DWPW_C64") ? atoi(getenv("FRT_DWPW_C64")) : 1;  // measured: 64-px linear tiles, 2x2 waves: 46/60 us vs 54/71 for 8x16 tiles
+        static const int c64 = frt_tuning_env("FRT_DWPW_C64") ? atoi(frt_tuning_env("FRT_DWPW_C64")) : 1;  // measured: 64-px linear tiles, 2x2 waves: 46/60 us vs 54/71 for 8x16 tiles
         if (c64 == 1) launch_fused<2, 2, 32, 1, false>(a, s);
         else if (c64 == 2) launch_fused<1, 2, 32, 1, false>(a, s);
         else if (c64 == 3) big ? launch_fused<4, 1, 16, 2, true>(a, s) : launch_fused<4, 1, 16, 2, false>(a, s);
         else big ? launch_fused<4, 1, 32, 2, true>(a, s) : launch_fused<4, 1, 32, 2, false>(a, s);
     } else if (a.Cout == 128 || (a.Cout == 64)) {
         if (a.Cout == 128) {
-            static const int small = getenv("FRT_DWPW_SMALL") ? atoi(getenv("FRT_DWPW_SMALL")) : 1;
+            static const int small = frt_tuning_env("FRT_DWPW_SMALL") ? atoi(frt_tuning_env("FRT_DWPW_SMALL")) : 1;
             if (small == 1) launch_fused<1, 4, 32, 1, false>(a, s);  // (KC = 64, half as many rounds, measured 52 vs 46 us: registers)
             else if (small == 2) launch_fused<1, 2, 32, 2, false>(a, s);
             else if (small == 3) launch_fused<1, 2, 32, 1, false>(a, s);
@@ -494,7 +494,7 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
         }
         else launch_fused<2, 2, 32, 1, false>(a, s);
     } else if (a.Cout == 256) {
-        static const int small = getenv("FRT_DWPW_SMALL") ? atoi(getenv("FRT_DWPW_SMALL")) : 1;
+        static const int small = frt_tuning_env("FRT_DWPW_SMALL") ? atoi(frt_tuning_env("FRT_DWPW_SMALL")) : 1;
         if (small == 2) launch_fused<1, 2, 32, 2, false>(a, s);
         else if (small == 3) launch_fused<1, 2, 32, 1, false>(a, s);
         else launch_fused<1, 4, 32, 2, false>(a, s);

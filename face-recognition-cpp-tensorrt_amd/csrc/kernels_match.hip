@@ -28,8 +28,16 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return (v > bv) || (v == bv && i < bi); }
 
-template <int NQ, bool FULL>
-__global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ G, int N, int D, const float *__restrict__ E, int F,
+// GT: storage type of the gallery rows (float: the reference's layout; half_t: fp16-stored shard, BASELINE config 5 - the stored
+// values are widened exactly to fp32 on the way into LDS, all arithmetic stays the same fp32 fmaf chain).
+__device__ __forceinline__ floatx4 load_row4(const float *p) { return *reinterpret_cast<const floatx4 *>(p); }
+__device__ __forceinline__ floatx4 load_row4(const half_t *p) {
+    const half4 h = *reinterpret_cast<const half4 *>(p);
+    return floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+template <int NQ, bool FULL, typename GT = float>
+__global__ __launch_bounds__(256) void match_kernel(const GT *__restrict__ G, int N, int D, const float *__restrict__ E, int F,
                                                     MatchPartial *__restrict__ partial, float *__restrict__ out_full, int num_tiles,
                                                     int row_offset, const int *__restrict__ tile_list, const int *__restrict__ d_num_tiles) {
     // tile_list != nullptr: run only over the listed 128-row gallery tiles (num_tiles = list length): the exact re-rank pass of
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(256) void match_kernel(const float *__restrict__ G,
         for (int i = 0; i < 4; ++i) {
             const int row = ld_row + 32 * i;
             const long g = (long)tile * BM + row;
-            ga[i] = g < N ? *reinterpret_cast<const floatx4 *>(G + g * D + k0 + ld_ch * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+            ga[i] = g < N ? load_row4(G + g * D + k0 + ld_ch * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
@@ -244,11 +252,12 @@ __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ 
 }
 
 // max over rows of ||g||^2 (non-negative floats order like their bit patterns -> atomicMax on the int view); one wave per row
-__global__ __launch_bounds__(256) void row_norm_max_kernel(const float *__restrict__ G, int N, int D, int *__restrict__ out_bits) {
+template <typename GT>
+__global__ __launch_bounds__(256) void row_norm_max_kernel(const GT *__restrict__ G, int N, int D, int *__restrict__ out_bits) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     float s = 0.f;
     for (int k = lane * 4; k < D && row < N; k += 256) {
-        const floatx4 v = *reinterpret_cast<const floatx4 *>(G + (long)row * D + k);
+        const floatx4 v = load_row4(G + (long)row * D + k);
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
@@ -454,18 +463,17 @@ __global__ __launch_bounds__(256) void match_select_kernel(const float *__restri
         if (!(row[t] < thr) && atomicExch(&tile_flags[t / sub], 1) == 0) tile_list[atomicAdd(count, 1)] = t / sub;
 }
 
-template <int NQ, bool FULL>
-void launch_t(const float *G, int N, int D, const float *E, int F, MatchPartial *partial, float *out_full, int blocks, int row_offset,
+template <int NQ, bool FULL, typename GT = float>
+void launch_t(const GT *G, int N, int D, const float *E, int F, MatchPartial *partial, float *out_full, int blocks, int row_offset,
               hipStream_t s, const int *tile_list = nullptr, const int *d_num_tiles = nullptr) {
     const int tiles = (N + BM - 1) / BM;
     const size_t lds = (size_t)2 * (BM + NQ * 32) * BK * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<NQ, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<NQ, FULL, GT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     dim3 grid(blocks, (F + NQ * 32 - 1) / (NQ * 32));
-    hipLaunchKernelGGL((match_kernel<NQ, FULL>), grid, dim3(256), lds, s, G, N, D, E, F, partial, out_full, tiles, row_offset, tile_list, d_num_tiles);
+    hipLaunchKernelGGL((match_kernel<NQ, FULL, GT>), grid, dim3(256), lds, s, G, N, D, E, F, partial, out_full, tiles, row_offset, tile_list, d_num_tiles);
 }
 
 }  // namespace
@@ -488,6 +496,25 @@ void launch_match_top1(const float *gallery, int N, int D, const float *queries,
     hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out);
 }
 
+void launch_match_top1_h(const half_t *g16, int N, int D, const float *queries, int F, MatchPartial *partial, int partial_blocks,
+                         int32_t *idx_out, float *sim_out, int row_offset, hipStream_t s) {
+    if (F <= 32)
+        launch_t<1, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
+    else if (F <= 64)
+        launch_t<2, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
+    else
+        launch_t<4, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out);
+}
+
+void launch_match_full_h(const half_t *g16, int N, int D, const float *queries, int F, float *out, hipStream_t s) {
+    const int blocks = match_top1_blocks(N, F);
+    if (F <= 32)
+        launch_t<1, true, half_t>(g16, N, D, queries, F, nullptr, out, blocks, 0, s);
+    else
+        launch_t<4, true, half_t>(g16, N, D, queries, F, nullptr, out, blocks, 0, s);
+}
+
 void launch_match_full(const float *gallery, int N, int D, const float *queries, int F, float *out, hipStream_t s) {
     const int blocks = match_top1_blocks(N, F);
     if (F <= 32)
@@ -501,7 +528,17 @@ void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int 
     (void)hipMemsetAsync(max_norm2_bits, 0, sizeof(int), s);
     const long n8 = (long)N * D / 8;
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, gallery, g16, n8, (int *)nullptr, 0L);
-    hipLaunchKernelGGL(row_norm_max_kernel, dim3((N + 3) / 4), dim3(256), 0, s, gallery, N, D, max_norm2_bits);
+    hipLaunchKernelGGL(row_norm_max_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, gallery, N, D, max_norm2_bits);
+}
+
+// fp16-STORED gallery (no fp32 copy on the device): only the largest row norm is needed, the stored rows are their own shadow
+void launch_gallery_norm16(const half_t *g16, int N, int D, int *max_norm2_bits, hipStream_t s) {
+    (void)hipMemsetAsync(max_norm2_bits, 0, sizeof(int), s);
+    hipLaunchKernelGGL(row_norm_max_kernel<half_t>, dim3((N + 3) / 4), dim3(256), 0, s, g16, N, D, max_norm2_bits);
+}
+// fp32 rows (device) -> fp16 rows; n8 = elements / 8
+void launch_rows_to_half(const float *in, half_t *out, long n8, hipStream_t s) {
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, in, out, n8, (int *)nullptr, 0L);
 }
 
 void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
@@ -513,10 +550,9 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
     const long n_thr = q8 > nzero ? q8 : nzero;
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, queries, w.q16, q8, w.tile_flags, nzero);
     const size_t lds = (size_t)4 * 128 * CBK * sizeof(half_t) + 4 * 128 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     // Both coarse kernels stream the 1 GB fp16 shadow at 4.0 TB/s (251 vs 258 us at N = 1M, F = 128; the HBM pipe is the limit:
     // 128 KB per CU in flight for ~8 us).  v1 stays the default, v2 (FRT_MATCH_COARSE_V2=1) is the simpler memory path.
@@ -525,10 +561,9 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
     if (D == 512 && coarse_v2) {
         coarse_sub = 4;
         const size_t lds2 = (size_t)128 * (512 + 8) * sizeof(half_t);
-        static bool attr2_done = false;
-        if (!attr2_done) {
+        static bool attr2_done[FRT_MAX_DEVICES] = {};
+        if (frt_first_use_on_device(attr2_done)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            attr2_done = true;
         }
         dim3 g2(tiles < 256 ? tiles : 256, (F + 127) / 128);
         hipLaunchKernelGGL((match_coarse2_kernel<512>), g2, dim3(256), lds2, s, g16, N, w.q16, F, w.tilemax, tiles);
@@ -542,6 +577,9 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
     // 32 queries per workgroup (grid.y = query blocks): the list is short (a few hundred tiles), so the pass is bound by the
     // time ONE workgroup needs for a tile - 1024 fp32 MFMAs per wave with 128 queries (27 us), 256 with 32 (7 us).  Same
     // per-(row, query) arithmetic as the full scan, hence still bit-identical.
-    launch_t<1, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
+    if (gallery)
+        launch_t<1, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
+    else  // fp16-stored gallery: the exact pass widens the stored rows (same per-tile code path as launch_match_top1_h's full scan)
+        launch_t<1, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
     hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out);
 }

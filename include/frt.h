@@ -8,8 +8,11 @@
  *
  * Conventions: plain pointers and sizes only; opaque handles; every function returns an frt_status (0 = ok) and
  * leaves a message retrievable with frt_last_error() (thread-local).  Host pointers unless the name ends in "_dev".
- * Objects serialise their own device work with a per-object mutex (the reference objects are not thread-safe although
- * the Crow server is multithreaded, src/app.cpp:367); distinct objects may be used concurrently.
+ * Threading (the reference objects are not thread-safe although the Crow server is multithreaded, src/app.cpp:367): every
+ * object has a mutex around its entry points and object-level calls are synchronous; a pipeline borrows its three objects, takes
+ * their mutexes while it enqueues, and leaves an event behind each stage that later object-level calls on the same object wait
+ * for on the device - so object-level calls, frt_pipeline_run from several threads, and pipelined batches in flight may be
+ * mixed freely.  Distinct objects may be used concurrently.
  *
  * Axis naming follows the reference: Bbox.x* are ROWS, Bbox.y* are COLUMNS (src/retinaface.cpp:165).
  */
@@ -119,11 +122,32 @@ void frt_matcher_destroy(frt_matcher *m);
 /* MatMul::init (src/matmul.cpp:9-34): gallery A[num_row][num_col] row-major fp32, copied to the device.  Idempotent:
  * a second call frees the previous device copy (the reference leaks it on every /reload). */
 int frt_matcher_init(frt_matcher *m, const float *gallery, int num_row, int num_col);
+/* Storage precision of the gallery rows for the NEXT frt_matcher_init / frt_matcher_gallery_begin: 0 = fp32 rows (default; the
+ * reference's MatMul), 1 = rows stored as fp16 on the device (BASELINE config 5, "fp16 embeddings": half the HBM bytes per scan
+ * and per GPU).  With fp16 storage the similarities are DEFINED as the fp32 dot products with the fp16-rounded rows
+ * (sum_k e[k] * float(half(g[k])), fp32 fmaf chain) - calculate / top1 / the pipeline all agree on them bit for bit. */
+int frt_matcher_set_storage(frt_matcher *m, int fp16);
+/* Streaming gallery load == the loop of Database::getEmbeddings (src/db.cpp:316-346):
+ *   initKnownEmbeds(n)            -> frt_matcher_gallery_begin(m, n, 512)
+ *   addEmbedding(id, blob) x n    -> frt_matcher_gallery_append(m, blob, 1)     (blob = sqlite3_column_blob: raw little-endian
+ *                                    float32[num_col]; any number of consecutive rows per call; copied before the call returns)
+ *   initMatMul()                  -> frt_matcher_gallery_commit(m)
+ * Rows are staged in pinned host chunks and uploaded asynchronously while the caller fetches the next ones; the previous gallery
+ * stays searchable until commit swaps it (and frees it: the reference leaks both copies on every /reload).  commit with fewer
+ * rows than reserved is fine (the count actually appended becomes num_row); appending more is FRT_ERR_CAPACITY. */
+int frt_matcher_gallery_begin(frt_matcher *m, int row_capacity, int num_col);
+int frt_matcher_gallery_append(frt_matcher *m, const void *rows, int n_rows);
+int frt_matcher_gallery_commit(frt_matcher *m);
+int frt_matcher_num_rows(const frt_matcher *m);
 /* MatMul::calculate (src/matmul.cpp:36-77): outputs[i*num_row + j] = sum_k embeds[i][k] * gallery[j][k], fp32. */
 int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, float *outputs);
 /* Fused calculate + getOutputs argmax: idx_out[i] = FIRST j maximising the similarity (std::max_element semantics),
  * sim_out[i] = that similarity.  Never materialises the [n x num_row] matrix. */
 int frt_matcher_top1(frt_matcher *m, const float *embeds, int embed_count, int32_t *idx_out, float *sim_out);
+/* frt_matcher_top1 with everything resident in HBM, asynchronous on hip_stream (a hipStream_t as void*, NULL = default stream):
+ * queries [n][num_col] fp32, idx_dev int32 [n], sim_dev fp32 [n].  The sharded-gallery path (dist.py) feeds it the RCCL
+ * all-gathered embeddings without a host round trip. */
+int frt_matcher_top1_dev(frt_matcher *m, const void *embeds_dev, int embed_count, void *idx_dev, void *sim_dev, void *hip_stream);
 /* Sharded galleries: declare that local row 0 of this matcher is global row `row_offset`; top-1
  * indices (frt_matcher_top1, the pipeline's match_idx) are then global.  The full matrix of calculate() stays local. */
 int frt_matcher_set_row_offset(frt_matcher *m, int row_offset);
@@ -157,12 +181,21 @@ int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_f
  * ticket; wait(ticket) blocks until that batch's outputs are in host memory.  All three host buffers must stay valid and
  * untouched until wait() returns, and should be pinned (hipHostMalloc / hipHostRegister): with pageable memory the copies
  * degrade to synchronous ones.  Up to 4 batches may be in flight; a 5th submit() first waits for the oldest.  Tickets complete
- * in order.  Not to be mixed with frt_pipeline_run_dev calls in flight on the same pipeline. */
+ * in order.  frt_pipeline_run (below the same path: submit + wait) may be called from several threads at once. */
 int frt_pipeline_submit(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, long *ticket_out);
 int frt_pipeline_wait(frt_pipeline *p, long ticket);
 /* Same with everything resident in HBM: frames_dev u8 [n_frames][rows][cols][3]; results_dev / embeds_dev device
  * buffers (embeds_dev may be NULL).  Asynchronous on the pipeline stream; frt_pipeline_sync() waits. */
 int frt_pipeline_run_dev(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev);
+/* Same, ordered behind the caller's producer: ready_event is a hipEvent_t (as void*) the caller recorded after the work that
+ * writes frames_dev (an upload, frt_jpeg_decode_batch_dev, frt_resize_frames_dev ... on ANY stream); the stages wait for it on the
+ * device.  This is the form to use when the frames are produced asynchronously: with software pipelining on, plain
+ * frt_pipeline_run_dev does not wait for earlier work on the pipeline stream (see frt_pipeline_set_overlap). */
+int frt_pipeline_run_dev_after(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev, void *ready_event);
+/* Safe mode for callers that produce the frames on the pipeline stream itself: every frt_pipeline_run_dev call first records an
+ * event on that stream and the stages wait for it.  Correct by construction, but the pipeline stream also carries the joins of the
+ * previous calls, so consecutive calls no longer overlap - prefer frt_pipeline_run_dev_after with a separate upload stream. */
+int frt_pipeline_set_input_sync(frt_pipeline *p, int enable);
 int frt_pipeline_sync(frt_pipeline *p);
 /* Run on a caller-owned HIP stream (a hipStream_t passed as void*, e.g. PyTorch's current stream, so that RCCL collectives
  * issued by the caller are ordered after the pipeline without a host synchronisation).  NULL restores the private stream. */

@@ -43,7 +43,18 @@ inline void getCroppedFaces(cv::Mat frame, std::vector<struct Bbox> &outputBbox,
     }
 }
 
-class ArcFaceIR50 {
+// `static int classCount` of the reference (src/arcface.h:39, defined once in src/arcface.cpp:19).  This shell is header-only and
+// the reference includes arcface.h from two translation units (src/app.cpp:3 and src/db.cpp via src/db.h:8), so the definition
+// has to be ODR-safe in C++11 (no inline variables): a static data member of a class TEMPLATE may be defined in a header, and
+// ArcFaceIR50 inherits it - `ArcFaceIR50::classCount` / `recognizer.classCount` keep working unchanged.
+template <class Tag = void>
+struct ArcFaceIR50Statics {
+    static int classCount;  // process-wide, as in the reference
+};
+template <class Tag>
+int ArcFaceIR50Statics<Tag>::classCount = 0;
+
+class ArcFaceIR50 : public ArcFaceIR50Statics<> {
   public:
     ArcFaceIR50(TRTLogger gLogger, const std::string engineFile, int frameWidth, int frameHeight, std::string inputName, std::string outputName,
                 std::vector<int> inputShape, int outputDim, int maxBatchSize, int maxFacesPerScene, float knownPersonThreshold, int device = 0)
@@ -73,25 +84,30 @@ class ArcFaceIR50 {
     void doInference(float *input, float *output) { checkFrtStatus(frt_embedder_infer(h_, input, 1, output)); }                          // arcface.cpp:131-137
     void doInference(float *input, float *output, int batchSize) { checkFrtStatus(frt_embedder_infer(h_, input, batchSize, output)); }  // arcface.cpp:139-148
 
+    // Gallery management (src/arcface.cpp:150-164, :233-236).  The reference keeps a host array m_knownEmbeds (new float[num*D], never
+    // freed) and uploads it in initMatMul; here every row goes straight into libfrt's pinned staging chunks and on to the device
+    // while the caller (Database::getEmbeddings, src/db.cpp:316-346) fetches the next one - no second 2 GB host copy, no leak on
+    // /reload, and the previous gallery stays searchable until initMatMul() swaps the new one in.
     void addEmbedding(const std::string className, float embedding[]) {  // arcface.cpp:150-154 (copies immediately: db.cpp:339 passes a blob pointer)
+        matmul.galleryAppend(embedding, 1);
         classNames.push_back(className);
-        std::copy(embedding, embedding + m_OUTPUT_D, m_knownEmbeds.begin() + (size_t)classCount * m_OUTPUT_D);
         classCount++;
     }
     void addEmbedding(const std::string className, std::vector<float> embedding) {  // arcface.cpp:156-160
+        assert((int)embedding.size() == m_OUTPUT_D);
+        matmul.galleryAppend(embedding.data(), 1);
         classNames.push_back(className);
-        std::copy(embedding.begin(), embedding.end(), m_knownEmbeds.begin() + (size_t)classCount * m_OUTPUT_D);
         classCount++;
     }
-    // Extension: bulk enrolment (one copy instead of one call per row; db.cpp:339's loop collapses to this)
+    // Extension: bulk enrolment (one call for n rows; db.cpp:339's loop collapses to this)
     void addEmbeddings(const std::vector<std::string> &names, const float *embeddings) {
+        matmul.galleryAppend(embeddings, (int)names.size());
         classNames.insert(classNames.end(), names.begin(), names.end());
-        std::copy(embeddings, embeddings + names.size() * (size_t)m_OUTPUT_D, m_knownEmbeds.begin() + (size_t)classCount * m_OUTPUT_D);
         classCount += (int)names.size();
     }
-    void initKnownEmbeds(int num) { m_knownEmbeds.assign((size_t)num * m_OUTPUT_D, 0.f); }  // arcface.cpp:162
-    void initMatMul() { matmul.init(m_knownEmbeds.data(), classCount, m_OUTPUT_D); }       // arcface.cpp:164
-    void resetEmbeddings() {                                                                // arcface.cpp:233-236
+    void initKnownEmbeds(int num) { matmul.galleryBegin(num, m_OUTPUT_D); }  // arcface.cpp:162
+    void initMatMul() { matmul.galleryCommit(); }                            // arcface.cpp:164
+    void resetEmbeddings() {                                                  // arcface.cpp:233-236
         classCount = 0;
         classNames.clear();
     }
@@ -193,19 +209,15 @@ class ArcFaceIR50 {
     MatMul &matcher() { return matmul; }
 
     std::vector<struct CroppedFace> croppedFaces;
-    static int classCount;  // process-wide, as in the reference (src/arcface.h:39, arcface.cpp:19)
+    // static int classCount: inherited from ArcFaceIR50Statics<> above (src/arcface.h:39, arcface.cpp:19)
 
   private:
     frt_embedder *h_;
     int m_frameWidth, m_frameHeight, m_INPUT_C, m_INPUT_H, m_INPUT_W, m_OUTPUT_D, m_maxBatchSize, m_maxFacesPerScene;
     float m_knownPersonThresh;
-    std::vector<float> m_embeds, m_knownEmbeds, m_outputs;
+    std::vector<float> m_embeds, m_outputs;
     std::vector<std::string> classNames;
     MatMul matmul;
 };
-
-#ifndef FRT_ARCFACE_NO_STATIC_DEFINITION
-int ArcFaceIR50::classCount = 0;  // define FRT_ARCFACE_NO_STATIC_DEFINITION in all but one translation unit
-#endif
 
 #endif  // FRT_ARCFACE_H

@@ -22,6 +22,20 @@ class MatMul {
         ensure();
         checkFrtStatus(frt_matcher_calculate(h_, embeds, embedCount, outputs));
     }
+    // Extension: streaming load (== initKnownEmbeds / addEmbedding x n / initMatMul without a host copy of the gallery): rows go
+    // through pinned staging chunks to the device while the caller fetches the next ones (src/db.cpp:316-346)
+    void galleryBegin(int rowCapacity, int numCol) {
+        ensure();
+        checkFrtStatus(frt_matcher_gallery_begin(h_, rowCapacity, numCol));
+    }
+    void galleryAppend(const float *rows, int n) { checkFrtStatus(frt_matcher_gallery_append(h_, rows, n)); }
+    void galleryCommit() { checkFrtStatus(frt_matcher_gallery_commit(h_)); }
+    int numRows() const { return frt_matcher_num_rows(h_); }
+    // Extension: store the gallery rows as fp16 on the device (next init / galleryBegin); see frt_matcher_set_storage
+    void setStorageFp16(bool on) {
+        ensure();
+        checkFrtStatus(frt_matcher_set_storage(h_, on ? 1 : 0));
+    }
     // Extension: fused argmax (what ArcFaceIR50::getOutputs computes from the full matrix), never materialises [n x numRow].
     void top1(float *embeds, int embedCount, int *idx, float *sim) {
         ensure();

@@ -1,12 +1,14 @@
 // The reference's /inference call sequence (src/app.cpp:304-310) written against the drop-in shells, compiled with
-// g++ -std=c++11 exactly like reference application code would be.  Usage:
-//   dropin_demo <det.frtw> <rec.frtw> <frame.bin (u8 BGR HWC)> <rows> <cols> <gallery.bin (fp32 [n][512])> <n>
+// g++ -std=c++11 exactly like reference application code would be; dropin_db.cpp is the second translation unit (the reference
+// links app.cpp + db.cpp, both of which include arcface.h).  Usage:
+//   dropin_demo <det.frtw> <rec.frtw> <frame.bin (u8 BGR HWC)> <rows> <cols> <gallery.bin (fp32 [n][512]) | gallery.db (SQLite)> <n>
 // Prints one line per face: x1 y1 x2 y2 score argmax sim   (argmax = gallery row of the best match)
 // With a single argument "--selftest" it only exercises the no-GPU error paths.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 
+#include "dropin_db.h"
 #include "frt/arcface.h"
 #include "frt/retinaface.h"
 
@@ -30,8 +32,12 @@ int main(int argc, char **argv) {
             ok += std::string(e.what()) == "Cant find engine file";  // src/arcface.cpp:67
         }
         static_assert(sizeof(Bbox) == 20, "Bbox layout");
-        std::printf("selftest %s\n", ok == 2 ? "ok" : "FAILED");
-        return ok == 2 ? 0 : 1;
+        // one process-wide classCount, shared by both translation units (src/arcface.h:39, src/arcface.cpp:19)
+        ArcFaceIR50::classCount = 41;
+        ok += Database::classCountSeenFromDbTU() == 41;
+        ArcFaceIR50::classCount = 0;
+        std::printf("selftest %s\n", ok == 3 ? "ok" : "FAILED");
+        return ok == 3 ? 0 : 1;
     }
     if (argc != 8) return 2;
     const int rows = std::atoi(argv[4]), cols = std::atoi(argv[5]), n = std::atoi(argv[7]);
@@ -40,11 +46,24 @@ int main(int argc, char **argv) {
     // construction as in src/app.cpp:52-57
     RetinaFace detector(gLogger, argv[1], cols, rows, "input_det", {"output_det0", "output_det1"}, {3, rows, cols}, 1, 4, 0.4f, 0.6f);
     ArcFaceIR50 recognizer(gLogger, argv[2], cols, rows, "input", "output", {3, 112, 112}, 512, 1, 4, 0.65f);
-    // gallery load as in src/db.cpp:326-340
-    recognizer.initKnownEmbeds(n);
-    const float *g = reinterpret_cast<const float *>(gb.data());
-    for (int i = 0; i < n; ++i) recognizer.addEmbedding(std::to_string(i), const_cast<float *>(g + (size_t)i * 512));
-    recognizer.initMatMul();
+    const std::string gpath(argv[6]);
+    if (gpath.size() > 3 && gpath.compare(gpath.size() - 3, 3, ".db") == 0) {
+        // start-up as in src/app.cpp:62,101-105: the database TU feeds the recogniser row by row from SQLite's blob buffer
+        Database db(gpath, 512);
+        if (db.getEmbeddings(recognizer) != 0) return 5;
+        if (ArcFaceIR50::classCount != n || Database::classCountSeenFromDbTU() != n) return 6;
+        recognizer.initMatMul();
+        // /reload as in src/app.cpp:354-365 (must not leak or break the matcher)
+        recognizer.resetEmbeddings();
+        if (db.getEmbeddings(recognizer) != 0) return 5;
+        recognizer.initMatMul();
+    } else {
+        // gallery load as in src/db.cpp:326-340
+        recognizer.initKnownEmbeds(n);
+        const float *g = reinterpret_cast<const float *>(gb.data());
+        for (int i = 0; i < n; ++i) recognizer.addEmbedding(std::to_string(i), const_cast<float *>(g + (size_t)i * 512));
+        recognizer.initMatMul();
+    }
     // src/app.cpp:304-310
     std::vector<struct Bbox> outputBbox = detector.findFace(frame);
     if (outputBbox.empty()) {
