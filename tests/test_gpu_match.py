@@ -157,3 +157,92 @@ print("OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_dim_not_multiple_of_64_stays_on_the_exact_scan(frt, synth):
+    """the fp16 screening kernel walks K in steps of 64; D = 96 (and 32) with N >= 32768 must fall back to the exact
+    scan instead of dropping the last 32 dimensions from the coarse scores."""
+    from oracle import match
+    rng = np.random.default_rng(5)
+    for D in (96, 32):
+        N, F = 40000, 37
+        g = rng.standard_normal((N, D)).astype(np.float32)
+        g /= np.linalg.norm(g, axis=1, keepdims=True)
+        q = g[rng.integers(0, N, F)] + 0.05 * rng.standard_normal((F, D)).astype(np.float32)
+        # make the LAST 32 dimensions decide: a decoy in another 128-row tile that beats the answer on the first 64 dims only (a coarse
+        # pass blind to dims 64..95 would score it 1.0 against ~0.67 and drop the answer's tile from the exact re-rank)
+        if D == 96:
+            g[20000, :64] = 1.5 * g[7, :64]
+            g[20000, 64:] = -g[7, 64:]
+            q[0] = g[7]
+        mm = frt.MatMul()
+        mm.init(g)
+        idx, sim = mm.top1(q)
+        oi, osim = match.top1(q, g)
+        assert np.array_equal(idx, oi), D
+        assert np.abs(sim - osim).max() < 1e-5
+        mm.close()
+
+
+@pytest.mark.parametrize("N", [5000, 70000])
+def test_fp16_stored_gallery(frt, synth, N):
+    """BASELINE config 5 stores the gallery as fp16: similarities are then DEFINED on the fp16-rounded rows (fp32 accumulate).  Full
+    matrix, top-1 (exact scan for N = 5000, screened for N = 70000) and duplicate-row ties against the NumPy oracle on those rows."""
+    from oracle import match
+    g = synth.make_gallery(N)
+    g[N - 3] = g[11]          # duplicate rows: first index must win
+    g16 = g.astype(np.float16).astype(np.float32)
+    rng = np.random.default_rng(3)
+    q = g[rng.integers(0, N, 45)] + 0.02 * rng.standard_normal((45, 512)).astype(np.float32)
+    q[0] = g16[11]
+    mm = frt.MatMul()
+    mm.setStorage(True)
+    mm.init(g)
+    idx, sim = mm.top1(q)
+    oi, osim = match.top1(q, g16)
+    assert np.array_equal(idx, oi) and idx[0] == 11
+    assert np.abs(sim - osim).max() < 1e-5
+    full = mm.calculate(q[:5])
+    assert np.abs(full - q[:5] @ g16.T).max() < 1e-5
+    assert np.array_equal(full.argmax(1), idx[:5])
+    # back to fp32 storage on the same object
+    mm.setStorage(False)
+    mm.init(g)
+    idx32, sim32 = mm.top1(q)
+    o32, s32 = match.top1(q, g)
+    assert np.array_equal(idx32, o32) and np.abs(sim32 - s32).max() < 1e-5
+    mm.close()
+
+
+def test_streaming_gallery_load_equals_init(frt, synth):
+    """initKnownEmbeds / addEmbedding x n / initMatMul as begin / append / commit: ragged appends (1 row, blobs, > one staging chunk),
+    fewer rows than reserved, over-capacity error, reload on the same object."""
+    from oracle import match
+    N = 10000
+    g = synth.make_gallery(N)
+    q = g[[5, 4097, 9999]] + 0.01
+    mm = frt.MatMul()
+    mm.galleryBegin(N + 50, 512)
+    mm.galleryAppend(g[0])                       # one row (addEmbedding)
+    mm.galleryAppend(g[1:3].tobytes())           # a raw blob, as sqlite3_column_blob hands it over
+    mm.galleryAppend(g[3:9000])                  # more than two staging chunks at once
+    mm.galleryAppend(g[9000:])
+    with pytest.raises(frt.FrtError) as e:
+        mm.galleryAppend(np.zeros((51, 512), np.float32))
+    assert e.value.code == frt.FRT_ERR_CAPACITY
+    mm.galleryCommit()
+    assert mm.m == N
+    idx, sim = mm.top1(q)
+    oi, osim = match.top1(q, g)
+    assert np.array_equal(idx, oi) and np.abs(sim - osim).max() < 1e-5
+    # /reload: the old gallery answers until commit
+    mm.galleryBegin(100, 512)
+    mm.galleryAppend(g[::-1][:100].copy())
+    idx_mid, _ = mm.top1(q)
+    assert np.array_equal(idx_mid, oi)
+    mm.galleryCommit()
+    idx2, _ = mm.top1(g[[9999, 9950]])
+    assert list(idx2) == [0, 49]
+    with pytest.raises(frt.FrtError):
+        mm.galleryAppend(g[0])                   # no load in progress
+    mm.close()
