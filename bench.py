@@ -4,25 +4,35 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the whole hot path over one batch of 32 synthetic 640x640 frames that are already resident in
-HBM: letterbox/normalise -> RetinaFace-mnet0.25 -> decode + NMS (K = 4 faces per frame) -> bicubic crop -> ArcFace IR-50
-(fp16 MFMA convs, fp32 accumulate) -> cosine top-1 against a 1M x 512 fp32 gallery (fp32 MFMA).  Nothing is cached
-between steps and no stage is skipped.  With N > 1 every rank (one process per GPU) owns a full gallery replica and its
-own 32 frames (weak scaling).  Frames are independent, so there is NO collective on the data path; the per-face result
-records are all-gathered with RCCL once after the timed region (--gather-every-step does it per step).
+One "step" = one pass of the whole hot path over one batch of 32 synthetic 640x640 frames: letterbox/normalise ->
+RetinaFace-mnet0.25 -> decode + NMS (K = 4 faces per frame) -> bicubic crop -> ArcFace IR-50 (fp16 MFMA convs, fp32 accumulate) ->
+cosine top-1 against a 1M x 512 fp32 gallery (fp32 MFMA).  Nothing is cached between steps and no stage is skipped.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel family = the ArcFace 3x3 implicit-GEMM convs (conv_mfma_kernel); achieved = algorithmic
-                FLOPs of those launches / their HIP-event time, measured live on the pipeline's stream during the timed
-                steps; peak = 2.5 PFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md).
-  cpu_baseline  the oracle (reference-faithful CPU restatement, oracle/) timed on this box's host cores over a bounded
-                sample of the same workload, rank 0 at N = 1 only.
+TIMED REGION: u8 frames in PINNED HOST memory -> per-face (box, top-1 index, similarity) records back in host memory,
+through frt_pipeline_submit / frt_pipeline_wait with three batches in flight (H2D of 39 MB per step on the copy stream, D2H of the
+4.6 KB record block).  The figure with frames and results resident in HBM (frt_pipeline_run_dev) is reported beside it in
+`hbm_resident`; `--resident` makes it the primary one.  With N > 1 every rank (one process per GPU) owns a full gallery replica and
+its own 32 frames (weak scaling; `--strong` splits ONE 32-frame batch over the ranks - BASELINE configs[3] as written, also reported
+as a side object of every N > 1 run).  Frames are independent, so there is NO collective on the data path; with N > 1 the per-face
+result records of every step are all-gathered over RCCL on a side stream inside the timed region (configs[3]'s exchange step).
+`--sharded-gallery` runs configs[4] instead: the gallery is row-sharded over the ranks and stored as fp16, embeddings are
+all-gathered, every rank searches its shard, the (index, similarity) winners are all-gathered and merged (first maximum wins).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      dominant kernel family = the ArcFace 3x3 implicit-GEMM convs; achieved = algorithmic FLOPs of those launches /
+                their HIP-event time, measured live on the stream they run on during one step of the timed region; peak = 2.5 PFLOP/s
+                dense fp16 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle (reference-faithful CPU restatement, oracle/) timed on this box's host cores over bounded samples of
+                the same workload, rank 0 at N = 1 only: the full CPU pipeline and the reference's HOST-side work alone
+                (pre/post-processing + O(F*N) argmax), each with all cores and with one thread.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -32,18 +42,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense; /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+DEPTH = 3                        # batches in flight at the host boundary
 
 
-def cpu_baseline(frt, det_sd, rec_sd, gallery, frames, K, budget_s=20.0):
-    """Reference-faithful CPU pipeline (oracle) on a bounded sample: frames are processed one at a time, like the reference."""
-    import torch
-
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = checker, timed here as the reported baseline only)
+# ----------------------------------------------------------------------------------------------------------------------
+def _cpu_full(det_sd, rec_sd, gallery, frames, K, budget_s):
+    """Full CPU pipeline, frames one at a time like the reference (src/app.cpp:304-310)."""
     import oracle
     from oracle import match, nets
     H, W = frames.shape[1:3]
-    faces = 0
+    faces = n = 0
     t0 = time.perf_counter()
-    n = 0
     for fr in frames:
         x = oracle.det_preprocess(fr, H, W)
         loc, conf = nets.retinaface_forward(det_sd, x[None])
@@ -55,10 +66,119 @@ def cpu_baseline(frt, det_sd, rec_sd, gallery, frames, K, budget_s=20.0):
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": round(faces / dt, 3), "unit": "faces/sec", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d frame(s) of the same 640x640 workload, %d faces, full CPU pipeline (oracle nets fp32 on torch-CPU, "
-                      "C post-processing/crop, NumPy %dx512 match), %.1f s" % (n, faces, gallery.shape[0], dt)}
+    return faces, n, time.perf_counter() - t0
+
+
+def _cpu_host_work(heads, embeds, gallery, frames, K, budget_s):
+    """Only what the REFERENCE does on the host around its GPU engines: letterbox + normalise + planarise (retinaface.cpp:106-136),
+    anchor regeneration + decode + sort + NMS (:154-271), crop + bicubic + normalise (arcface.cpp:3-17,116-129) and the arg-max over a
+    materialised [F, N] similarity matrix (arcface.cpp:203-217).  Network outputs are precomputed (they come from the GPU there)."""
+    import oracle
+    H, W = frames.shape[1:3]
+    faces = n = 0
+    sims = np.ascontiguousarray(np.random.default_rng(0).random((K, gallery.shape[0]), dtype=np.float32))  # what cuBLASLt hands back
+    t0 = time.perf_counter()
+    while True:
+        for i, fr in enumerate(frames):
+            oracle.det_preprocess(fr, H, W)
+            boxes = oracle.postprocess(heads[i][0], heads[i][1], W, H, W, H, 0.4, 0.6, K)
+            oracle.face_normalize(oracle.crop_faces(fr, boxes))
+            for row in sims[:len(boxes)]:
+                int(np.argmax(row))  # std::max_element over one row of the F x N matrix
+            faces += len(boxes)
+            n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    return faces, n, time.perf_counter() - t0
+
+
+def cpu_baseline(det_sd, rec_sd, gallery, frames, K):
+    import torch
+
+    import oracle
+    from oracle import nets
+    ncpu = int(torch.get_num_threads())
+    H, W = frames.shape[1:3]
+    heads = []
+    for fr in frames[:8]:
+        loc, conf = nets.retinaface_forward(det_sd, oracle.det_preprocess(fr, H, W)[None])
+        heads.append((loc[0], conf[0]))
+    out = {}
+    f, n, dt = _cpu_full(det_sd, rec_sd, gallery, frames, K, 10.0)
+    full_all = f / dt
+    sample_full = "%d frame(s), %d faces, %.1f s" % (n, f, dt)
+    f, n, dt = _cpu_host_work(heads, None, gallery, frames[:8], K, 4.0)
+    host_all = f / dt  # (the oracle's C code is single-threaded; "all cores" only changes NumPy/torch internals)
+    torch.set_num_threads(1)
+    try:
+        f, n, dt = _cpu_full(det_sd, rec_sd, gallery, frames, K, 8.0)
+        full_1 = f / dt
+        sample_full_1 = "%d frame(s), %d faces, %.1f s" % (n, f, dt)
+        f, n, dt = _cpu_host_work(heads, None, gallery, frames[:8], K, 4.0)
+        host_1 = f / dt
+    finally:
+        torch.set_num_threads(ncpu)
+    out = {"value": round(full_all, 3), "unit": "faces/sec", "cores": ncpu, "kind": "port",
+           "sample": "full CPU pipeline (oracle nets fp32 on torch-CPU, C post-processing/crop, NumPy %dx512 match) on frames of the same "
+                     "640x640 workload, one at a time like the reference: %s" % (gallery.shape[0], sample_full),
+           "single_thread": {"value": round(full_1, 3), "cores": 1, "sample": sample_full_1},
+           "reference_host_work_only": {
+               "what": "only the work the reference itself does on the host around its TensorRT/cuBLASLt calls: letterbox+normalise, anchor "
+                       "regeneration+decode+sort+NMS, crop+bicubic+normalise, arg-max over a materialised [F,N] fp32 row per face "
+                       "(retinaface.cpp:106-136,154-271; arcface.cpp:3-17,116-129,203-217); network outputs precomputed",
+               "value": round(host_all, 3), "unit": "faces/sec", "cores": ncpu,
+               "single_thread": {"value": round(host_1, 3), "cores": 1}},
+           "host": {"nproc": os.cpu_count(), "cpu": _cpu_model()}}
+    return out
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# power / clock evidence: rocm-smi sampled by a side thread while the timed region runs
+# ----------------------------------------------------------------------------------------------------------------------
+class SmiSampler:
+    def __init__(self, device, period=0.25):
+        self.device, self.period, self.samples, self._stop, self._t = device, period, [], threading.Event(), None
+
+    def _run(self):
+        while not self._stop.is_set():
+            t = time.time()
+            try:
+                o = subprocess.run(["rocm-smi", "-d", str(self.device), "--showpower", "--showclocks", "--json"], capture_output=True,
+                                   text=True, timeout=5).stdout
+                card = next(iter(json.loads(o).values()))
+                rec = {"t": round(t, 3)}
+                for k, v in card.items():
+                    kl = k.lower()
+                    if "power" in kl and "(w)" in kl:
+                        rec["power_w"] = float(v)
+                    elif kl.startswith("sclk clock speed"):
+                        rec["sclk_mhz"] = float(str(v).strip("()Mhz "))
+                    elif kl.startswith("mclk clock speed"):
+                        rec["mclk_mhz"] = float(str(v).strip("()Mhz "))
+                self.samples.append(rec)
+            except Exception:  # noqa: BLE001  (rocm-smi missing / format change: evidence only, never fatal)
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._t.join(10)
 
 
 def main():
@@ -66,20 +186,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (per step in total with --strong)")
     ap.add_argument("--faces", type=int, default=4, help="det_maxFacesPerScene (K)")
     ap.add_argument("--gallery", type=int, default=1_000_000)
     ap.add_argument("--frame", default="640x640", help="frame size WxH (default 640x640 = the metric; 1920x1080 = BASELINE config 3's "
                                                        "video frames, letterboxed to the 640x640 detector input). Implies --no-cpu-baseline when not 640x640")
     ap.add_argument("--mode", default="ir", choices=["ir", "ir_se"], help="IR-50 (the reference's network) or IR-SE-50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-every-step", action="store_true",
-                    help="all-gather the result records after EVERY step (default: once, after the timed region)")
+    ap.add_argument("--resident", action="store_true", help="primary timed region with frames/results resident in HBM (frt_pipeline_run_dev)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: ONE batch of --batch frames split over the ranks (BASELINE configs[3])")
+    ap.add_argument("--sharded-gallery", action="store_true",
+                    help="BASELINE configs[4]: gallery row-sharded over the ranks and stored as fp16; RCCL all-gather of embeddings and of the top-1 winners")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step RCCL all-gather of the result records")
     ap.add_argument("--stage-profile", default=None, help="write a per-stage HIP-event breakdown (extra untimed steps) to this file")
-    ap.add_argument("--host-boundary", action="store_true",
-                    help="also time the synchronous host-buffer entry point (pinned host frames in, host results out: PCIe inclusive); "
-                         "extra untimed-by-the-contract leg, reported in its own object")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (no side measurements)")
+    ap.add_argument("--smi-trace", default=None, help="write the rocm-smi power/clock samples taken during the timed region to this file")
     args = ap.parse_args()
 
     import torch
@@ -87,6 +209,7 @@ def main():
 
     import __graft_entry__ as entry
     frt = entry.load_pkg()
+    fd = frt.dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -103,39 +226,152 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     s = frt.synth
-    B, K, H, W = args.batch, args.faces, 640, 640   # detector input
+    K, H, W = args.faces, 640, 640   # detector input
     FW, FH = (int(v) for v in args.frame.lower().split("x"))
     if (FW, FH) != (W, H):
         args.no_cpu_baseline = True
+    # frames of this rank: weak = its own --batch frames; strong = its share of ONE --batch-frame batch
+    if args.strong:
+        fb, fe = fd.shard_range(args.batch, rank, world)
+        B = max(fe - fb, 1)
+        frame_start = fb
+    else:
+        B = args.batch
+        frame_start = rank * B
+    F = B * K
     tmp = tempfile.mkdtemp(prefix="frt_bench_%d_" % rank)
     det_sd = s.retinaface_state(1)
     rec_sd = s.arcface_state(2, args.mode, calib=s.load_calibration(args.mode))
     det_path = frt.write_weights(os.path.join(tmp, "det.frtw"), det_sd, 1)
     rec_path = frt.write_weights(os.path.join(tmp, "rec.frtw"), rec_sd, 2 if args.mode == "ir" else 3)
     det = frt.RetinaFace(det_path, FW, FH, (3, H, W), B, K, 0.4, 0.6, device=local_rank)
-    rec = frt.ArcFaceIR50(rec_path, FW, FH, (3, 112, 112), 512, B * K, K, 0.65, device=local_rank)
+    rec = frt.ArcFaceIR50(rec_path, FW, FH, (3, 112, 112), 512, F, K, 0.65, device=local_rank)
     gallery = s.make_gallery(args.gallery)
-    rec.setGallery(gallery)  # bulk initKnownEmbeds + addEmbedding x N (2 GB: no per-row copies)
-    rec.initMatMul()
+    t_load = time.perf_counter()
+    if args.sharded_gallery:
+        gb, ge = fd.gallery_shard(args.gallery, rank, world)
+        rec.matmul.setStorage(True)                    # fp16-stored shard
+        rec.setGallery(gallery[gb:ge])
+        rec.initMatMul()
+        rec.matmul.setRowOffset(gb)
+    else:
+        rec.setGallery(gallery)  # bulk initKnownEmbeds + addEmbedding x N through the streaming loader (pinned chunks, async copies)
+        rec.initMatMul()
+    gallery_load_s = time.perf_counter() - t_load
     pipe = frt.Pipeline(det, rec, B)
 
-    frames = s.make_frames(B, FH, FW, start=rank * B)  # weak scaling: every rank has its own 32 frames
-    d_frames = torch.from_numpy(frames).cuda()
-    F = B * K
-    d_res = torch.zeros(F * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
-    d_all = torch.zeros(world * F * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") if use_dist else None
+    # two alternating batches so that consecutive steps never see the same pixels
+    batches = [s.make_frames(B, FH, FW, start=frame_start), s.make_frames(B, FH, FW, start=frame_start + 4096)]
+    h_frames = [torch.from_numpy(b).pin_memory() for b in batches]
+    h_np = [t.numpy() for t in h_frames]
+    RD = frt.RESULT_DTYPE
+    h_res = [torch.zeros(F * RD.itemsize, dtype=torch.uint8).pin_memory() for _ in range(4)]
+    h_views = [r.numpy().view(RD) for r in h_res]
+    d_frames = [t.cuda() for t in h_frames]
+    NRING = 4
+    d_res = [torch.zeros(F * RD.itemsize, dtype=torch.uint8, device="cuda") for _ in range(NRING)]
+    d_all = [torch.zeros(world * F * RD.itemsize, dtype=torch.uint8, device="cuda") for _ in range(NRING)] if use_dist else None
+    h_all = [torch.zeros(world * F * RD.itemsize, dtype=torch.uint8).pin_memory() for _ in range(NRING)] if use_dist else None
     stream = torch.cuda.current_stream()
     pipe.set_stream(stream.cuda_stream)
+    side = torch.cuda.Stream() if use_dist else None       # RCCL all-gather + D2H of the gathered records
+    upload = torch.cuda.Stream() if use_dist else None
+    d_stage = [torch.empty_like(d_frames[0]) for _ in range(NRING)] if use_dist else None
+    ev_up = [torch.cuda.Event() for _ in range(NRING)] if use_dist else None
+    ev_res = [torch.cuda.Event() for _ in range(NRING)] if use_dist else None
+    ev_side = [torch.cuda.Event() for _ in range(NRING)] if use_dist else None
+    gather = use_dist and not args.no_gather
 
-    def step():
-        pipe.run_dev(d_frames.data_ptr(), B, d_res.data_ptr(), None)
-        if use_dist and args.gather_every_step:  # see the note below: not part of the data path, off by default
-            dist.all_gather_into_tensor(d_all, d_res)
+    # ---- sharded-gallery mode (configs[4]): second pipeline without a matcher produces embeddings; match + merge follow here
+    if args.sharded_gallery:
+        pipe.close()
+        pipe = frt.Pipeline(det, rec, B, match=False)
+        pipe.set_stream(stream.cuda_stream)
+        d_emb = [torch.zeros(F, 512, device="cuda") for _ in range(NRING)]
+        d_idx = torch.zeros(world * F, dtype=torch.int32, device="cuda")
+        d_sim = torch.zeros(world * F, dtype=torch.float32, device="cuda")
+        final = [None]
 
-    for _ in range(args.warmup):
-        step()
+    # ---------------------------------------------------------------------------------------------------- step bodies
+    def run_host(n_steps, profile_step=None):
+        """pinned host frames -> host records, DEPTH batches in flight (frt_pipeline_submit / frt_pipeline_wait)."""
+        tickets = []
+        for i in range(n_steps):
+            if len(tickets) >= DEPTH:
+                pipe.wait(tickets.pop(0))
+            if i == profile_step:
+                frt.profile_enable(1)
+            tickets.append(pipe.submit(h_np[i & 1], h_views[i % 4]))
+            if i == profile_step:
+                frt.profile_enable(-1)  # pause: keep the records, stop recording (host-side flag, no sync)
+        for t in tickets:
+            pipe.wait(t)
+
+    def run_host_dist(n_steps, profile_step=None):
+        """Same boundary with N > 1: upload on a copy stream, stages behind its event, and on a side stream the RCCL all-gather of the
+        step's records followed by the D2H of the gathered block - none of it on the pipeline's stage streams."""
+        for i in range(n_steps):
+            r = i % NRING
+            if i >= NRING:
+                ev_side[r].synchronize()          # ring slot free again (its gathered block has reached the host)
+            with torch.cuda.stream(upload):
+                d_stage[r].copy_(h_frames[i & 1], non_blocking=True)
+                ev_up[r].record(upload)
+            if i == profile_step:
+                frt.profile_enable(1)
+            pipe.run_dev(d_stage[r].data_ptr(), B, d_res[r].data_ptr(), None, ready_event=ev_up[r].cuda_event)
+            if i == profile_step:
+                frt.profile_enable(-1)
+            ev_res[r].record(stream)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_res[r])
+                if gather:
+                    dist.all_gather_into_tensor(d_all[r], d_res[r])
+                    h_all[r].copy_(d_all[r], non_blocking=True)
+                else:
+                    h_res[r].copy_(d_res[r], non_blocking=True)
+                ev_side[r].record(side)
+        side.synchronize()
+
+    def run_resident(n_steps, profile_step=None):
+        for i in range(n_steps):
+            if i == profile_step:
+                frt.profile_enable(1)
+            pipe.run_dev(d_frames[i & 1].data_ptr(), B, d_res[i % NRING].data_ptr(), None)
+            if i == profile_step:
+                frt.profile_enable(-1)
+
+    def run_sharded(n_steps, profile_step=None):
+        for i in range(n_steps):
+            r = i % NRING
+            if i == profile_step:
+                frt.profile_enable(1)
+            pipe.run_dev(d_frames[i & 1].data_ptr(), B, d_res[r].data_ptr(), d_emb[r].data_ptr())
+            if i == profile_step:
+                frt.profile_enable(-1)
+            q_all = fd.all_gather_embeddings(d_emb[r]) if use_dist else d_emb[r]      # exchange 1: every rank gets every query
+            nq = q_all.shape[0]
+            rec.matmul.top1_dev(q_all.data_ptr(), nq, d_idx.data_ptr(), d_sim.data_ptr(), stream.cuda_stream)
+            if use_dist:
+                final[0] = fd.sharded_top1(d_idx[:nq], d_sim[:nq])                       # exchange 2: winners, first maximum wins
+            else:
+                final[0] = (d_idx[:nq], d_sim[:nq])
+
+    if args.sharded_gallery:
+        run = run_sharded
+    elif args.resident:
+        run = run_resident
+    elif use_dist:
+        run = run_host_dist
+    else:
+        run = run_host
+
+    run(max(args.warmup, 1))
     torch.cuda.synchronize()
-    res = np.frombuffer(d_res.cpu().numpy().tobytes(), frt.RESULT_DTYPE)
+    if args.sharded_gallery or args.resident or use_dist:
+        res = np.frombuffer(d_res[(max(args.warmup, 1) - 1) % NRING].cpu().numpy().tobytes(), RD)
+    else:
+        res = h_views[(max(args.warmup, 1) - 1) % 4]
     faces_per_step = int(res["valid"].sum())
 
     profile = not args.no_profile
@@ -143,20 +379,25 @@ def main():
     # they cost ~0.5 ms per step (two event packets around each of ~55 conv launches) - 11 % of the number being measured.  libfrt
     # runs a profiled call serially on the pipeline stream (no other stage competes for the dispatch), so the bracketed time is the
     # kernel's own duration - the number rocprofv3 reports; with four streams in flight it was 2.7x that.
-    sampled_step = args.steps - 1  # the LAST step: the pipeline drains at the end of the region anyway, so serialising it costs no refill
+    sampled_step = args.steps - 1 if profile else None
     frt.profile_enable(0)
+    smi = SmiSampler(local_rank) if (rank == 0 and args.smi_trace) else None  # (one rocm-smi call takes longer than a 20-step region)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    if smi:
+        smi.__enter__()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        if profile and i == sampled_step:
-            frt.profile_enable(1)
-        step()
-        if profile and i == sampled_step:
-            frt.profile_enable(-1)  # pause: keep the records, stop recording (host-side flag, no sync)
+    run(args.steps, sampled_step)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if smi:
+        smi.__exit__()
+    if gather and run is run_host_dist and args.steps >= 1:
+        # the last step's gathered block must hold this rank's own records at its rank offset
+        r = (args.steps - 1) % NRING
+        own = h_all[r][rank * F * RD.itemsize:(rank + 1) * F * RD.itemsize]
+        assert torch.equal(own, d_res[r].cpu()), "all-gather mismatch"
     if use_dist:
         dist.barrier()
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -179,6 +420,7 @@ def main():
         return t
 
     roofline = None
+    dom = None
     if profile:
         labels, ms, work = frt.profile_collect()
         frt.profile_enable(0)
@@ -191,11 +433,17 @@ def main():
             fam = sum(v[1] for v in live.values()) / (fam_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_FP16_MFMA_TFLOPS, 4), "traffic": None,
-                        "kernel": dom + " (ArcFace 3x3 conv, LDS-resident halo patch; fp16 in, fp32 accumulate)",
+                        "kernel": dom + " (ArcFace 3x3 conv; fp16 in, fp32 accumulate)",
                         "launches": n, "avg_launch_us": round(1e3 * tot_ms / n, 2), "flop_per_launch": round(tot_flop / n, 1),
                         "share_of_step_time": round(tot_ms / (1e3 * dt / args.steps), 4),
                         "all_3x3_conv_kernels": {"achieved": round(fam, 2), "frac": round(fam / PEAK_FP16_MFMA_TFLOPS, 4),
-                                                 "share_of_step_time": round(fam_ms / (1e3 * dt / args.steps), 4)}}
+                                                 "share_of_step_time": round(fam_ms / (1e3 * dt / args.steps), 4),
+                                                 "per_kernel": {k: {"launches": v[2], "avg_launch_us": round(1e3 * v[0] / v[2], 2),
+                                                                    "achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in live.items()}},
+                        "note": "achieved/frac/avg_launch_us: live HIP-event durations of every launch of the kernel in ONE step (step %d of %d) "
+                                "inside the timed region; that call runs serially on the pipeline stream so that the events bracket the kernel "
+                                "alone (events on every step would cost 11 %% of the step time, and under the 4-stream pipeline the bracketed "
+                                "time includes other streams' dispatches)" % (args.steps, args.steps)}
             try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_profiles.sh)
                 import glob
                 for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
@@ -209,13 +457,61 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
 
-    if roofline is not None:
-        # The timed region runs the two-stream pipeline: conv launches share the CUs with the next batch's detector, so their
-        # live durations include that contention.  Same measurement again, serially (extra untimed steps), for the record.
+    extras = {}
+    if not args.no_extras and not args.sharded_gallery:
+        # ---- the other boundary, same number of steps, untimed by the contract
+        other, tag = (run_resident, "hbm_resident") if not args.resident else (run_host_dist if use_dist else run_host, "host_boundary")
+        other(3)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        ta = time.perf_counter()
+        other(args.steps)
+        torch.cuda.synchronize()
+        dta = time.perf_counter() - ta
+        extras[tag] = {"faces_per_sec_this_rank": round(faces_per_step * args.steps / dta, 1), "ms_per_step": round(1e3 * dta / args.steps, 4),
+                       "steps": args.steps,
+                       "note": ("frt_pipeline_run_dev: frames and result records resident in HBM, no PCIe traffic in the region"
+                                if tag == "hbm_resident" else "pinned host frames in, host records out (PCIe inclusive)")}
+        # ---- steady state: the contract region includes the pipeline fill, the drain and the serial profiled step, which weigh 10 %
+        #      of a 20-step region; the same loop over >= 100 steps without the profiled step is the steady-state rate
+        if args.steps < 100:
+            n_ss = 100
+            tb = time.perf_counter()
+            run(n_ss)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - tb
+            extras["steady_state"] = {"steps": n_ss, "faces_per_sec_this_rank": round(faces_per_step * n_ss / dtb, 1),
+                                      "ms_per_step": round(1e3 * dtb / n_ss, 4),
+                                      "note": "same loop as the timed region over %d steps, no profiled step (the %d-step contract region "
+                                              "carries pipeline fill + drain + one serial profiled step)" % (n_ss, args.steps)}
+    if use_dist and not args.strong and not args.sharded_gallery and not args.no_extras:
+        # ---- BASELINE configs[3] as written: ONE 32-frame batch split over the ranks (strong scaling), gallery replicated
+        sb, se = fd.shard_range(args.batch, rank, world)
+        nb = se - sb
+        if nb > 0:
+            for _ in range(3):
+                pipe.run_dev(d_frames[0].data_ptr(), nb, d_res[0].data_ptr(), None)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = time.perf_counter()
+        for i in range(args.steps):
+            if nb > 0:
+                pipe.run_dev(d_frames[i & 1].data_ptr(), nb, d_res[i % NRING].data_ptr(), None)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - ts
+        tt = torch.tensor([dts], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        extras["strong_scaling"] = {"frames_per_step_total": args.batch, "frames_this_rank": nb, "faces_per_sec": round(args.batch * K * args.steps / float(tt.item()), 1),
+                                    "ms_per_step": round(1e3 * float(tt.item()) / args.steps, 4),
+                                    "note": "BASELINE configs[3]: one %d-frame batch split over %d ranks, HBM-resident frames" % (args.batch, world)}
+
+    if roofline is not None and not args.no_extras:
+        # Same measurement again, serially (extra untimed steps with the pipeline switched off), for the record.
         pipe.set_overlap(False)
         frt.profile_enable(1)
-        for _ in range(3):
-            step()
+        for i in range(3):
+            pipe.run_dev(d_frames[i & 1].data_ptr(), B, d_res[0].data_ptr(), d_emb[0].data_ptr() if args.sharded_gallery else None)
         torch.cuda.synchronize()
         labels, ms, work = frt.profile_collect()
         frt.profile_enable(0)
@@ -226,16 +522,11 @@ def main():
             roofline["serial_achieved"] = round(ach, 2)
             roofline["serial_frac"] = round(ach / PEAK_FP16_MFMA_TFLOPS, 4)
             roofline["serial_avg_launch_us"] = round(1e3 * ser[dom][0] / ser[dom][2], 2)
-            roofline["note"] = ("achieved/frac/avg_launch_us: live HIP-event durations of every launch of the kernel in ONE step (step %d of %d) "
-                                "inside the timed region; that call runs serially on the pipeline stream so that the events bracket the kernel "
-                                "alone (events on every step would cost 11 %% of the step time, and under the 4-stream pipeline the bracketed "
-                                "time includes other streams' dispatches); serial_*: same launches again in 3 extra untimed steps with the "
-                                "pipeline switched off" % (sampled_step + 1, args.steps))
 
     if args.stage_profile and rank == 0:  # extra, untimed steps with stage-level HIP events -> a side file (not the JSON line)
         frt.profile_enable(2)
-        for _ in range(3):
-            step()
+        for i in range(3):
+            pipe.run_dev(d_frames[i & 1].data_ptr(), B, d_res[0].data_ptr(), d_emb[0].data_ptr() if args.sharded_gallery else None)
         torch.cuda.synchronize()
         labels, ms, work = frt.profile_collect()
         frt.profile_enable(0)
@@ -248,38 +539,18 @@ def main():
         with open(args.stage_profile, "w") as f:
             json.dump({k: {"ms_per_step": v[0] / 3, "work_per_step": v[1] / 3, "launch_groups_per_step": v[2] / 3} for k, v in agg.items()}, f, indent=1)
 
-    host_boundary = None
-    if args.host_boundary and rank == 0:
-        # The reference-style boundary: the caller hands over HOST frames and gets HOST results (frt_pipeline_run); every call is
-        # synchronous, so neither the H2D copy nor the stages of neighbouring calls overlap.  Not the metric - DESIGN.md quotes it.
-        h_frames = torch.from_numpy(frames).pin_memory().numpy()
-        for _ in range(2):
-            pipe.run(h_frames, want_embeds=False)
-        th = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.run(h_frames, want_embeds=False)
-        dth = time.perf_counter() - th
-        host_boundary = {"faces_per_sec": round(faces_per_step * args.steps / dth, 1), "ms_per_step": round(1e3 * dth / args.steps, 3),
-                         "h2d_bytes_per_step": int(frames.nbytes), "note": "frt_pipeline_run: pinned host frames in, host results out, one synchronous call per step"}
-        # ... and the asynchronous form (frt_pipeline_submit / frt_pipeline_wait), 3 batches in flight from one host thread
-        h_res = [torch.zeros(F * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in range(4)]
-        h_views = [r.numpy().view(frt.RESULT_DTYPE) for r in h_res]
-        def pump(n):
-            tickets = []
-            for i in range(n):
-                if len(tickets) >= 3:
-                    pipe.wait(tickets.pop(0))
-                tickets.append(pipe.submit(h_frames, h_views[i % 4]))
-            for t in tickets:
-                pipe.wait(t)
-        pump(4)
-        th = time.perf_counter()
-        pump(args.steps)
-        dth = time.perf_counter() - th
-        host_boundary["async"] = {"faces_per_sec": round(faces_per_step * args.steps / dth, 1), "ms_per_step": round(1e3 * dth / args.steps, 3),
-                                  "note": "frt_pipeline_submit/wait: same buffers, 3 batches in flight (H2D on the copy stream under the stages)"}
-
     if rank == 0:
+        if args.sharded_gallery:
+            boundary = "HBM-resident frames -> merged top-1 on the device"
+            par = ("frames sharded dp%d, gallery ROW-sharded over %d rank(s) (%d rows each, fp16-stored), RCCL all-gather of embeddings, per-shard "
+                   "top-1 with global indices, RCCL all-gather of (idx, sim) + first-maximum merge" % (world, world, (args.gallery + world - 1) // world))
+        else:
+            boundary = ("HBM-resident frames -> HBM-resident records (frt_pipeline_run_dev)" if args.resident else
+                        "pinned host frames -> host records, %d batches in flight (%s)" % (DEPTH, "upload stream + frt_pipeline_run_dev_after + "
+                                                                                            "side-stream D2H" if use_dist else "frt_pipeline_submit/wait"))
+            par = "frames sharded dp%d (%s), gallery replicated, no data-path collective%s" % (
+                world, "strong: one batch split over the ranks" if args.strong else "weak: every rank its own batch",
+                "; RCCL all-gather of every step's result records on a side stream inside the timed region" if gather else "")
         out = {
             "metric": "faces/sec end-to-end (detect+embed+match), 640x640 batch=32, 1M gallery",
             "value": round(total_faces_per_step * args.steps / dt, 2),
@@ -289,30 +560,37 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f16 MFMA recogniser convs (fp32 accumulate) + fp32-accurate detector (fp32 MFMA, fp16 hi/lo-split MFMA for the 64-channel 3x3 convs) + f32 MFMA match",
             "data": "synthetic",
-            "config": {"workload": "%dx%d frames (640x640 detector input) batch=%d frames/GPU, K=%d faces/frame, %dx512 fp32 gallery replicated per GPU, "
-                                   "RetinaFace-mnet0.25 + ArcFace %s" % (FW, FH, B, K, args.gallery, "IR-50" if args.mode == "ir" else "IR-SE-50"),
+            "config": {"workload": "%s; %dx%d frames (640x640 detector input) batch=%d frames/GPU, K=%d faces/frame, %dx512 %s gallery, "
+                                   "RetinaFace-mnet0.25 + ArcFace %s" % (boundary, FW, FH, B, K, args.gallery,
+                                                                         "fp16-stored row-sharded" if args.sharded_gallery else "fp32 replicated per GPU",
+                                                                         "IR-50" if args.mode == "ir" else "IR-SE-50"),
+                       "boundary": boundary,
                        "frames_per_step_per_gpu": B, "faces_per_frame": K, "faces_per_step": total_faces_per_step,
-                       "gallery_rows": args.gallery, "parallelism": "frames sharded dp%d, no data-path collective, RCCL all-gather of results after the timed region" % world},
+                       "gallery_rows": args.gallery, "h2d_bytes_per_step": 0 if (args.resident or args.sharded_gallery) else int(batches[0].nbytes),
+                       "gallery_load_s": round(gallery_load_s, 3), "parallelism": par},
             "roofline": roofline,
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frt, det_sd, rec_sd, gallery, frames, K)
-        if host_boundary:
-            out["host_boundary"] = host_boundary
+        out.update(extras)
+        if smi and smi.samples:
+            pw = [x["power_w"] for x in smi.samples if "power_w" in x]
+            ck = [x["sclk_mhz"] for x in smi.samples if "sclk_mhz" in x]
+            out["power_clock"] = {"samples": len(smi.samples), "power_w_mean": round(float(np.mean(pw)), 1) if pw else None,
+                                  "power_w_max": round(float(np.max(pw)), 1) if pw else None,
+                                  "sclk_mhz_mean": round(float(np.mean(ck)), 1) if ck else None,
+                                  "note": "rocm-smi --showpower --showclocks sampled every 0.25 s by a side thread during the timed region"}
+            if args.smi_trace:
+                with open(args.smi_trace, "w") as f:
+                    json.dump(smi.samples, f)
+        if world == 1 and not args.no_cpu_baseline and not args.sharded_gallery:
+            out["cpu_baseline"] = cpu_baseline(det_sd, rec_sd, gallery, batches[0], K)
         print(json.dumps(out), flush=True)
     if use_dist:
-        # Frames are independent and the gallery is replicated, so the hot path has NO exchange step: every rank's results are
-        # complete on their own.  The RCCL all-gather that gives every rank the whole node's answer runs once here, outside the
-        # timed region (measured: a 4.6 KB all_gather_into_tensor costs 12 us on an idle stream but ~1.5 ms when queued behind
-        # compute - per-step use would serialise the two-stream pipeline; --gather-every-step measures exactly that).
-        dist.all_gather_into_tensor(d_all, d_res)
-        torch.cuda.synchronize()
-        assert torch.equal(d_all[rank * d_res.numel():(rank + 1) * d_res.numel()], d_res), "all-gather mismatch"
+        dist.barrier()
         dist.destroy_process_group()
 
 

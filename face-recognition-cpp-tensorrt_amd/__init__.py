@@ -445,12 +445,14 @@ class ArcFaceIR50:
 # batched device-resident pipeline (new surface)
 # ----------------------------------------------------------------------------------------------------------------------
 class Pipeline:
-    def __init__(self, detector, recognizer, max_frames):
+    def __init__(self, detector, recognizer, max_frames, match=True):
+        """``match=False``: no matcher stage (records carry match_idx = -1); the caller matches the embeddings itself, e.g. against a
+        sharded gallery (dist.py)."""
         self._h = _vp()
         self.det, self.rec = detector, recognizer
         self.max_frames = int(max_frames)
         self.max_faces = detector.maxFacesPerScene
-        _check(lib.frt_pipeline_create(detector._h, recognizer._h, recognizer.matmul._h, self.max_frames, ctypes.byref(self._h)))
+        _check(lib.frt_pipeline_create(detector._h, recognizer._h, recognizer.matmul._h if match else None, self.max_frames, ctypes.byref(self._h)))
 
     def run(self, frames, want_embeds=True):
         frames = np.ascontiguousarray(frames, np.uint8)

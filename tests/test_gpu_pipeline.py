@@ -229,3 +229,139 @@ def test_repeated_runs_are_bit_identical_at_the_benchmark_size(frt, synth, blobs
     pipe.close()
     det.close()
     rec.close()
+
+
+def test_pipeline_run_from_several_threads(frt, synth, blobs):
+    """frt_pipeline_run is the entry point a multithreaded server (src/app.cpp:367) would call concurrently.  Every call
+    takes its own staging set, so four threads hammering it must each get exactly the single-threaded answer for their frames."""
+    import threading
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 2, 4, 320, 320
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    rec.setGallery(synth.make_gallery(3000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    batches = [synth.make_frames(B, H, W, start=3 * i) for i in range(4)]
+    want = [tuple(a.copy() for a in pipe.run(b)) for b in batches]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(25):
+                r, e = pipe.run(batches[i])
+                if not (np.array_equal(r, want[i][0]) and np.array_equal(e, want[i][1])):
+                    errors.append(i)
+                    return
+        except Exception as ex:  # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    pipe.close()
+    det.close()
+    rec.close()
+
+
+def test_object_level_calls_wait_for_pipeline_stages_in_flight(frt, synth, blobs):
+    """after frt_pipeline_run_dev returns, its stages still run on the pipeline's streams and share the detector's
+    candidate buffers / the recogniser's activations / the matcher's scratch with the object-level entry points.  Calling those
+    immediately (no synchronisation by the caller) must give the quiet-device answers, and the pipelined results must survive."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 8, 4, 640, 640
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    gal = synth.make_gallery(40000)
+    rec.setGallery(gal)
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    frames = synth.make_frames(B, H, W)
+    other = synth.make_frames(1, H, W, start=77)[0]
+    want_res, _ = pipe.run(frames)
+    want_boxes = det.findFace(other)
+    want_emb = rec.forward(other, want_boxes)
+    q = gal[[3, 30003]] + 0.01
+    want_idx, want_sim = rec.matmul.top1(q)
+    d_frames = torch.from_numpy(frames).cuda()
+    d_res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(6)]
+    pipe.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(6):
+        pipe.run_dev(d_frames.data_ptr(), B, d_res[i].data_ptr(), None)
+        if i % 2 == 0:
+            boxes = det.findFace(other)              # detector stage of call i may still be running
+            assert np.array_equal(boxes, want_boxes), i
+        if i % 3 == 1:
+            emb = rec.forward(other, want_boxes)     # recogniser pass in flight on either activation set
+            assert np.array_equal(emb, want_emb), i
+        idx, sim = rec.matmul.top1(q)                # match stage in flight on the shared scratch
+        assert np.array_equal(idx, want_idx) and np.array_equal(sim, want_sim), i
+    torch.cuda.synchronize()
+    for i in range(6):
+        got = np.frombuffer(d_res[i].cpu().numpy().tobytes(), frt.RESULT_DTYPE)
+        assert np.array_equal(got, want_res), i
+    pipe.set_stream(None)
+    pipe.close()
+    det.close()
+    rec.close()
+
+
+def test_run_dev_orders_behind_the_callers_producer(frt, synth, blobs):
+    """frt_pipeline_run_dev_after (caller's event) and frt_pipeline_set_input_sync (event on the pipeline stream): frames that are
+    still being uploaded when the call is made must be the ones the stages see."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 8, 4, 640, 640
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    rec.setGallery(synth.make_gallery(3000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    batches = [synth.make_frames(B, H, W, start=11 * i) for i in range(4)]
+    want = [pipe.run(b)[0].copy() for b in batches]
+    pinned = [torch.from_numpy(b).pin_memory() for b in batches]
+    filler = torch.zeros(256 << 20, dtype=torch.uint8).pin_memory()   # a long copy in front of each upload keeps it late
+    d_fill = torch.empty_like(filler, device="cuda")
+    d_frames = [torch.zeros_like(p, device="cuda") for p in pinned]
+    d_res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in batches]
+    main = torch.cuda.current_stream()
+    pipe.set_stream(main.cuda_stream)
+    up = torch.cuda.Stream()
+    # (a) the caller's own event on a separate upload stream: calls keep overlapping
+    evs = []
+    for i in range(4):
+        with torch.cuda.stream(up):
+            d_fill.copy_(filler, non_blocking=True)
+            d_frames[i].copy_(pinned[i], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(up)
+        evs.append(ev)
+        pipe.run_dev(d_frames[i].data_ptr(), B, d_res[i].data_ptr(), None, ready_event=ev.cuda_event)
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert np.array_equal(np.frombuffer(d_res[i].cpu().numpy().tobytes(), frt.RESULT_DTYPE), want[i]), i
+    # (b) safe mode: upload on the pipeline stream itself
+    pipe.set_input_sync(True)
+    for t in d_frames + d_res:
+        t.zero_()
+    torch.cuda.synchronize()
+    for i in range(4):
+        d_fill.copy_(filler, non_blocking=True)
+        d_frames[i].copy_(pinned[i], non_blocking=True)
+        pipe.run_dev(d_frames[i].data_ptr(), B, d_res[i].data_ptr(), None)
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert np.array_equal(np.frombuffer(d_res[i].cpu().numpy().tobytes(), frt.RESULT_DTYPE), want[i]), i
+    pipe.set_input_sync(False)
+    pipe.set_stream(None)
+    pipe.close()
+    det.close()
+    rec.close()
