@@ -272,7 +272,11 @@ def main():
     d_res = [torch.zeros(F * RD.itemsize, dtype=torch.uint8, device="cuda") for _ in range(NRING)]
     d_all = [torch.zeros(world * F * RD.itemsize, dtype=torch.uint8, device="cuda") for _ in range(NRING)] if use_dist else None
     h_all = [torch.zeros(world * F * RD.itemsize, dtype=torch.uint8).pin_memory() for _ in range(NRING)] if use_dist else None
-    stream = torch.cuda.current_stream()
+    # NOT torch's default stream: that is the legacy NULL stream, and every operation on it (an event record, a collective's stream
+    # hand-over) is a barrier against all blocking streams - including the pipeline's stage streams - which serialises the stages
+    # (measured: 7.9 instead of 3.6 ms per step).  Everything below runs on an ordinary stream.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     pipe.set_stream(stream.cuda_stream)
     side = torch.cuda.Stream() if use_dist else None       # RCCL all-gather + D2H of the gathered records
     upload = torch.cuda.Stream() if use_dist else None

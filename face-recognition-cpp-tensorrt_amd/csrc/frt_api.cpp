@@ -12,45 +12,24 @@
 #include <string>
 #include <vector>
 
+#include "frt_host.hpp"
 #include "frt_kernels.h"
 #include "frt_weights.hpp"
 
 void launch_pack_results(const frt_bbox *boxes, const int *n_boxes, const int *valid, const int32_t *idx, const float *sim, int max_faces,
                          int F, frt_face_result *out, hipStream_t s);
 
-namespace {
-
-thread_local std::string g_err;
-
-struct FrtError {
-    int code;
-    std::string msg;
-};
-
-[[noreturn]] void raise(int code, const std::string &m) { throw FrtError{code, m}; }
-
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) raise(FRT_ERR_DEVICE, std::string("HIP API failed: ") + #expr + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-template <typename Fn>
-int guarded(Fn &&fn) {
-    try {
-        fn();
-        g_err.clear();
-        return FRT_OK;
-    } catch (const FrtError &e) {
-        g_err = e.msg;
-        return e.code;
-    } catch (const std::exception &e) {
-        g_err = e.what();
-        return FRT_ERR_FORMAT;
-    }
+namespace frthost {
+std::string &last_error() {
+    static thread_local std::string err;
+    return err;
 }
+}  // namespace frthost
+using frthost::guarded;
+using frthost::raise;
+using frthost::use_device;
 
-void use_device(int dev) { HIPCHK(hipSetDevice(dev)); }
+namespace {
 
 // ------------------------------------------------------------------------------------------------ device memory helpers
 struct Arena {
@@ -1290,7 +1269,7 @@ struct frt_pipeline {
 // =====================================================================================================================
 extern "C" {
 
-const char *frt_last_error(void) { return g_err.c_str(); }
+const char *frt_last_error(void) { return frthost::last_error().c_str(); }
 const char *frt_version(void) { return "libfrt 0.1 (gfx950)"; }
 int frt_device_count(void) {
     int n = 0;
