@@ -91,6 +91,15 @@ ABI = {
     "frt_align_faces": (_i, [_vp, _i, _i, _sz, _vp, _i, _vp, _i]),
     "frt_embedder_forward_aligned": (_i, [_vp, _vp, _i, _i, _sz, _vp, _i, _vp, _vp]),
     "frt_pipeline_set_align": (_i, [_vp, _i]),
+    "frt_jpeg_info": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "frt_jpeg_decoder_create": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
+    "frt_jpeg_decoder_destroy": (None, [_vp]),
+    "frt_jpeg_decode_batch_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "frt_jpeg_decode": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "frt_jpeg_read_coefficients": (_i, [_vp, _sz, _vp, _sz, _vp]),
+    "frt_jpeg_encode_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "frt_jpeg_write_jfif": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp]),
+    "frt_base64_encode": (_sz, [_vp, _sz, _vp, _sz]),
     "frt_profile_enable": (_i, [_i]),
     "frt_profile_collect": (_i, [_vp, _sz, _vp, _vp, _i]),
 }
@@ -515,6 +524,98 @@ class Pipeline:
     def close(self):
         if self._h:
             lib.frt_pipeline_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# JPEG frame ingest / reply step (src/app.cpp:296, 328-340)
+# ----------------------------------------------------------------------------------------------------------------------
+def jpeg_info(data):
+    b = np.frombuffer(bytes(data), np.uint8)
+    w, h, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib.frt_jpeg_info(_ptr(b), b.size, ctypes.byref(w), ctypes.byref(h), ctypes.byref(c)))
+    return w.value, h.value, c.value
+
+
+def jpeg_read_coefficients(data):
+    """Host half of the decoder: -> (geometry dict, coef int16 [total_blocks, 64] natural order, not dequantised)."""
+    b = np.frombuffer(bytes(data), np.uint8)
+    g = np.zeros(219, np.int32)
+    _check(lib.frt_jpeg_read_coefficients(_ptr(b), b.size, None, 0, _ptr(g)))
+    coef = np.zeros((int(g[26]), 64), np.int16)
+    _check(lib.frt_jpeg_read_coefficients(_ptr(b), b.size, _ptr(coef), coef.shape[0], _ptr(g)))
+    comps = [dict(zip(("h", "v", "bw", "bh", "dw", "dh", "block0"), (int(x) for x in g[5 + 7 * i:12 + 7 * i]))) for i in range(int(g[2]))]
+    geo = dict(width=int(g[0]), height=int(g[1]), ncomp=int(g[2]), hmax=int(g[3]), vmax=int(g[4]), comps=comps,
+               q=[g[27 + 64 * i:27 + 64 * (i + 1)].astype(np.int32).copy() for i in range(int(g[2]))])
+    return geo, coef
+
+
+def jpeg_write_jfif(quality, width, height, coef_zigzag):
+    c = np.ascontiguousarray(coef_zigzag, np.int16)
+    out = np.zeros(c.size * 3 + 4096, np.uint8)
+    n = ctypes.c_size_t(0)
+    _check(lib.frt_jpeg_write_jfif(int(quality), int(width), int(height), _ptr(c), _ptr(out), out.size, ctypes.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def base64_encode(data):
+    b = np.frombuffer(bytes(data), np.uint8)
+    need = lib.frt_base64_encode(_ptr(b) if b.size else None, b.size, None, 0)
+    out = ctypes.create_string_buffer(need)
+    lib.frt_base64_encode(_ptr(b) if b.size else None, b.size, out, need)
+    return out.value.decode()
+
+
+class JpegCodec:
+    """``cv::imdecode`` in front of the hot path and ``cv::imencode('.jpg')`` behind it: Huffman coding on host threads, transforms on the device."""
+
+    def __init__(self, max_images=32, max_width=1920, max_height=1088, n_threads=0, device=0):
+        self._h = _vp()
+        self.max_images = int(max_images)
+        _check(lib.frt_jpeg_decoder_create(self.max_images, int(max_width), int(max_height), int(n_threads), device, ctypes.byref(self._h)))
+
+    def decode(self, data):
+        """bytes -> u8 BGR [h, w, 3] at the image's own size."""
+        w, h, _ = jpeg_info(data)
+        b = np.frombuffer(bytes(data), np.uint8)
+        out = np.zeros((h, w, 3), np.uint8)
+        _check(lib.frt_jpeg_decode(self._h, _ptr(b), b.size, _ptr(out), out.size, None, None))
+        return out
+
+    def decode_batch_dev(self, blobs, frames_ptr, out_h, out_w, hip_stream=None):
+        """list of bytes -> device frames [n][out_h][out_w][3] at raw address ``frames_ptr`` (asynchronous on ``hip_stream``)."""
+        keep = [np.frombuffer(bytes(b), np.uint8) for b in blobs]
+        n = len(keep)
+        ptrs = (ctypes.c_void_p * n)(*[k.ctypes.data for k in keep])
+        sizes = (ctypes.c_size_t * n)(*[k.size for k in keep])
+        _check(lib.frt_jpeg_decode_batch_dev(self._h, ptrs, sizes, n, _vp(frames_ptr), int(out_h), int(out_w), _vp(hip_stream) if hip_stream else None))
+
+    def encode(self, images, quality=95, device_ptr=None, shape=None):
+        """u8 BGR [n, rows, cols, 3] (host array, or raw device address + ``shape``) -> list of JFIF byte strings."""
+        if device_ptr is None:
+            a = np.ascontiguousarray(images, np.uint8)
+            if a.ndim == 3:
+                a = a[None]
+            n, rows, cols = a.shape[:3]
+            src, dev = _ptr(a), 0
+        else:
+            n, rows, cols = shape
+            src, dev = _vp(device_ptr), 1
+        stride = rows * cols * 3 + 4096
+        out = np.zeros((n, stride), np.uint8)
+        sizes = (ctypes.c_size_t * n)()
+        _check(lib.frt_jpeg_encode_batch(self._h, src, dev, n, rows, cols, int(quality), _ptr(out), stride, sizes))
+        return [out[i, :sizes[i]].tobytes() for i in range(n)]
+
+    def close(self):
+        if self._h:
+            lib.frt_jpeg_decoder_destroy(self._h)
             self._h = _vp()
 
     def __del__(self):

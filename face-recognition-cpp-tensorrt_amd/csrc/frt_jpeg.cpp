@@ -442,12 +442,30 @@ void write_jfif_420(const EncTables &t, int width, int height, const int16_t *co
         }
         if (run) bw.put(t.code[ak][0], t.len[ak][0]);  // EOB
     };
+    // Blocks that lie completely outside the image (they only exist to fill the last MCU column / row) are not transformed pixels in
+    // the IJG encoder: their AC terms are zero and their DC repeats the previous block of the MCU, so that they cost (almost) no bits.
+    const int yw_real = (width + 7) / 8, yh_real = (height + 7) / 8;                    // real luma blocks
+    const int cw_real = ((width + 1) / 2 + 7) / 8, ch_real = ((height + 1) / 2 + 7) / 8;  // real chroma blocks
+    int16_t dummy[64];
     for (int my = 0; my < mcuy; ++my)
         for (int mx = 0; mx < mcux; ++mx) {
+            int prev_dc = 0;  // DC of the previous block in this MCU's luma sequence
             for (int v = 0; v < 2; ++v)
-                for (int h = 0; h < 2; ++h) put_block(coef + ((size_t)(my * 2 + v) * ybw + mx * 2 + h) * 64, 0);
-            put_block(coef + (yblocks + (size_t)my * mcux + mx) * 64, 1);
-            put_block(coef + (yblocks + cblocks + (size_t)my * mcux + mx) * 64, 2);
+                for (int h = 0; h < 2; ++h) {
+                    const int16_t *b = coef + ((size_t)(my * 2 + v) * ybw + mx * 2 + h) * 64;
+                    if (my * 2 + v >= yh_real || mx * 2 + h >= yw_real) {
+                        std::memset(dummy, 0, sizeof(dummy));
+                        dummy[0] = (int16_t)prev_dc;
+                        b = dummy;
+                    }
+                    prev_dc = b[0];
+                    put_block(b, 0);
+                }
+            for (int c = 1; c <= 2; ++c) {  // one chroma block per MCU: it is real iff the MCU reaches into the image (always true)
+                (void)cw_real;
+                (void)ch_real;
+                put_block(coef + (yblocks + (c - 1) * cblocks + (size_t)my * mcux + mx) * 64, c);
+            }
         }
     bw.flush();
     o.push_back(0xFF);

@@ -213,8 +213,8 @@ int frt_pipeline_set_graph(frt_pipeline *p, int enable);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Frame ingest: the caller's `cv::resize(img, img, Size(frameWidth, frameHeight))` (src/app.cpp:166,301;
- * default INTER_LINEAR, 8UC3) on the device, bit-identical to the CPU restatement of OpenCV's fixed-point path.  JPEG decode
- * itself stays with the caller.
+ * default INTER_LINEAR, 8UC3) on the device, bit-identical to the CPU restatement of OpenCV's fixed-point path; and the JPEG decode
+ * in front of it / the JPEG + base64 reply behind the hot path (below).
  * ------------------------------------------------------------------------------------------------------------------ */
 /* host in, host out; out: out_rows x out_cols x 3, tight rows */
 int frt_resize_frame(const uint8_t *bgr, int rows, int cols, size_t row_stride, uint8_t *out, int out_rows, int out_cols, int device);
@@ -222,6 +222,42 @@ int frt_resize_frame(const uint8_t *bgr, int rows, int cols, size_t row_stride, 
  * e.g. straight into the buffer handed to frt_pipeline_run_dev */
 int frt_resize_frames_dev(const void *src_dev, int n, int rows, int cols, size_t row_stride, size_t frame_stride, void *dst_dev,
                           int out_rows, int out_cols, void *hip_stream);
+
+/* JPEG decode in front of the resize (src/app.cpp:296: cv::imdecode(byte_vector, IMREAD_UNCHANGED)) and the reply step behind the
+ * hot path (src/app.cpp:328-340: cv::imencode(".jpg", best crop) + base64).  OpenCV hands both to libjpeg with its defaults (integer
+ * "islow" DCT, triangle-filter chroma upsampling, quality 95, 4:2:0, Annex-K Huffman tables) - all-integer algorithms, reproduced
+ * here bit for bit: Huffman coding on a pool of host threads (it is serial per scan), dequantisation + IDCT + upsampling + colour
+ * conversion (+ the resize) and colour conversion + downsampling + FDCT + quantisation on the device.  Supported streams: baseline /
+ * extended-sequential Huffman, 8 bit, grey or YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling, restart intervals; progressive and
+ * arithmetic-coded streams return FRT_ERR_FORMAT.  Grey images come out with the value replicated to B, G and R. */
+typedef struct frt_jpeg_decoder frt_jpeg_decoder;
+/* header only; any of the out pointers may be NULL */
+int frt_jpeg_info(const uint8_t *data, size_t size, int *width, int *height, int *components);
+/* n_threads <= 0: one host thread per image up to the machine's core count (max 64).  max_images = JPEGs per decode_batch call. */
+int frt_jpeg_decoder_create(int max_images, int max_width, int max_height, int n_threads, int device, frt_jpeg_decoder **out);
+void frt_jpeg_decoder_destroy(frt_jpeg_decoder *d);
+/* n JPEG byte strings -> frames_dev u8 BGR [n][out_h][out_w][3] (device; e.g. the buffer handed to frt_pipeline_run_dev_after).  Images
+ * whose size differs from out_w x out_h are resized like frt_resize_frames_dev (cv::resize default INTER_LINEAR).  The call returns when
+ * the entropy decoding is done and the device work is queued on hip_stream (NULL: the decoder's own stream); the JPEG bytes may be
+ * released then, frames_dev is complete once hip_stream has run. */
+int frt_jpeg_decode_batch_dev(frt_jpeg_decoder *d, const uint8_t *const *data, const size_t *sizes, int n, void *frames_dev, int out_h, int out_w,
+                              void *hip_stream);
+/* one image, host in / host out, at its own size: bgr_out [height][width][3] */
+int frt_jpeg_decode(frt_jpeg_decoder *d, const uint8_t *data, size_t size, uint8_t *bgr_out, size_t capacity, int *width, int *height);
+/* host half only (tests, tools): entropy-decoded, NOT dequantised coefficient blocks [total_blocks][64] in natural order (coef_out may
+ * be NULL) and the geometry: int32[219] = width, height, ncomp, hmax, vmax, 3 x (h, v, blocks_w, blocks_h, samples_w, samples_h, first
+ * block), total_blocks, 3 x 64 quantiser steps (natural order). */
+int frt_jpeg_read_coefficients(const uint8_t *data, size_t size, int16_t *coef_out, size_t coef_capacity_blocks, int32_t *geometry_out);
+/* Reply step: n equally sized u8 BGR images [n][rows][cols][3] (host pointer, or device pointer with device_input = 1, e.g. the crops
+ * of frt_embedder_forward) -> n JFIF streams, slot i at out + i * out_stride, length out_sizes[i].  quality as cv::imencode's
+ * IMWRITE_JPEG_QUALITY (the reference uses the default, 95). */
+int frt_jpeg_encode_batch(frt_jpeg_decoder *d, const void *bgr, int device_input, int n, int rows, int cols, int quality, uint8_t *out, size_t out_stride,
+                          size_t *out_sizes);
+/* host half only: quantised blocks in zigzag order (all luma blocks [2*mcuy][2*mcux], then Cb, then Cr [mcuy][mcux]) -> JFIF stream */
+int frt_jpeg_write_jfif(int quality, int width, int height, const int16_t *coef_zigzag, uint8_t *out, size_t capacity, size_t *size_out);
+/* crow::utility::base64encode (src/app.cpp:331): standard alphabet with '=' padding, NUL-terminated.  Returns the string length, or
+ * the capacity needed (length + 1) when out is NULL or too small. */
+size_t frt_base64_encode(const uint8_t *data, size_t size, char *out, size_t capacity);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Optional 5-point alignment mode (default OFF).  The reference has none: it trims the landmark head off the detector
