@@ -21,7 +21,7 @@ import numpy as np
 from . import dist, synth, weights_io  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfrt.so")
+LIB_PATH = os.environ.get("FRT_LIB") or os.path.join(_HERE, "libfrt.so")  # FRT_LIB: measurement builds (make TUNING=1), tools only
 
 if not os.path.exists(LIB_PATH):
     raise ImportError("libfrt.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

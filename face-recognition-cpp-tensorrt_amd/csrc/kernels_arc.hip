@@ -603,11 +603,12 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
                 if (ABL == 8 || ABL == 9) {
                 } else if (kk + BFD < 4) bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dp + (kk + BFD) * 32);
                 else bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dpn + (kk + BFD - 4) * 32);
-                if (ABL != 1 && ABL != 7 && ABL != 9 && kk == 0 && j == 1) {  // weight fragments of step t+2 into the slot step t-1 used
+                constexpr int JL = NT > 1 ? 1 : 0;  // pixel-tile slot that carries the loads of future steps
+                if (ABL != 1 && ABL != 7 && ABL != 9 && kk == 0 && j == JL) {  // weight fragments of step t+2 into the slot step t-1 used
                     constexpr int T2 = TAP + LA;
                     load_w(T2 < 9 ? c : c + 1, T2 % 9, std::integral_constant<int, (T2 % 9) % WR>{});
                 }
-                if (ABL != 1 && ABL != 6 && ABL != 9 && kk == 1 && j == 1 && !SINGLE && TAP < PT)
+                if (ABL != 1 && ABL != 6 && ABL != 9 && kk == 1 && j == JL && !SINGLE && TAP < PT)
                     issue_patch(c + 1, std::integral_constant<int, (TAP < PT ? TAP : 0) * PPS>{}, std::integral_constant<int, PPS>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -921,36 +922,64 @@ void launch_glds_t(const ConvMfmaArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((conv_glds_kernel<WCO, WPX, NSTAGE, ABL>), grid, dim3(256), lds, s, a);
 }
 
-// strip geometry for the patch kernel; returns false when the layer is not eligible
-bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &single) {
+// strip geometry for the patch kernel; returns false when the layer is not eligible.  nt = pixel tiles per strip (1, 2, 4 or 7: the
+// instantiations below).  The strip height follows the BATCH: a strip as tall as fits 7 tiles gives the best weight-fragment reuse, but
+// the grids are then sized for >= 128 faces (14x14x256 at 32 faces: 64 workgroups on 256 CUs, and a 32-face pass cost 66 % of a
+// 128-face one).  With fewer faces the strips get shorter until the launch has about one workgroup per CU again.
+bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &single, int &nt) {
     // pair mode measured: 56x56 layers 91-105 -> 87-95 us, but the 112x112 layer 306 -> 348 us (it is HBM-bound: 205 MB in, 205 MB
     // out, and a 2-row strip re-reads its halo rows twice) - so the 112x112 layer stays on the im2col LDS-DMA kernel
     const bool pair = a.Cout == 64 && a.Cin == 64 && a.H <= 56;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || (a.Cout % 128 && !pair) || a.Cin % 64 || a.splits != 1 || a.H != a.W) return false;
     if (a.mode == EPI_PARTIAL) return false;
     if (a.mode == EPI_BN_ADD_BN && !(a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
+    single = a.Cin == 64;
+    const int co_tiles = pair ? 1 : a.Cout / 128;
+    static const bool small_ok = !(frt_tuning_env("FRT_CONV_SMALL_BATCH") && frt_tuning_env("FRT_CONV_SMALL_BATCH")[0] == '0');
+    constexpr int kWant = 224;  // workgroups that count as "fills the 256 CUs"
+    auto tiles_for = [](int px) { return px <= 32 ? 1 : (px <= 64 ? 2 : (px <= 128 ? 4 : (px <= 224 ? 7 : 0))); };
+    auto slots_of = [&](int r, int ni) { return (ni * (r + 2) * (a.W + 2) * 9 + 255) / 256; };
+    auto fits = [&](int r, int ni, int t) {  // LDS budget of the instantiation that serves t tiles (see launch_conv_mfma)
+        const int sl = slots_of(r, ni);
+        if (pair) return t == 7 && ni * (r + 2) * (a.W + 2) * 9 <= 34 * 128;
+        if (single) return t == 7 && sl <= 15;
+        return t == 7 ? sl <= 12 : (t == 4 ? sl <= 10 : sl <= 5);
+    };
+    R = 0;
+    n_img = 1;
+    nt = 0;
     if (a.H * a.W <= 56) {
-        // whole small images per strip.  4 images (7 tiles) leave 7x7x512 at 32 strips x 4 cout tiles = 128 workgroups on 256 CUs;
-        // 2 images (4 tiles, NT = 4 instantiation) double the grid for the same total MFMA work
+        // whole small images per strip: 2 images (98 pixels, 4 tiles) put 7x7x512 at 64 strips x 4 cout tiles = 256 workgroups for 128
+        // faces (4 images / 7 tiles would leave 128); below 128 faces one image per strip (2 tiles)
         static const int small_nt = frt_tuning_env("FRT_CONV_SMALL_NT") ? atoi(frt_tuning_env("FRT_CONV_SMALL_NT")) : 4;
-        n_img = (small_nt * 32) / (a.H * a.W);
-        R = a.H;
+        for (int ni : {(small_nt * 32) / (a.H * a.W), 1}) {
+            if (ni < 1) continue;
+            const int t = tiles_for(ni * a.H * a.W);
+            if (!t || !fits(a.H, ni, t)) continue;
+            if (!R || (small_ok && ((a.B + n_img - 1) / n_img) * co_tiles < kWant)) {
+                R = a.H;
+                n_img = ni;
+                nt = t;
+            }
+        }
+        if (!R) return false;
     } else {
-        n_img = 1;
-        R = 0;
         static const int lim14 = frt_tuning_env("FRT_CONV_NT4_14") ? 128 : 224;  // experiment: half-image strips (4 tiles) on the 14x14 layers
         const int lim = a.H == 14 ? lim14 : 224;
-        for (int d = 1; d <= a.H; ++d)
-            if (a.H % d == 0 && d * a.W <= lim) R = d;
+        for (int d = a.H; d >= 1; --d) {  // tallest strip first
+            if (a.H % d || d * a.W > lim) continue;
+            // slots are enumerated over the padded row width when that still fits the same number of tiles (conflict-free LDS reads)
+            int t = tiles_for(d * (a.W + 2));
+            if (!t || t != tiles_for(d * a.W)) t = tiles_for(d * a.W);
+            if (!t || !fits(d, 1, t)) continue;
+            if (d * a.W * 10 < t * 32 * 7) continue;  // more than 30 % dead pixel slots
+            R = d;
+            nt = t;
+            if (!small_ok || a.B * (a.H / d) * co_tiles >= kWant) break;  // (else: keep shortening; the shortest eligible strip stays)
+        }
         if (!R) return false;
     }
-    if (n_img * R * a.W < (n_img * R * a.W <= 128 ? 96 : 160)) return false;  // too many dead pixel slots
-    const int NP = n_img * (R + 2) * (a.W + 2);
-    const int slots = (NP * 9 + 255) / 256;
-    single = a.Cin == 64;
-    pps = slots;  // DMA slots (1 KB per wave each) the patch image needs
-    if (pair) return NP * 9 <= 34 * 128;
-    if (single ? slots > 15 : slots > 12) return false;  // LDS budget, see launch_patch_t instantiations
+    pps = slots_of(R, n_img);  // DMA slots (1 KB per wave each) the patch image needs
     return true;
 }
 
@@ -982,16 +1011,18 @@ int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage
 }  // namespace
 
 // Which kernel symbol a launch resolves to (also the profiling label, so bench.py / rocprofv3 can be matched by name).
-enum { CV_V1_22, CV_V1_14, CV_G2_22, CV_G2_14, CV_G3_22, CV_G3_14, CV_P_PAIR, CV_P_SINGLE, CV_P_255, CV_P_264, CV_P_255_NT4 };
+enum { CV_V1_22, CV_V1_14, CV_G2_22, CV_G2_14, CV_G3_22, CV_G3_14, CV_P_PAIR, CV_P_SINGLE, CV_P_255, CV_P_264, CV_P_255_NT4, CV_P_NT2, CV_P_NT1 };
 static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
     const int impl = conv_impl();
     static const int use_patch = frt_tuning_env("FRT_CONV_PATCH") ? atoi(frt_tuning_env("FRT_CONV_PATCH")) : 1;
-    int slots;
+    int slots, nt;
     bool single;
-    if (impl >= 2 && use_patch && patch_geometry(a, R, n_img, slots, single)) {
+    if (impl >= 2 && use_patch && patch_geometry(a, R, n_img, slots, single, nt)) {
         if (a.Cout == 64) return CV_P_PAIR;   // pair mode: 2 strips x 68 KB patch
         if (single) return CV_P_SINGLE;       // 15 slots (60 KB)
-        if (n_img * R * a.W <= 128 && slots <= 10) return CV_P_255_NT4;  // 4 pixel tiles per strip (small maps)
+        if (nt == 1) return CV_P_NT1;         // short strips for small batches: 2 x 20 KB patch buffers
+        if (nt == 2) return CV_P_NT2;
+        if (nt == 4) return CV_P_255_NT4;     // 4 pixel tiles per strip (small maps)
         return slots <= 10 ? CV_P_255 : CV_P_264;  // 2 x 40 KB / 2 x 48 KB patch buffers
     }
     const bool wide = a.Cout % 128 == 0;
@@ -1004,7 +1035,8 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
     static const char *names[] = {"conv_mfma_kernel<2, 2>", "conv_mfma_kernel<1, 4>", "conv_glds_kernel<2, 2, 2, 0>", "conv_glds_kernel<1, 4, 2, 0>",
                                   "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true, 7, 2, 3>",
                                   "conv_patch_kernel<3, 5, 5, true, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 7, 1, 3>",
-                                  "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3>"};
+                                  "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3>",
+                                  "conv_patch_kernel<5, 1, 5, false, 0, false, 2, 1, 3>", "conv_patch_kernel<5, 1, 5, false, 0, false, 1, 1, 3>"};
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
@@ -1051,6 +1083,8 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 19) return launch_patch_t<2, 5, 5, false, 0, false, 4, 1>(a, R, n_img, s);
 #endif
             return launch_patch_t<10, 1, 5, false, 0, false, 4, 1>(a, R, n_img, s);
+        case CV_P_NT2: return launch_patch_t<5, 1, 5, false, 0, false, 2, 1>(a, R, n_img, s);
+        case CV_P_NT1: return launch_patch_t<5, 1, 5, false, 0, false, 1, 1>(a, R, n_img, s);
         case CV_V1_22: return launch_conv_t<2, 2>(a, s);
         case CV_V1_14: return launch_conv_t<1, 4>(a, s);
         case CV_G2_22:

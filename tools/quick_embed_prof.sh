@@ -11,6 +11,6 @@ f=glob.glob('/tmp/pe/**/*kernel_stats.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print('total ms/pass', round(tot/5e6,3))
-for r in rows[:6]: print(' ', r['Name'].replace('(anonymous namespace)::','')[:80], r['Calls'], round(float(r['AverageNs'])/1e3,1), 'min', round(float(r['MinNs'])/1e3,1))
+for r in rows[:int(__import__('os').environ.get('NROWS','14'))]: print(' ', r['Name'].replace('(anonymous namespace)::','')[:80], r['Calls'], round(float(r['AverageNs'])/1e3,1), 'min', round(float(r['MinNs'])/1e3,1))
 PY
 done
