@@ -505,6 +505,7 @@ void frt_detector::postprocess(int n, hipStream_t s, frt_bbox *boxes_out, int *n
 struct ArcUnit {
     int cin, depth, stride, h_in;  // input spatial size (square)
     half_t *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;
+    half_t *w1f = nullptr, *w2f = nullptr;  // fragment-ordered copies for the strip kernel (stride-1 3x3 convs)
     float *prelu = nullptr, *s2 = nullptr, *b2 = nullptr, *ssc = nullptr, *bsc = nullptr;
     float *sn = nullptr, *bn = nullptr;  // BatchNorm that consumes this unit's output (next unit's leading BN / output_layer.0)
     float *se_w1 = nullptr, *se_w2 = nullptr;
@@ -581,6 +582,22 @@ std::vector<uint16_t> conv_w_f16(const frt::Blob &b, const std::string &name, in
             for (int t = 0; t < ks * ks; ++t) w[((size_t)co * ks * ks + t) * cin + ci] = frt::f32_to_f16(src[((size_t)co * cin + ci) * ks * ks + t]);
     return w;
 }
+// 3x3 weights in the order the strip kernel's MFMA A fragments consume them: [Cout/32][Cin/64][tap][kk][lane = (k half, cout row)][8]
+// (kernels_arc.hip: conv_patch_kernel); a wave's load of one fragment is then one contiguous kilobyte.  Empty unless Cin % 64 == 0.
+std::vector<uint16_t> conv_w_f16_frag(const frt::Blob &b, const std::string &name, int cout, int cin) {
+    if (cin % 64 || cout % 32) return {};
+    const float *src = b.get(name, (size_t)cout * cin * 9).data;
+    std::vector<uint16_t> w((size_t)cout * cin * 9);
+    const int nch = cin / 64;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const int blk = co >> 5, r = co & 31, ch = ci >> 6, kk = (ci & 63) >> 4, hi = (ci & 15) >> 3, e = ci & 7;
+                const size_t off = (((((size_t)blk * nch + ch) * 9 + t) * 4 + kk) * 64 + hi * 32 + r) * 8 + e;
+                w[off] = frt::f32_to_f16(src[((size_t)co * cin + ci) * 9 + t]);
+            }
+    return w;
+}
 std::vector<float> vec_of(const frt::Blob &b, const std::string &name, size_t n) {
     const float *p = b.get(name, n).data;
     return std::vector<float>(p, p + n);
@@ -624,6 +641,14 @@ void frt_embedder::build(const frt::Blob &b) {
             a.h_in = h;
             const std::string p = "body." + std::to_string(idx);
             a.w1 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".res_layer.1.weight", a.depth, a.cin, 3)));
+            {  // conv1 is always stride 1; conv2 only in the units that keep the resolution
+                const std::vector<uint16_t> f1 = conv_w_f16_frag(b, p + ".res_layer.1.weight", a.depth, a.cin);
+                if (!f1.empty()) a.w1f = reinterpret_cast<half_t *>(arena.upload(f1));
+                if (a.stride == 1) {
+                    const std::vector<uint16_t> f2 = conv_w_f16_frag(b, p + ".res_layer.3.weight", a.depth, a.depth);
+                    if (!f2.empty()) a.w2f = reinterpret_cast<half_t *>(arena.upload(f2));
+                }
+            }
             a.prelu = arena.upload(vec_of(b, p + ".res_layer.2.weight", a.depth));
             a.w2 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".res_layer.3.weight", a.depth, a.depth, 3)));
             frt::bn_fold(b, p + ".res_layer.4", a.depth, sc, bi);
@@ -720,6 +745,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             ConvMfmaArgs a{};
             a.x = Z[cur];
             a.w = u.w1;
+            a.wf = u.w1f;
             a.B = F; a.H = h; a.W = h; a.Cin = u.cin; a.Ho = h; a.Wo = h; a.Cout = u.depth; a.ks = 3; a.stride = 1; a.pad = 1;
             a.mode = EPI_PRELU;
             a.p0 = u.prelu;
@@ -755,6 +781,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             ConvMfmaArgs a{};
             a.x = T;
             a.w = u.w2;
+            a.wf = u.w2f;
             a.B = F; a.H = h; a.W = h; a.Cin = u.depth; a.Ho = ho; a.Wo = ho; a.Cout = u.depth; a.ks = 3; a.stride = u.stride; a.pad = 1;
             a.p0 = u.s2;
             a.p1 = u.b2;
@@ -818,8 +845,8 @@ struct frt_matcher {
     int q_cap = 0;
     size_t full_cap = 0;
     int blocks = 0;
-    // screened top-1 (fp16 shadow gallery; see kernels_match.hip).  Off for small galleries, for D % 64 != 0 (the coarse kernel
-    // walks K in steps of 64) and with FRT_MATCH_SCREEN=0.
+    // screened top-1 (fp16 shadow gallery; see kernels_match.hip).  Off for small galleries, for widths the coarse kernel is not
+    // instantiated for (anything but 64 / 128 / 256 / 512) and with FRT_MATCH_SCREEN=0.
     half_t *d_g16 = nullptr;   // fp16 shadow of d_gallery, or the fp16-STORED gallery itself
     bool store16 = false;      // current gallery is fp16-stored
     bool want16 = false;       // storage mode of the NEXT init / gallery_begin (frt_matcher_set_storage)
@@ -893,7 +920,8 @@ struct frt_matcher {
         ld.rows = ld.fill = ld.cur = 0;
         if (cap > 0) {
             if (ld.f16) {
-                HIPCHK(hipMalloc(reinterpret_cast<void **>(&ld.d_new16), (size_t)cap * cols * sizeof(half_t)));
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&ld.d_new16), gallery16_elems(cap, cols) * sizeof(half_t)));
+                HIPCHK(hipMemsetAsync(ld.d_new16, 0, gallery16_elems(cap, cols) * sizeof(half_t), ld.s));  // fragment order, zero pad rows
                 for (int i = 0; i < Load::NCH; ++i)
                     if (!ld.d_stage[i]) HIPCHK(hipMalloc(reinterpret_cast<void **>(&ld.d_stage[i]), need * sizeof(float)));
             } else {
@@ -908,7 +936,7 @@ struct frt_matcher {
         const size_t off = (size_t)(ld.rows - ld.fill) * ld.D, n = (size_t)ld.fill * ld.D;
         if (ld.f16) {
             HIPCHK(hipMemcpyAsync(ld.d_stage[c], ld.h_stage[c], n * sizeof(float), hipMemcpyHostToDevice, ld.s));
-            launch_rows_to_half(ld.d_stage[c], ld.d_new16 + off, (long)(n / 8), ld.s);
+            launch_rows_to_half(ld.d_stage[c], (long)(ld.rows - ld.fill), (long)ld.fill, ld.D, ld.d_new16, ld.s);  // (chunks start on 128-row tiles)
         } else {
             HIPCHK(hipMemcpyAsync(ld.d_new32 + off, ld.h_stage[c], n * sizeof(float), hipMemcpyHostToDevice, ld.s));
         }
@@ -962,7 +990,7 @@ struct frt_matcher {
         if (old16) (void)hipFree(old16);
         blocks = match_top1_blocks(N, 0);
         const char *scr_env = getenv("FRT_MATCH_SCREEN");
-        screen = N >= 32768 && D % 64 == 0 && !(scr_env && scr_env[0] == '0');
+        screen = N >= 32768 && match_screen_supported(D) && !(scr_env && scr_env[0] == '0');
         gmax_norm = 0.f;
         if (N > 0 && (screen || store16)) {  // fp16 shadow copy (fp32 storage) + the largest row norm (rounding bound of the screening pass)
             int *d_bits = nullptr;
@@ -970,7 +998,7 @@ struct frt_matcher {
             if (store16) {
                 launch_gallery_norm16(d_g16, N, D, d_bits, stream);
             } else {
-                HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_g16), (size_t)N * D * sizeof(half_t)));
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_g16), gallery16_elems(N, D) * sizeof(half_t)));
                 launch_gallery_shadow(d_gallery, N, D, d_g16, d_bits, stream);
             }
             int bits = 0;
@@ -1004,7 +1032,7 @@ struct frt_matcher {
             const size_t tiles = ((size_t)N + 127) / 128;
             free_screen_scratch();
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.q16), (size_t)cap * D * sizeof(half_t)));
-            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tilemax), (size_t)cap * tiles * 4 * sizeof(float)));  // up to 4 coarse entries per tile
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tilemax), (size_t)cap * tiles * 4 * sizeof(float)));  // 4 coarse entries per tile (one per wave)
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_flags), (tiles + 1) * sizeof(int)));  // [tiles] flags + the candidate count:
             scr.count = scr.tile_flags + tiles;                                                           // one contiguous range to clear per call
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_list), tiles * sizeof(int)));

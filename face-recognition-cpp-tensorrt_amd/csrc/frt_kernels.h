@@ -61,7 +61,11 @@ void launch_match_top1_h(const half_t *g16, int N, int D, const float *queries, 
                          int32_t *idx_out, float *sim_out, int row_offset, hipStream_t s);
 void launch_match_full_h(const half_t *g16, int N, int D, const float *queries, int F, float *out, hipStream_t s);
 void launch_gallery_norm16(const half_t *g16, int N, int D, int *max_norm2_bits, hipStream_t s);
-void launch_rows_to_half(const float *in, half_t *out, long n8, hipStream_t s);
+// The fp16 gallery (shadow or stored) is kept in MFMA-fragment order and padded to whole 128-row tiles (see kernels_match.hip):
+size_t gallery16_elems(int N, int D);
+bool match_screen_supported(int D);  // D the coarse kernel is instantiated for
+// fp32 rows [n_rows][D] (first row = global row row0, a multiple of 128) -> their place in the fp16 gallery (which must be zero-filled first)
+void launch_rows_to_half(const float *in, long row0, long n_rows, int D, half_t *g16, hipStream_t s);
 
 // ---------------------------------------------------------------- post-processing (kernels_post.hip)
 struct DetGeom {
@@ -153,6 +157,7 @@ enum { EPI_PRELU = 0, EPI_BN = 1, EPI_BN_ADD_BN = 2, EPI_PARTIAL = 3 };
 struct ConvMfmaArgs {
     const half_t *x;   // [B][H][W][Cin]
     const half_t *w;   // [Cout][ks*ks*Cin]
+    const half_t *wf;  // optional fragment-ordered copy for the strip kernel: [Cout/32][Cin/64][9][4][64 lanes][8] (3x3, Cin % 64 == 0); null: none
     int B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad;
     int mode;
     const float *p0, *p1, *p2, *p3;

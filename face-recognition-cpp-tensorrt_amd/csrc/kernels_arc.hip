@@ -485,7 +485,6 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     const int row0 = (strip % strips_per_img) * R;
 
     const int n_chunks = p.Cin >> 6;
-    const long Ktot = 9L * p.Cin;
 
     // ---- patch DMA descriptors: slot q of this lane covers 16-byte chunk g = (q*4 + wave)*64 + lane of the patch image
     int poff[NSLOT];
@@ -506,7 +505,11 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     //      four 16-byte fragments (kk = 0..3) of W[co_base + wave*32 + r][tap][chunk*64 + (kk*2+hi)*8 ..] straight from L2 into
     //      registers, two steps ahead (register ring of 3 steps, index = tap % 3 at compile time).  This removes the weight
     //      tile from the LDS write AND read paths - LDS bandwidth (fragment reads + LDS-DMA writes) was the binding resource.
-    const half_t *wrow = p.w + (long)(co_base + cow + r) * Ktot + hi * 8;
+    //      The fragments come from a second, FRAGMENT-ORDERED copy of the weights (p.wf, packed by the host at load time):
+    //      [32-cout block][64-channel chunk][tap][kk][lane][8 halfs], so each of these loads is one contiguous kilobyte per wave and a
+    //      wave walks its 32 couts' weights as one sequential stream (row-major rows made every load touch 32 different 128-byte lines,
+    //      32 bytes of each: four times the address/tag work for the same bytes).
+    const half_t *wfrag = p.wf + ((long)((co_base + cow) >> 5) * n_chunks) * (9 * 4 * 512) + lane * 8;
     // ---- B-fragment base addresses: pixel slot -> patch row of tap (0,0)
     int pbase[NT];
 #pragma unroll
@@ -528,9 +531,9 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     constexpr int LA = WR - 1;  // weight fragments are fetched LA steps ahead
     auto load_w = [&](int c, int tap, auto slot_c) {  // wave-uniform c, tap; clamped at the tail (values unused there)
         constexpr int S = decltype(slot_c)::value;
-        const int woff = (ABL == 13) ? 0 : (c < n_chunks ? tap * p.Cin + (c << 6) : 0);  // 13: every step re-reads the same fragments (cache hits)
+        const int woff = (ABL == 13) ? 0 : (c < n_chunks ? (c * 9 + tap) * (4 * 512) : 0);  // 13: every step re-reads the same fragments (cache hits)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) areg[S][kk] = *reinterpret_cast<const half8 *>(wrow + woff + kk * 16);
+        for (int kk = 0; kk < 4; ++kk) areg[S][kk] = *reinterpret_cast<const half8 *>(wfrag + woff + kk * 512);
     };
     auto issue_patch = [&](int c, auto q0_c, auto nq_c) {
         constexpr int Q0 = decltype(q0_c)::value, NQ = decltype(nq_c)::value;
@@ -930,6 +933,7 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     // pair mode measured: 56x56 layers 91-105 -> 87-95 us, but the 112x112 layer 306 -> 348 us (it is HBM-bound: 205 MB in, 205 MB
     // out, and a 2-row strip re-reads its halo rows twice) - so the 112x112 layer stays on the im2col LDS-DMA kernel
     const bool pair = a.Cout == 64 && a.Cin == 64 && a.H <= 56;
+    if (!a.wf) return false;  // the strip kernel streams the fragment-ordered weight copy
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || (a.Cout % 128 && !pair) || a.Cin % 64 || a.splits != 1 || a.H != a.W) return false;
     if (a.mode == EPI_PARTIAL) return false;
     if (a.mode == EPI_BN_ADD_BN && !(a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;

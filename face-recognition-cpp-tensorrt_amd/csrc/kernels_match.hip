@@ -28,11 +28,22 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return (v > bv) || (v == bv && i < bi); }
 
-// GT: storage type of the gallery rows (float: the reference's layout; half_t: fp16-stored shard, BASELINE config 5 - the stored
-// values are widened exactly to fp32 on the way into LDS, all arithmetic stays the same fp32 fmaf chain).
-__device__ __forceinline__ floatx4 load_row4(const float *p) { return *reinterpret_cast<const floatx4 *>(p); }
-__device__ __forceinline__ floatx4 load_row4(const half_t *p) {
-    const half4 h = *reinterpret_cast<const half4 *>(p);
+// GT: storage type of the gallery rows (float: the reference's row-major layout; half_t: the fp16 gallery - shadow copy for the
+// screening pass or the fp16-STORED shard of BASELINE config 5; stored values are widened exactly to fp32 on the way into LDS, all
+// arithmetic stays the same fp32 fmaf chain).
+//
+// The fp16 gallery is NOT row-major: it is kept in the order the coarse kernel's MFMA A fragments consume it, so that every
+// wave-level load of the 1 GB scan is ONE contiguous kilobyte (8 full 128-byte lines).  Row g, column k lives at
+//   ((((g >> 7) * 4 + ((g >> 5) & 3)) * (D / 16) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (g & 31)) * 8 + (k & 7)
+// i.e. [128-row tile][32-row wave block][16-wide k step][lane = (k half, row)][8 halfs].  (Row-major rows made a lane fetch 16 bytes
+// of its own 1 KB row per instruction: 32 different lines per load, each line requested four times - both earlier coarse kernels
+// stalled at 4.0 TB/s on it.)  The allocation is padded to whole 128-row tiles; pad rows are zero.
+__device__ __forceinline__ long g16_index(long g, int k, int D) {
+    return ((((g >> 7) * 4 + ((g >> 5) & 3)) * (long)(D >> 4) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (g & 31)) * 8 + (k & 7);
+}
+__device__ __forceinline__ floatx4 load_g4(const float *G, long g, int D, int k) { return *reinterpret_cast<const floatx4 *>(G + g * D + k); }
+__device__ __forceinline__ floatx4 load_g4(const half_t *G, long g, int D, int k) {  // k % 4 == 0: four columns never straddle an 8-group
+    const half4 h = *reinterpret_cast<const half4 *>(G + g16_index(g, k, D));
     return floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(256) void match_kernel(const GT *__restrict__ G, in
         for (int i = 0; i < 4; ++i) {
             const int row = ld_row + 32 * i;
             const long g = (long)tile * BM + row;
-            ga[i] = g < N ? load_row4(G + g * D + k0 + ld_ch * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+            ga[i] = g < N ? load_g4(G, g, D, k0 + ld_ch * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
@@ -233,13 +244,13 @@ __global__ __launch_bounds__(64) void match_reduce_kernel(const MatchPartial *__
 // The exact fp32 scan above is bound by the fp32 matrix rate for a 128-face batch (2*512*N*F flop at <= 157 TF/s).  Screening
 // makes the common case HBM-bound instead without changing a single result bit:
 //   1. coarse: S~[q][g] on v_mfma_f32_32x32x16_f16 from an fp16 shadow copy of the gallery (half the bytes, 16x the matrix
-//      rate); only the maximum per (query, 128-row tile) is kept;
+//      rate; kept in MFMA-fragment order so that the scan is made of contiguous 1 KB loads); only the maximum per (query, 32-row
+//      block of a 128-row tile) is kept;
 //   2. select: with fp16-rounded inputs and fp32 accumulation |S~ - S| <= delta_q = 1.2e-3 * ||q|| * max_g ||g|| (2^-10 from the
 //      two roundings via Cauchy-Schwarz, plus accumulation slack), so every row that attains the exact maximum of query q lives
 //      in a tile whose coarse maximum is >= (best coarse maximum of q) - 2*delta_q.  Those tiles go on a list (each once);
 //   3. exact: match_kernel runs over the listed tiles only, for all queries - the same code path per tile as the full scan,
 //      so similarities are bitwise those of the full scan and the first-index tie rule is unchanged.  Extra tiles are harmless.
-constexpr int CBK = 64;  // halfs per k-step of the coarse kernel (128-byte rows)
 
 // (also clears `nzero` ints at `zero`: the screened search's tile flags + candidate count, which used to be two memset launches)
 __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ in, half_t *__restrict__ out, long n8, int *__restrict__ zero, long nzero) {
@@ -251,13 +262,32 @@ __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ 
     *reinterpret_cast<half8 *>(out + i * 8) = o;
 }
 
+// fp32 rows [n_rows][D] (row-major, row 0 = global row row0 of the gallery) -> fragment-ordered fp16 gallery.  thread = one 16-byte
+// output piece (8 halfs); consecutive threads write consecutive pieces.
+__global__ __launch_bounds__(256) void gallery_to_half_kernel(const float *__restrict__ in, long row0, long n_rows, int D, half_t *__restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;  // piece index relative to the first tile touched
+    const int KS = D >> 4;
+    const long tile0 = row0 >> 7;
+    const long piece = t + tile0 * 4 * KS * 64;           // absolute piece index in the fragment-ordered gallery
+    const long blk = piece >> 6;                           // (tile, wave, kstep)
+    const int lane = (int)(piece & 63), hi = lane >> 5, r = lane & 31;
+    const int ks = (int)(blk % KS);
+    const long tw = blk / KS;
+    const long g = (tw >> 2) * 128 + (tw & 3) * 32 + r;
+    if (g < row0 || g >= row0 + n_rows) return;           // rows of other chunks / the zero padding of the last tile
+    const float *src = in + (g - row0) * D + ks * 16 + hi * 8;
+    const floatx4 a = *reinterpret_cast<const floatx4 *>(src), b = *reinterpret_cast<const floatx4 *>(src + 4);
+    half8 o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+    *reinterpret_cast<half8 *>(out + piece * 8) = o;
+}
+
 // max over rows of ||g||^2 (non-negative floats order like their bit patterns -> atomicMax on the int view); one wave per row
 template <typename GT>
 __global__ __launch_bounds__(256) void row_norm_max_kernel(const GT *__restrict__ G, int N, int D, int *__restrict__ out_bits) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     float s = 0.f;
     for (int k = lane * 4; k < D && row < N; k += 256) {
-        const floatx4 v = load_row4(G + (long)row * D + k);
+        const floatx4 v = load_g4(G, (long)row, D, k);
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
@@ -267,102 +297,17 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const GT *__restrict_
     if (threadIdx.x == 0) atomicMax(out_bits, __float_as_int(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
-__global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restrict__ G, int N, int D, const half_t *__restrict__ Q, int F,
-                                                           float *__restrict__ tilemax, int num_tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t *As = reinterpret_cast<half_t *>(smem);                 // [2][128][64]
-    half_t *Bs = As + 2 * 128 * CBK;                               // [2][128][64]
-    float *red = reinterpret_cast<float *>(Bs + 2 * 128 * CBK);    // [4][128]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hi = lane >> 5;
-    const int q0 = blockIdx.y * 128;
-    const int ksteps = D / CBK;
-    const int my_tiles = num_tiles > (int)blockIdx.x ? (num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    const int total = my_tiles * ksteps;
-    const int ld_row = tid >> 3, ld_ch = tid & 7;
-    half8 ga[4], qa[4];
-    auto load_global = [&](int it) {
-        const int tile = blockIdx.x + (it / ksteps) * gridDim.x;
-        const int k0 = (it % ksteps) * CBK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long g = (long)tile * 128 + ld_row + 32 * i;
-            // streamed once per call: non-temporal, so that the 1 GB scan does not push the recogniser's activations out of L2 / MALL
-            ga[i] = g < N ? __builtin_nontemporal_load(reinterpret_cast<const half8 *>(G + g * D + k0 + ld_ch * 8)) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-            const int q = q0 + ld_row + 32 * i;
-            qa[i] = q < F ? *reinterpret_cast<const half8 *>(Q + (long)q * D + k0 + ld_ch * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    };
-    auto store_lds = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = ld_row + 32 * i;
-            *reinterpret_cast<half8 *>(As + buf * 128 * CBK + row * CBK + swz(row, ld_ch) * 8) = ga[i];
-            *reinterpret_cast<half8 *>(Bs + buf * 128 * CBK + row * CBK + swz(row, ld_ch) * 8) = qa[i];
-        }
-    };
-    floatx16 acc[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-    if (total > 0) {
-        load_global(0);
-        store_lds(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int it = 0; it < total; ++it) {
-        if (it + 1 < total) load_global(it + 1);
-        const half_t *Ab = As + cur * 128 * CBK, *Bb = Bs + cur * 128 * CBK;
-        const int arow = wave * 32 + r;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ch = kk * 2 + hi;
-            const half8 a8 = *reinterpret_cast<const half8 *>(Ab + arow * CBK + swz(arow, ch) * 8);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int brow = n * 32 + r;
-                const half8 b8 = *reinterpret_cast<const half8 *>(Bb + brow * CBK + swz(brow, ch) * 8);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[n], 0, 0, 0);
-            }
-        }
-        if (it + 1 < total) store_lds(cur ^ 1);
-        const bool last = (it % ksteps) == ksteps - 1;
-        const int tile = blockIdx.x + (it / ksteps) * gridDim.x;
-        if (last) {  // per-query maximum over this wave's 32 gallery rows (rows beyond N are excluded)
-            const int gbase = tile * 128 + wave * 32;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                float m = -INFINITY;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int g = gbase + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    if (g < N) m = fmaxf(m, acc[n][e]);
-                    acc[n][e] = 0.f;
-                }
-                m = fmaxf(m, __shfl_xor(m, 32));
-                if (hi == 0) red[wave * 128 + n * 32 + r] = m;
-            }
-        }
-        __syncthreads();
-        if (last && tid < 128 && q0 + tid < F)
-            tilemax[(long)(q0 + tid) * num_tiles + tile] = fmaxf(fmaxf(red[tid], red[128 + tid]), fmaxf(red[256 + tid], red[384 + tid]));
-        cur ^= 1;
-    }
-}
-
-// ---------------------------------------------------------------- coarse pass v2: queries resident in LDS, gallery rows straight to registers
-// v1 moves BOTH operands global -> registers -> LDS every 64-wide k-step (the 128 queries are re-fetched for every gallery tile)
-// and reached 3.2 TB/s on the fp16 shadow gallery.  Here a persistent workgroup (one per CU) keeps the whole fp16 query block
-// [128][D] in LDS (133 KB, rows padded by 16 B: conflict-free ds_read_b128) for its lifetime and streams its gallery tiles -
-// 128 rows, one 32-row MFMA block per wave - straight from HBM into A-fragment registers: lane (row r, half hi) reads the 16-byte
-// pieces of its own row.  The A registers form a ring exactly one tile deep: register ks is consumed by the MFMAs of k-step ks
-// and immediately refilled with the same k-step of the NEXT tile, i.e. every load has a full tile of MFMAs (4096 clk, about the
-// HBM latency under load) to land, with 128 KB per CU in flight.  LDS carries only the query fragments.
+// ---------------------------------------------------------------- coarse pass: queries resident in LDS, gallery fragments straight to registers
+// A persistent workgroup (one per CU) keeps the whole fp16 query block [128][D] in LDS (133 KB at D = 512, rows padded by 16 B:
+// conflict-free ds_read_b128) for its lifetime and streams its gallery tiles - 128 rows, one 32-row MFMA block per wave - from HBM
+// straight into A-fragment registers: thanks to the fragment-ordered gallery layout every load instruction of a wave is one contiguous
+// kilobyte.  The A registers form a ring exactly one tile deep: register ks is consumed by the MFMAs of k-step ks and immediately
+// refilled with the same k-step of the NEXT tile, i.e. every load has a full tile of MFMAs (4096 clk) to land, with 128 KB per CU in
+// flight.  LDS carries only the query fragments.  No barrier in the loop (a barrier per tile stalls the load stream - loads are only
+// issued from MFMA steps - and cost ~20 % of the bandwidth): every wave writes its own maximum, four coarse entries per tile.
 template <int D>
-__global__ __launch_bounds__(256) void match_coarse2_kernel(const half_t *__restrict__ G, int N, const half_t *__restrict__ Q, int F,
-                                                            float *__restrict__ tilemax, int num_tiles) {
+__global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restrict__ G, int N, const half_t *__restrict__ Q, int F,
+                                                           float *__restrict__ tilemax, int num_tiles) {
     constexpr int KS = D / 16;   // k-steps
     constexpr int QP = D + 8;    // halves per query row in LDS
     extern __shared__ __attribute__((aligned(16))) char smem2[];
@@ -378,22 +323,18 @@ __global__ __launch_bounds__(256) void match_coarse2_kernel(const half_t *__rest
     }
     int tile = blockIdx.x;
     if (tile >= num_tiles) return;  // (uniform per workgroup; no barrier has been executed yet)
-    auto row_ptr = [&](int t) {
-        long g = (long)t * 128 + wave * 32 + r;
-        if (g >= N) g = N - 1;  // clamped: excluded from the maximum below
-        return G + g * D + 8 * hi;
-    };
+    auto frag_ptr = [&](int t) { return G + (((long)t * 4 + wave) * KS) * 512 + lane * 8; };  // + ks * 512 halfs (1 KB) per k-step
     half8 areg[KS];
     {
-        const half_t *gp = row_ptr(tile);
+        const half_t *gp = frag_ptr(tile);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) areg[ks] = *reinterpret_cast<const half8 *>(gp + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) areg[ks] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(gp + ks * 512));
     }
     __syncthreads();
     const half_t *qb = Qs + r * QP + 8 * hi;
     for (; tile < num_tiles; tile += gridDim.x) {
         const int next = tile + gridDim.x;
-        const half_t *gn = row_ptr(next < num_tiles ? next : tile);
+        const half_t *gn = frag_ptr(next < num_tiles ? next : tile);
         floatx16 acc[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n)
@@ -410,11 +351,10 @@ __global__ __launch_bounds__(256) void match_coarse2_kernel(const half_t *__rest
             }
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[ks], bq[ks & 1][n], acc[n], 0, 0, 0);
-            areg[ks] = *reinterpret_cast<const half8 *>(gn + ks * 16);  // refill with the next tile's fragment
+            // refill with the next tile's fragment; streamed once per call: non-temporal, so that the 1 GB scan does not push the
+            // recogniser's working set out of L2 / MALL
+            areg[ks] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(gn + ks * 512));
         }
-        // per-query maximum over this wave's 32 gallery rows (rows beyond N are excluded).  Written per WAVE (4 entries per
-        // tile): no cross-wave reduction, hence no barrier in the loop - a barrier per tile stalls the load stream (loads are
-        // only issued from MFMA steps) and cost ~20 % of the bandwidth.
         __builtin_amdgcn_sched_barrier(0);
         const int gbase = tile * 128 + wave * 32;
 #pragma unroll
@@ -423,7 +363,7 @@ __global__ __launch_bounds__(256) void match_coarse2_kernel(const half_t *__rest
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int g = gbase + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (g < N) m = fmaxf(m, acc[n][e]);
+                if (g < N) m = fmaxf(m, acc[n][e]);  // (pad rows of the last tile are excluded)
             }
             m = fmaxf(m, __shfl_xor(m, 32));
             const int q = q0 + n * 32 + r;
@@ -437,7 +377,7 @@ __global__ __launch_bounds__(256) void match_coarse2_kernel(const half_t *__rest
 __global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ tilemax, int num_tiles, int sub, const float *__restrict__ Q,
                                                            int D, float gmax_norm, int *__restrict__ tile_flags, int *__restrict__ tile_list,
                                                            int *__restrict__ count) {
-    // `sub` coarse entries per 128-row tile (1: match_coarse_kernel, 4: match_coarse2_kernel writes one per wave)
+    // `sub` coarse entries per 128-row tile (match_coarse_kernel writes one per wave: 4)
     __shared__ float sm[8];
     const int q = blockIdx.x, tid = threadIdx.x;
     const int n_ent = num_tiles * sub;
@@ -524,10 +464,22 @@ void launch_match_full(const float *gallery, int N, int D, const float *queries,
 }
 
 // ---------------------------------------------------------------- screened top-1 (host side)
+bool match_screen_supported(int D) { return D == 64 || D == 128 || D == 256 || D == 512; }  // coarse kernel instantiations (queries must fit LDS)
+
+size_t gallery16_elems(int N, int D) { return (size_t)((N + 127) / 128) * 128 * D; }  // whole 128-row tiles
+
+// fp32 rows [n_rows][D] whose first row is global row row0 (a multiple of 128) -> their place in the fragment-ordered fp16 gallery
+void launch_rows_to_half(const float *in, long row0, long n_rows, int D, half_t *g16, hipStream_t s) {
+    if (n_rows <= 0) return;
+    const long tiles = (n_rows + 127) / 128;
+    const long pieces = tiles * 4 * (D / 16) * 64;
+    hipLaunchKernelGGL(gallery_to_half_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, in, row0, n_rows, D, g16);
+}
+
 void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int *max_norm2_bits, hipStream_t s) {
     (void)hipMemsetAsync(max_norm2_bits, 0, sizeof(int), s);
-    const long n8 = (long)N * D / 8;
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, gallery, g16, n8, (int *)nullptr, 0L);
+    (void)hipMemsetAsync(g16, 0, gallery16_elems(N, D) * sizeof(half_t), s);  // (pad rows of the last tile stay zero)
+    launch_rows_to_half(gallery, 0, N, D, g16, s);
     hipLaunchKernelGGL(row_norm_max_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, gallery, N, D, max_norm2_bits);
 }
 
@@ -536,9 +488,15 @@ void launch_gallery_norm16(const half_t *g16, int N, int D, int *max_norm2_bits,
     (void)hipMemsetAsync(max_norm2_bits, 0, sizeof(int), s);
     hipLaunchKernelGGL(row_norm_max_kernel<half_t>, dim3((N + 3) / 4), dim3(256), 0, s, g16, N, D, max_norm2_bits);
 }
-// fp32 rows (device) -> fp16 rows; n8 = elements / 8
-void launch_rows_to_half(const float *in, half_t *out, long n8, hipStream_t s) {
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, in, out, n8, (int *)nullptr, 0L);
+
+template <int D>
+static void launch_coarse_t(const half_t *g16, int N, const half_t *q16, int F, float *tilemax, int tiles, hipStream_t s) {
+    const size_t lds = (size_t)128 * (D + 8) * sizeof(half_t);
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 g(tiles < 256 ? tiles : 256, (F + 127) / 128);
+    hipLaunchKernelGGL((match_coarse_kernel<D>), g, dim3(256), lds, s, g16, N, q16, F, tilemax, tiles);
 }
 
 void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
@@ -549,30 +507,13 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
     const long nzero = (long)tiles + 1;  // tile flags + the candidate count behind them (ScreenScratch: count == tile_flags + tiles)
     const long n_thr = q8 > nzero ? q8 : nzero;
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, queries, w.q16, q8, w.tile_flags, nzero);
-    const size_t lds = (size_t)4 * 128 * CBK * sizeof(half_t) + 4 * 128 * sizeof(float);
-    static bool attr_done[FRT_MAX_DEVICES] = {};
-    if (frt_first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    switch (D) {
+        case 64: launch_coarse_t<64>(g16, N, w.q16, F, w.tilemax, tiles, s); break;
+        case 128: launch_coarse_t<128>(g16, N, w.q16, F, w.tilemax, tiles, s); break;
+        case 256: launch_coarse_t<256>(g16, N, w.q16, F, w.tilemax, tiles, s); break;
+        default: launch_coarse_t<512>(g16, N, w.q16, F, w.tilemax, tiles, s); break;  // match_screen_supported() gates the callers
     }
-    // Both coarse kernels stream the 1 GB fp16 shadow at 4.0 TB/s (251 vs 258 us at N = 1M, F = 128; the HBM pipe is the limit:
-    // 128 KB per CU in flight for ~8 us).  v1 stays the default, v2 (FRT_MATCH_COARSE_V2=1) is the simpler memory path.
-    static const bool coarse_v2 = getenv("FRT_MATCH_COARSE_V2") != nullptr;
-    int coarse_sub = 1;
-    if (D == 512 && coarse_v2) {
-        coarse_sub = 4;
-        const size_t lds2 = (size_t)128 * (512 + 8) * sizeof(half_t);
-        static bool attr2_done[FRT_MAX_DEVICES] = {};
-        if (frt_first_use_on_device(attr2_done)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        }
-        dim3 g2(tiles < 256 ? tiles : 256, (F + 127) / 128);
-        hipLaunchKernelGGL((match_coarse2_kernel<512>), g2, dim3(256), lds2, s, g16, N, w.q16, F, w.tilemax, tiles);
-    } else {
-        dim3 cgrid(tiles < 1024 ? tiles : 1024, (F + 127) / 128);
-        hipLaunchKernelGGL(match_coarse_kernel, cgrid, dim3(256), lds, s, g16, N, D, w.q16, F, w.tilemax, tiles);
-    }
-    hipLaunchKernelGGL(match_select_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles, coarse_sub, queries, D, gmax_norm, w.tile_flags, w.tile_list,
-                       w.count);
+    hipLaunchKernelGGL(match_select_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles, 4, queries, D, gmax_norm, w.tile_flags, w.tile_list, w.count);
     // exact re-rank over the listed tiles (count lives on the device); the partial scratch is [partial_blocks][F]
     // 32 queries per workgroup (grid.y = query blocks): the list is short (a few hundred tiles), so the pass is bound by the
     // time ONE workgroup needs for a tile - 1024 fp32 MFMAs per wave with 128 queries (27 us), 256 with 32 (7 us).  Same

@@ -129,34 +129,24 @@ def test_sharded_gallery_merge_equals_single_gallery(frt, synth, N):
         m.close()
 
 
-def test_coarse_kernel_v2_selects_the_same_answers():
-    """The opt-in register-streaming coarse kernel (FRT_MATCH_COARSE_V2=1, read once per process -> subprocess) must leave the
-    screened top-1 bit-identical to the exact scan as well."""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys
-import numpy as np
-sys.path.insert(0, os.getcwd())
-import __graft_entry__ as entry
-frt = entry.load_pkg()
-N = 50000 + 13
-g = frt.synth.make_gallery(N)
-g[45000] = g[77]
-q = np.concatenate([frt.synth.make_queries(g, [77, 45000, 12, 49999], noise=0.0),
-                    np.random.default_rng(3).standard_normal((60, 512)).astype(np.float32)])
-m = frt.MatMul(0)
-m.init(g)
-i, s = m.top1(q)
-full = m.calculate(q)
-assert np.array_equal(i, full.argmax(1).astype(np.int32)) and np.array_equal(s, full.max(1)), "mismatch"
-assert i[0] == 77 and i[1] == 77
-print("OK")
-'''
-    env = dict(os.environ, FRT_MATCH_COARSE_V2="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+@pytest.mark.parametrize("D", [64, 128, 256, 512])
+def test_screened_top1_at_every_supported_width(frt, D):
+    """The coarse kernel is instantiated for D = 64 / 128 / 256 / 512 (the fp16 shadow gallery is stored in MFMA-fragment order, padded
+    to whole 128-row tiles).  N not a multiple of 128, duplicate rows across tiles, random queries: screened == full matrix, bit for bit."""
+    rng = np.random.default_rng(D)
+    N = 50000 + 13
+    g = rng.standard_normal((N, D)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    g[45000] = g[77]
+    g[N - 1] = g[N - 200]
+    q = np.concatenate([g[[77, 45000, 12, N - 1, N - 200]], rng.standard_normal((60, D)).astype(np.float32)])
+    m = frt.MatMul(0)
+    m.init(g)
+    i, s = m.top1(q)
+    full = m.calculate(q)
+    assert np.array_equal(i, full.argmax(1).astype(np.int32)) and np.array_equal(s, full.max(1))
+    assert i[0] == 77 and i[1] == 77 and i[3] == N - 200 and i[4] == N - 200
+    m.close()
 
 
 def test_dim_not_multiple_of_64_stays_on_the_exact_scan(frt, synth):
