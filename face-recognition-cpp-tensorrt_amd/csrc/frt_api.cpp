@@ -506,6 +506,7 @@ struct ArcUnit {
     int cin, depth, stride, h_in;  // input spatial size (square)
     half_t *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;
     half_t *w1f = nullptr, *w2f = nullptr;  // fragment-ordered copies for the strip kernel (stride-1 3x3 convs)
+    half_t *w2f2 = nullptr;                 // ... for the stride-2 strip kernel (conv2 of the first unit of a stage)
     float *prelu = nullptr, *s2 = nullptr, *b2 = nullptr, *ssc = nullptr, *bsc = nullptr;
     float *sn = nullptr, *bn = nullptr;  // BatchNorm that consumes this unit's output (next unit's leading BN / output_layer.0)
     float *se_w1 = nullptr, *se_w2 = nullptr;
@@ -584,8 +585,10 @@ std::vector<uint16_t> conv_w_f16(const frt::Blob &b, const std::string &name, in
 }
 // 3x3 weights in the order the strip kernel's MFMA A fragments consume them: [Cout/32][Cin/64][tap][kk][lane = (k half, cout row)][8]
 // (kernels_arc.hip: conv_patch_kernel); a wave's load of one fragment is then one contiguous kilobyte.  Empty unless Cin % 64 == 0.
-std::vector<uint16_t> conv_w_f16_frag(const frt::Blob &b, const std::string &name, int cout, int cin) {
+// stride2: taps in the step order of the stride-2 strip kernel (kernels_arc_s2.hip: phase planes (odd,odd) (even,even) (odd,even) (even,odd)).
+std::vector<uint16_t> conv_w_f16_frag(const frt::Blob &b, const std::string &name, int cout, int cin, bool stride2 = false) {
     if (cin % 64 || cout % 32) return {};
+    static const int s2_step_of_tap[9] = {0, 5, 1, 7, 4, 8, 2, 6, 3};  // inverse of the step -> tap table 0,2,6,8,4,1,7,3,5
     const float *src = b.get(name, (size_t)cout * cin * 9).data;
     std::vector<uint16_t> w((size_t)cout * cin * 9);
     const int nch = cin / 64;
@@ -593,7 +596,8 @@ std::vector<uint16_t> conv_w_f16_frag(const frt::Blob &b, const std::string &nam
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < 9; ++t) {
                 const int blk = co >> 5, r = co & 31, ch = ci >> 6, kk = (ci & 63) >> 4, hi = (ci & 15) >> 3, e = ci & 7;
-                const size_t off = (((((size_t)blk * nch + ch) * 9 + t) * 4 + kk) * 64 + hi * 32 + r) * 8 + e;
+                const int st = stride2 ? s2_step_of_tap[t] : t;
+                const size_t off = (((((size_t)blk * nch + ch) * 9 + st) * 4 + kk) * 64 + hi * 32 + r) * 8 + e;
                 w[off] = frt::f32_to_f16(src[((size_t)co * cin + ci) * 9 + t]);
             }
     return w;
@@ -644,10 +648,8 @@ void frt_embedder::build(const frt::Blob &b) {
             {  // conv1 is always stride 1; conv2 only in the units that keep the resolution
                 const std::vector<uint16_t> f1 = conv_w_f16_frag(b, p + ".res_layer.1.weight", a.depth, a.cin);
                 if (!f1.empty()) a.w1f = reinterpret_cast<half_t *>(arena.upload(f1));
-                if (a.stride == 1) {
-                    const std::vector<uint16_t> f2 = conv_w_f16_frag(b, p + ".res_layer.3.weight", a.depth, a.depth);
-                    if (!f2.empty()) a.w2f = reinterpret_cast<half_t *>(arena.upload(f2));
-                }
+                const std::vector<uint16_t> f2 = conv_w_f16_frag(b, p + ".res_layer.3.weight", a.depth, a.depth, a.stride == 2);
+                if (!f2.empty()) (a.stride == 1 ? a.w2f : a.w2f2) = reinterpret_cast<half_t *>(arena.upload(f2));
             }
             a.prelu = arena.upload(vec_of(b, p + ".res_layer.2.weight", a.depth));
             a.w2 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".res_layer.3.weight", a.depth, a.depth, 3)));
@@ -782,6 +784,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             a.x = T;
             a.w = u.w2;
             a.wf = u.w2f;
+            a.wf2 = u.w2f2;
             a.B = F; a.H = h; a.W = h; a.Cin = u.depth; a.Ho = ho; a.Wo = ho; a.Cout = u.depth; a.ks = 3; a.stride = u.stride; a.pad = 1;
             a.p0 = u.s2;
             a.p1 = u.b2;
@@ -854,7 +857,7 @@ struct frt_matcher {
     bool screen = false;
     ScreenScratch scr{};
     void free_screen_scratch() {
-        for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list})  // scr.count lives behind tile_flags
+        for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list, (void *)scr.segmax})  // scr.count lives behind tile_flags
             if (p) (void)hipFree(p);
         scr = ScreenScratch{};
     }
@@ -1036,6 +1039,7 @@ struct frt_matcher {
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_flags), (tiles + 1) * sizeof(int)));  // [tiles] flags + the candidate count:
             scr.count = scr.tile_flags + tiles;                                                           // one contiguous range to clear per call
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_list), tiles * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.segmax), (size_t)cap * 16 * sizeof(float)));
         }
         q_cap = cap;
     }

@@ -48,6 +48,7 @@ struct ScreenScratch {
     int *tile_flags;   // [tiles]
     int *tile_list;    // [tiles]
     int *count;        // [1], == tile_flags + tiles (cleared together)
+    float *segmax;     // [F][16] per-segment maxima of tilemax (selection step 1)
 };
 void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int *max_norm2_bits, hipStream_t s);
 void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
@@ -158,6 +159,7 @@ struct ConvMfmaArgs {
     const half_t *x;   // [B][H][W][Cin]
     const half_t *w;   // [Cout][ks*ks*Cin]
     const half_t *wf;  // optional fragment-ordered copy for the strip kernel: [Cout/32][Cin/64][9][4][64 lanes][8] (3x3, Cin % 64 == 0); null: none
+    const half_t *wf2; // same for the stride-2 strip kernel (kernels_arc_s2.hip): taps in ITS step order 0,2,6,8,4,1,7,3,5; null: none
     int B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad;
     int mode;
     const float *p0, *p1, *p2, *p3;
@@ -169,6 +171,9 @@ struct ConvMfmaArgs {
     const half_t *zeros;  // >= 16 bytes of zeros (source of padded taps for the LDS-DMA path)
 };
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
+bool conv_s2_applies(const ConvMfmaArgs &a);                // kernels_arc_s2.hip: 3x3 stride 2, Cout % 128 == 0
+bool launch_conv_s2(const ConvMfmaArgs &a, hipStream_t s);
+const char *conv_s2_label(const ConvMfmaArgs &a);
 bool conv64_applies(const ConvMfmaArgs &a);                 // kernels_arc_c64.hip: Cin = Cout = 64, 3x3, stride 1
 bool launch_conv64(const ConvMfmaArgs &a, hipStream_t s);
 const char *conv_kernel_label(const ConvMfmaArgs &a);  // kernel symbol (as rocprofv3 prints it) a launch resolves to

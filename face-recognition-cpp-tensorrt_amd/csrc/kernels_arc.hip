@@ -1041,6 +1041,7 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
                                   "conv_patch_kernel<3, 5, 5, true, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 7, 1, 3>",
                                   "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3>",
                                   "conv_patch_kernel<5, 1, 5, false, 0, false, 2, 1, 3>", "conv_patch_kernel<5, 1, 5, false, 0, false, 1, 1, 3>"};
+    if (const char *l2 = conv_s2_label(a)) return l2;
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
@@ -1049,6 +1050,7 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
 
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
     if (launch_conv64(a, s)) return;  // dedicated 64 -> 64 stride-1 kernel (kernels_arc_c64.hip)
+    if (launch_conv_s2(a, s)) return;  // stride-2 strip kernel on de-interleaved phase planes (kernels_arc_s2.hip)
     int R = 0, n_img = 0;
     const int v = conv_variant(a, R, n_img);
 #ifdef FRT_ABLATE

@@ -1,0 +1,330 @@
+// ArcFace IR-50: the stride-2 3x3 convolutions (second conv of the first unit of every stage, model_irse.py:48-65 with stride 2:
+// 128 -> 128 at 56 -> 28, 256 -> 256 at 28 -> 14, 512 -> 512 at 14 -> 7), fp16 NHWC, fp32 accumulation on v_mfma_f32_32x32x16_f16.
+//
+// They ran on the im2col LDS-DMA kernel (kernels_arc.hip: conv_glds_kernel), which moves every input pixel L2 -> LDS once per tap that
+// touches it and measured 58 - 83 us per layer against 37 - 42 us for the LDS-resident strip kernel on stride-1 layers with the same
+// 29.6 GFLOP.  This is the strip kernel's idea carried over to stride 2.
+//
+// A strip kernel keeps the strip's input patch resident in LDS and makes a tap a constant address offset: slot s -> patch row s + off.
+// With stride 2 consecutive output pixels are TWO input pixels apart (and LDS rows 2 * 144 B apart collide pairwise in the 64 banks),
+// and the patch of R output rows is 4x larger than at stride 1.  Both problems go away when the patch is staged de-interleaved by the
+// parity of the input row and column - four PHASE PLANES, each on the OUTPUT grid ((R+1) x (Wo+1) pixels, pixel pitch 144 B):
+//     input row 2*oy + kh - 1:   kh = 0 -> odd rows,  plane row oy        kh = 1 -> even rows, plane row oy      kh = 2 -> odd rows, plane row oy + 1
+// (same for columns), so inside a plane a tap is again "slot + constant" and consecutive slots are consecutive 144-byte rows
+// (conflict-free ds_read_b128).  The nine taps split over the planes as 4 (odd, odd) + 1 (even, even) + 2 (odd, even) + 2 (even, odd);
+// the K loop walks, per 64-channel chunk, plane by plane in that order.  Each plane has its own LDS buffer (4 x <= 36 KB): the moment
+// every wave has finished a plane (one workgroup barrier per plane), the SAME plane of the next channel chunk is fetched into it by
+// LDS-DMA - five or more (chunk, tap) steps before it is needed.  VMEM operations retire in order, so the wait in front of a plane is
+// an exact compile-time count: two younger plane fetches plus four weight-fragment loads per step issued since.
+// Weights: fragment-ordered copy in THIS kernel's step order (host-packed, [32-cout block][chunk][step][kk][lane][8 halfs]); each
+// wave streams its 32 couts' fragments straight into registers, two steps ahead, one contiguous kilobyte per load.
+// One workgroup (4 waves x 32 couts, NT pixel tiles each) per CU: the four plane buffers take up to 144 KB of the 160 KB LDS.
+#include "frt_kernels.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int PROW = 144;  // bytes per plane pixel (128 data + 16 pad)
+
+// step -> (plane, row offset, column offset); plane order (odd,odd), (even,even), (odd,even), (even,odd)
+__device__ constexpr int kSub[9] = {0, 0, 0, 0, 1, 2, 2, 3, 3};
+__device__ constexpr int kDr[9] = {0, 0, 1, 1, 0, 0, 1, 0, 0};
+__device__ constexpr int kDc[9] = {0, 1, 0, 1, 0, 0, 0, 0, 1};
+__device__ constexpr int kLen[4] = {4, 1, 2, 2};   // steps per plane
+__device__ constexpr int kRowPar[4] = {1, 0, 1, 0};  // plane -> input row parity (1: odd rows 2*i - 1, 0: even rows 2*i)
+__device__ constexpr int kColPar[4] = {1, 0, 0, 1};
+
+template <int NT, int PP>  // NT pixel tiles per strip; PP = LDS-DMA pieces (1 KB per wave) per thread per plane
+__global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
+    constexpr int PLANE_B = PP * 4096;
+    constexpr int LA = 2, WR = 3, BFD = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo, Wq = Wo + 1;
+    const int NPp = n_img * (R + 1) * Wq;  // pixels of one plane
+    const int strips_per_img = Ho / R;
+    const int n_valid = n_img * R * Wo;
+
+    const int n_co_tiles = p.Cout >> 7;
+    const int nblk = gridDim.x, bq = nblk >> 3, brem = nblk & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int lid = (xcd < brem ? xcd * (bq + 1) : brem * (bq + 1) + (xcd - brem) * bq) + slot;
+    const int co_tile = lid % n_co_tiles, strip = lid / n_co_tiles;
+    const int co_base = co_tile * 128, cow = wave * 32;
+    const int img0 = (strip / strips_per_img) * n_img;
+    const int oy0 = (strip % strips_per_img) * R;
+    const int n_chunks = p.Cin >> 6;
+
+    // ---- plane DMA descriptors: piece q of plane s covers 16-byte chunk g = (q*4 + wave)*64 + lane of the plane image
+    int poff[4][PP];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int q = 0; q < PP; ++q) {
+            const int g = (q * 4 + wave) * 64 + lane;
+            const int px = g / 9, pos = g - px * 9;
+            poff[s][q] = -1;
+            if (pos < 8 && px < NPp) {
+                const int il = px / ((R + 1) * Wq);
+                const int rem = px - il * ((R + 1) * Wq);
+                const int i = rem / Wq, j = rem - i * Wq;
+                const int y = 2 * (oy0 + i) - kRowPar[s], x = 2 * j - kColPar[s], b = img0 + il;
+                if (b < p.B && y >= 0 && y < H && x >= 0 && x < W) poff[s][q] = ((b * H + y) * W + x) * p.Cin + pos * 8;
+            }
+        }
+    const half_t *wfrag = p.wf + ((long)((co_base + cow) >> 5) * n_chunks) * (9 * 4 * 512) + lane * 8;
+    int pbase[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int sl = j * 32 + r;
+        int pidx = 0;
+        if (linear) {
+            pidx = sl < R * Wq ? sl : 0;
+        } else if (sl < n_valid) {
+            const int il = sl / (R * Wo);
+            const int rem = sl - il * (R * Wo);
+            const int rr = rem / Wo, cc = rem - rr * Wo;
+            pidx = (il * (R + 1) + rr) * Wq + cc;
+        }
+        pbase[j] = pidx * PROW + hi * 16;
+    }
+
+    half8 areg[WR][4];
+    auto load_w = [&](int c, int step, auto slot_c) {  // wave-uniform c, step; clamped at the tail (values unused there)
+        constexpr int S = decltype(slot_c)::value;
+        const int woff = c < n_chunks ? (c * 9 + step) * (4 * 512) : 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) areg[S][kk] = *reinterpret_cast<const half8 *>(wfrag + woff + kk * 512);
+    };
+    auto issue_plane = [&](int c, auto sub_c) {
+        constexpr int S = decltype(sub_c)::value;
+        const bool real = c < n_chunks;
+        char *pl = smem + S * PLANE_B + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < PP; ++q) {
+            const half_t *src = (real && poff[S][q] >= 0) ? p.x + (unsigned)(poff[S][q] + (c << 6)) : p.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(pl + q * 4096), 16, 0, 0);
+        }
+    };
+
+    floatx16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // prologue: all four planes of chunk 0, then the weight fragments of steps 0 and 1
+    issue_plane(0, std::integral_constant<int, 0>{});
+    issue_plane(0, std::integral_constant<int, 1>{});
+    issue_plane(0, std::integral_constant<int, 2>{});
+    issue_plane(0, std::integral_constant<int, 3>{});
+    load_w(0, 0, std::integral_constant<int, 0>{});
+    load_w(0, 1, std::integral_constant<int, 1>{});
+    half8 bf[BFD][NT];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LA) : "memory");  // this wave's plane pieces have landed (younger: the fragment loads)
+    __builtin_amdgcn_s_barrier();                                    // ... and everybody else's
+#pragma unroll
+    for (int k2 = 0; k2 < BFD; ++k2)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[k2][j] = *reinterpret_cast<const half8 *>(smem + pbase[j] + k2 * 32);  // step 0: plane 0, offsets (0, 0)
+
+    auto step = [&](int c, auto step_c) {
+        constexpr int ST = decltype(step_c)::value;
+        constexpr int NS = (ST + 1) % 9;
+        constexpr int AS = ST % WR;
+        constexpr bool LAST_OF_PLANE = kSub[NS] != kSub[ST];
+        const int dp = kSub[ST] * PLANE_B + (kDr[ST] * Wq + kDc[ST]) * PROW;
+        const int dpn = kSub[NS] * PLANE_B + (kDr[NS] * Wq + kDc[NS]) * PROW;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = kk & 1;
+            if (kk == 4 - BFD && LAST_OF_PLANE) {
+                // plane hand-over: every read of this plane's buffer has been issued (the refills from here on read the NEXT plane);
+                // wait for them, for this wave's pieces of the next plane (issued one chunk ago: since then two younger plane fetches
+                // and four fragment loads per step), meet, then refill THIS plane's buffer with the next chunk's data.
+                constexpr int NEXT = kSub[NS];
+                constexpr int YOUNGER = 4 * (9 - kLen[NEXT]) + 2 * PP;
+                static_assert(YOUNGER <= 63, "vmcnt field");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                issue_plane(c + 1, std::integral_constant<int, kSub[ST]>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[AS][kk], bf[cur][j], acc[j], 0, 0, 0);
+                if (kk + BFD < 4) bf[cur][j] = *reinterpret_cast<const half8 *>(smem + pbase[j] + dp + (kk + BFD) * 32);
+                else bf[cur][j] = *reinterpret_cast<const half8 *>(smem + pbase[j] + dpn + (kk + BFD - 4) * 32);
+                if (kk == 0 && j == (NT > 1 ? 1 : 0)) {  // weight fragments of step t+2 into the ring slot step t-1 used
+                    constexpr int T2 = ST + LA;
+                    load_w(T2 < 9 ? c : c + 1, T2 % 9, std::integral_constant<int, (T2 % 9) % WR>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int c = 0; c < n_chunks; ++c) {
+        step(c, std::integral_constant<int, 0>{});
+        step(c, std::integral_constant<int, 1>{});
+        step(c, std::integral_constant<int, 2>{});
+        step(c, std::integral_constant<int, 3>{});
+        step(c, std::integral_constant<int, 4>{});
+        step(c, std::integral_constant<int, 5>{});
+        step(c, std::integral_constant<int, 6>{});
+        step(c, std::integral_constant<int, 7>{});
+        step(c, std::integral_constant<int, 8>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's dummy DMAs still target LDS
+    __syncthreads();
+
+    // ------------------------------------------------------------------ epilogue (per wave: 32 couts x NT pixel tiles) through LDS
+    constexpr int EROW = 36;  // floats per pixel row (32 + 4 pad)
+    float *ep = reinterpret_cast<float *>(smem) + wave * (32 * EROW);
+    const int chunk = lane & 3;
+    const int cch = co_base + cow + chunk * 8;
+    floatx4 q0[2], q1[2], q2[2], q3[2];
+    q0[0] = *reinterpret_cast<const floatx4 *>(p.p0 + cch);
+    q0[1] = *reinterpret_cast<const floatx4 *>(p.p0 + cch + 4);
+    q1[0] = *reinterpret_cast<const floatx4 *>(p.p1 + cch);
+    q1[1] = *reinterpret_cast<const floatx4 *>(p.p1 + cch + 4);
+    const bool two = p.mode == EPI_BN_ADD_BN && p.out1;
+    if (two) {
+        q2[0] = *reinterpret_cast<const floatx4 *>(p.p2 + cch);
+        q2[1] = *reinterpret_cast<const floatx4 *>(p.p2 + cch + 4);
+        q3[0] = *reinterpret_cast<const floatx4 *>(p.p3 + cch);
+        q3[1] = *reinterpret_cast<const floatx4 *>(p.p3 + cch + 4);
+    }
+    const long Mtot = (long)p.B * Ho * Wo;
+    const float inv_wq = 1.0f / (float)Wq;
+    auto slot_pixel = [&](int sl, long &m) -> bool {  // pixel slot -> flattened output pixel index; false for dead slots
+        if (linear) {
+            const int rr = (int)(((float)sl + 0.5f) * inv_wq);  // exact for sl < 2^20
+            const int cc = sl - rr * Wq;
+            m = ((long)img0 * Ho + oy0 + rr) * Wo + cc;
+            return rr < R && cc < Wo && m < Mtot;
+        }
+        // compact enumeration: strips of whole images (R == Ho), contiguous in the flattened (image, row, column) index
+        m = ((long)img0 * Ho + oy0) * Wo + sl;
+        return sl < n_valid && m < Mtot;
+    };
+    half8 sc8[NT][2];
+    if (p.mode == EPI_BN_ADD_BN) {  // the shortcut has the output's geometry; all loads in flight before the transposes
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int sl = j * 32 + (lane >> 2) + 16 * it;
+                long m;
+                const bool ok = slot_pixel(sl, m);
+                sc8[j][it] = *reinterpret_cast<const half8 *>(p.sc + (ok ? m : 0) * p.Cout + cch);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+            *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int px = (lane >> 2) + 16 * it;
+            const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
+            const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
+            const int sl = j * 32 + px;
+            long m;
+            if (!slot_pixel(sl, m)) continue;
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3];
+            if (p.mode == EPI_BN_ADD_BN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)sc8[j][it][e];
+            }
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+            *reinterpret_cast<half8 *>(p.out0 + m * p.Cout + cch) = o;
+            if (two) {
+                half8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (half_t)(v[e] * q2[e >> 2][e & 3] + q3[e >> 2][e & 3]);
+                *reinterpret_cast<half8 *>(p.out1 + m * p.Cout + cch) = z;
+            }
+        }
+    }
+}
+
+template <int NT, int PP>
+void launch_s2_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
+    constexpr size_t lds = (size_t)4 * PP * 4096;
+    static_assert(lds <= 160 * 1024 && lds >= 4 * 32 * 36 * 4, "LDS budget / epilogue scratch");
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s2_kernel<NT, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int strips = ((a.B + n_img - 1) / n_img) * (a.Ho / R);
+    const int linear = (n_img == 1 && R * (a.Wo + 1) <= NT * 32) ? 1 : 0;
+    hipLaunchKernelGGL((conv_s2_kernel<NT, PP>), dim3(strips * (a.Cout / 128)), dim3(256), lds, s, a, R, n_img, linear);
+}
+
+// strip geometry; false: not eligible (the im2col kernel takes the layer)
+bool s2_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &nt, int &pp) {
+    if (!a.wf2 || a.ks != 3 || a.stride != 2 || a.pad != 1 || a.Cout % 128 || a.Cin % 64 || a.splits != 1 || a.H != a.W || (a.H & 1)) return false;
+    if (a.Ho * 2 != a.H || a.Wo * 2 != a.W) return false;
+    if (a.mode != EPI_BN && a.mode != EPI_BN_ADD_BN) return false;
+    if (a.mode == EPI_BN_ADD_BN && !(a.sc && a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
+    static const bool off = frt_tuning_env("FRT_CONV_S2") && frt_tuning_env("FRT_CONV_S2")[0] == '0';
+    if (off) return false;
+    const int Wq = a.Wo + 1;
+    if (a.Ho * a.Wo <= 64) {  // 14 -> 7: whole images per strip, compact slots; two images (98 pixels, 4 tiles) for full batches
+        R = a.Ho;
+        n_img = (a.B >= 96 && 2 * a.Ho * a.Wo <= 128) ? 2 : 1;
+        nt = n_img * a.Ho * a.Wo <= 64 ? 2 : 4;
+    } else {
+        n_img = 1;
+        R = 0;
+        for (int d = a.Ho; d >= 1; --d) {
+            if (a.Ho % d || d * Wq > 224) continue;
+            R = d;
+            break;
+        }
+        if (!R) return false;
+        nt = R * Wq <= 128 ? 4 : 7;
+        if (R * a.Wo * 10 < nt * 32 * 7) return false;  // more than 30 % dead pixel slots
+    }
+    pp = (n_img * (R + 1) * Wq * 9 + 255) / 256;
+    return pp <= 9;
+}
+
+}  // namespace
+
+bool conv_s2_applies(const ConvMfmaArgs &a) {
+    int R, n_img, nt, pp;
+    return s2_geometry(a, R, n_img, nt, pp);
+}
+
+const char *conv_s2_label(const ConvMfmaArgs &a) {
+    int R, n_img, nt, pp;
+    if (!s2_geometry(a, R, n_img, nt, pp)) return nullptr;
+    if (nt == 7) return "conv_s2_kernel<7, 9>";
+    if (nt == 4) return pp <= 5 ? "conv_s2_kernel<4, 5>" : "conv_s2_kernel<4, 9>";
+    return "conv_s2_kernel<2, 5>";
+}
+
+bool launch_conv_s2(const ConvMfmaArgs &a0, hipStream_t s) {
+    int R, n_img, nt, pp;
+    if (!s2_geometry(a0, R, n_img, nt, pp)) return false;
+    ConvMfmaArgs a = a0;
+    a.wf = a0.wf2;  // the kernel streams the stride-2 step order
+    if (nt == 7) launch_s2_t<7, 9>(a, R, n_img, s);
+    else if (nt == 4 && pp <= 5) launch_s2_t<4, 5>(a, R, n_img, s);
+    else if (nt == 4) launch_s2_t<4, 9>(a, R, n_img, s);
+    else if (pp <= 5) launch_s2_t<2, 5>(a, R, n_img, s);
+    else return false;
+    return true;
+}

@@ -151,7 +151,10 @@ __global__ __launch_bounds__(256) void dwpw_kernel(DwPwArgs a) {
 // clamped addresses (zeroing deferred to a select), the next channel's nine loads are in flight while the current one is
 // consumed, and the outputs leave as float4 stores.  Same arithmetic and summation order as dwpw_kernel (bit-identical results).
 // Needs W % 4 == 0 (the 320x320 and 160x160 blocks of the 640x640 network).
-template <int CT>
+// NS = slots of the input prefetch ring (NS - 1 channels in flight ahead of the one being consumed): at 176-240 registers only two
+// waves fit a SIMD, so the bytes in flight per CU come from the ring depth (one channel ahead = 37 KB per CU: 2.3 TB/s on the 8 -> 16
+// block at 320x320).
+template <int CT, int NS = 2>
 __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
     constexpr int REC = 12 + CT;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[q][c] = 0.f;
 
-    floatx4 mid[2][3];
-    float lft[2][3], rgt[2][3];
+    floatx4 mid[NS][3];
+    float lft[NS][3], rgt[NS][3];
     auto fetch = [&](int ci, int slot) {
         const float *x = inb + (long)ci * HW;
 #pragma unroll
@@ -200,13 +203,15 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
             rgt[slot][kh] = x[roff[kh] + roff_r];
         }
     };
-    fetch(0, 0);
-    for (int ci = 0; ci < a.Cin; ci += 2) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+    for (int sl = 0; sl < NS - 1; ++sl)
+        if (sl < a.Cin) fetch(sl, sl);
+    for (int ci = 0; ci < a.Cin; ci += NS) {
+#pragma unroll
+        for (int half = 0; half < NS; ++half) {  // (compile-time ring slot)
             const int c_ = ci + half;
             if (c_ >= a.Cin) break;
-            if (c_ + 1 < a.Cin) fetch(c_ + 1, half ^ 1);
+            if (c_ + NS - 1 < a.Cin) fetch(c_ + NS - 1, (half + NS - 1) % NS);
             const float *rec = wsm + c_ * REC;
             const floatx4 w0 = *reinterpret_cast<const floatx4 *>(rec);
             const floatx4 w1 = *reinterpret_cast<const floatx4 *>(rec + 4);
@@ -507,8 +512,13 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
         const long threads = (long)a.B * a.H * (a.W / 4);
         const dim3 grid((unsigned)((threads + 255) / 256));
         const size_t lds = (size_t)a.Cin * (12 + a.Cout) * sizeof(float);
-        if (a.Cout == 16) hipLaunchKernelGGL(dwpw_row4_kernel<16>, grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL(dwpw_row4_kernel<32>, grid, dim3(256), lds, s, a);
+        // (ring depth measured on the 8 -> 16 block: 98 / 97 / 99 us with 1 / 2 / 3 channels in flight - the kernel waits on memory 60 % of
+        //  its wave cycles but not for lack of bytes in flight; default = the shallow ring, 176 registers)
+        static const int ns16 = frt_tuning_env("FRT_ROW4_NS") ? atoi(frt_tuning_env("FRT_ROW4_NS")) : 2;
+        if (a.Cout == 16 && ns16 == 4) hipLaunchKernelGGL((dwpw_row4_kernel<16, 4>), grid, dim3(256), lds, s, a);
+        else if (a.Cout == 16 && ns16 == 3) hipLaunchKernelGGL((dwpw_row4_kernel<16, 3>), grid, dim3(256), lds, s, a);
+        else if (a.Cout == 16) hipLaunchKernelGGL((dwpw_row4_kernel<16, 2>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((dwpw_row4_kernel<32, 2>), grid, dim3(256), lds, s, a);
         return;
     }
     // fused while one channel tile covers every output channel (no depthwise recompute) ...

@@ -373,33 +373,45 @@ __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restr
     }
 }
 
-// one workgroup per query: best coarse tile maximum, ||q||, then every tile within 2*delta of the best goes on the list (once)
-__global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ tilemax, int num_tiles, int sub, const float *__restrict__ Q,
-                                                           int D, float gmax_norm, int *__restrict__ tile_flags, int *__restrict__ tile_list,
-                                                           int *__restrict__ count) {
+// Tile selection in two fully parallel steps (it used to be one workgroup per query walking its 31 252 coarse entries twice: 128
+// workgroups, 80 us).  Step 1: grid (segments, queries) - maximum of a segment of the query's coarse entries.  Step 2: same grid -
+// the query's best coarse maximum from the segment maxima, ||q||, then every tile of the segment within 2*delta of the best goes on the
+// list (once, over all queries).
+constexpr int SEL_SEG = 16;  // segments per query
+
+__global__ __launch_bounds__(256) void match_segmax_kernel(const float *__restrict__ tilemax, int n_ent, float *__restrict__ segmax) {
+    __shared__ float sm[4];
+    const int q = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+    const int e0 = (int)((long)n_ent * seg / SEL_SEG), e1 = (int)((long)n_ent * (seg + 1) / SEL_SEG);
+    const float *row = tilemax + (long)q * n_ent;
+    float m = -INFINITY;
+    for (int t = e0 + tid; t < e1; t += 256) m = fmaxf(m, row[t]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) sm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) segmax[q * SEL_SEG + seg] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+__global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ tilemax, int num_tiles, int sub, const float *__restrict__ segmax,
+                                                           const float *__restrict__ Q, int D, float gmax_norm, int *__restrict__ tile_flags,
+                                                           int *__restrict__ tile_list, int *__restrict__ count) {
     // `sub` coarse entries per 128-row tile (match_coarse_kernel writes one per wave: 4)
-    __shared__ float sm[8];
-    const int q = blockIdx.x, tid = threadIdx.x;
+    __shared__ float sm[4];
+    const int q = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
     const int n_ent = num_tiles * sub;
     const float *row = tilemax + (long)q * n_ent;
     float m = -INFINITY, n2 = 0.f;
-    for (int t = tid; t < n_ent; t += 256) m = fmaxf(m, row[t]);
+    for (int s = 0; s < SEL_SEG; ++s) m = fmaxf(m, segmax[q * SEL_SEG + s]);
     for (int k = tid; k < D; k += 256) n2 += Q[(long)q * D + k] * Q[(long)q * D + k];
-    for (int off = 32; off > 0; off >>= 1) {
-        m = fmaxf(m, __shfl_xor(m, off));
-        n2 += __shfl_xor(n2, off);
-    }
-    if ((tid & 63) == 0) {
-        sm[tid >> 6] = m;
-        sm[4 + (tid >> 6)] = n2;
-    }
+    for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
+    if ((tid & 63) == 0) sm[tid >> 6] = n2;
     __syncthreads();
-    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-    const float qn = sqrtf(sm[4] + sm[5] + sm[6] + sm[7]);
+    const float qn = sqrtf(sm[0] + sm[1] + sm[2] + sm[3]);
     const float delta = 1.2e-3f * qn * gmax_norm;
     // fp16 overflow / non-finite inputs: no valid bound -> take every tile (degenerates to the exact full scan)
     const float thr = (qn < 6.0e4f && gmax_norm < 6.0e4f && m == m && m > -INFINITY && m < INFINITY) ? m - 2.f * delta : -INFINITY;
-    for (int t = tid; t < n_ent; t += 256)
+    const int e0 = (int)((long)n_ent * seg / SEL_SEG), e1 = (int)((long)n_ent * (seg + 1) / SEL_SEG);
+    for (int t = e0 + tid; t < e1; t += 256)
         if (!(row[t] < thr) && atomicExch(&tile_flags[t / sub], 1) == 0) tile_list[atomicAdd(count, 1)] = t / sub;
 }
 
@@ -513,7 +525,9 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
         case 256: launch_coarse_t<256>(g16, N, w.q16, F, w.tilemax, tiles, s); break;
         default: launch_coarse_t<512>(g16, N, w.q16, F, w.tilemax, tiles, s); break;  // match_screen_supported() gates the callers
     }
-    hipLaunchKernelGGL(match_select_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles, 4, queries, D, gmax_norm, w.tile_flags, w.tile_list, w.count);
+    hipLaunchKernelGGL(match_segmax_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles * 4, w.segmax);
+    hipLaunchKernelGGL(match_select_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles, 4, w.segmax, queries, D, gmax_norm, w.tile_flags, w.tile_list,
+                       w.count);
     // exact re-rank over the listed tiles (count lives on the device); the partial scratch is [partial_blocks][F]
     // 32 queries per workgroup (grid.y = query blocks): the list is short (a few hundred tiles), so the pass is bound by the
     // time ONE workgroup needs for a tile - 1024 fp32 MFMAs per wave with 128 queries (27 us), 256 with 32 (7 us).  Same

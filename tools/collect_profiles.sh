@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the per-round measurement artefacts on the GPU box (run via gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01b'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
 # then copy gpurun_out/profiles_<tag>/* into profiles/.  PMC passes run separately from the kernel trace (see the pool rule).
 set -u
 TAG=${1:-rXX}
@@ -9,39 +9,61 @@ OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > "$OUT/${TAG}_pytest_gpu.log"
-python bench.py --no-cpu-baseline --stage-profile "$OUT/${TAG}_stages.json" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
+# 1. kernel trace of the benchmark command itself
 rm -rf /tmp/prof_stats && mkdir -p /tmp/prof_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o st -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv" 2>/dev/null
-for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_pmc_$C && mkdir -p /tmp/prof_pmc_$C
-  rocprofv3 --pmc $C -d /tmp/prof_pmc_$C -o p -- python "$ROOT/tools/prof_embed.py" 128 2 > /dev/null 2>&1
+# 2. counters, one group per pass, over a recogniser-only run: HBM bytes and matrix-pipe busy cycles
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  D=/tmp/prof_pmc_$(echo $C | cut -d' ' -f1)
+  rm -rf $D && mkdir -p $D
+  rocprofv3 --pmc $C -d $D -o p -- python "$ROOT/tools/prof_embed.py" 128 2 > /dev/null 2>&1
 done
-python - "$OUT/${TAG}_pmc_hbm.json" <<'EOF'
+python - "$OUT/${TAG}_pmc_hbm.json" "$OUT/${TAG}_pmc_mfma.json" <<'PYEOF'
 import collections, glob, json, sqlite3, statistics, sys
-def per_kernel(counter):
-    db = glob.glob("/tmp/prof_pmc_%s/**/*.db" % counter, recursive=True)[0]
+def per_kernel(dirname, counters):
+    db = glob.glob("/tmp/prof_pmc_%s/**/*.db" % dirname, recursive=True)[0]
     c = sqlite3.connect(db)
-    d = collections.defaultdict(lambda: collections.defaultdict(float))
+    d = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for disp, name, cn, val in c.execute("select dispatch_id, kernel_name, counter_name, value from counters_collection"):
-        if cn == counter:
-            d[name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]][disp] += val
-    return {k: list(v.values()) for k, v in d.items()}
-f, w = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
+        if cn in counters:
+            d[name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]][cn][disp] += val
+    return d
+f, w = per_kernel("FETCH_SIZE", ["FETCH_SIZE"]), per_kernel("WRITE_SIZE", ["WRITE_SIZE"])
 out = {}
 for k in f:
     if not k.startswith("conv"):
         continue
-    fm, wm = statistics.median(f[k]), statistics.median(w.get(k, [0]))
+    fm = statistics.median(f[k]["FETCH_SIZE"].values())
+    wm = statistics.median(w.get(k, {}).get("WRITE_SIZE", {0: 0}).values())
     # FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read)
-    out[k] = {"launches": len(f[k]), "fetch_size_kb_median": fm, "write_size_kb_median": wm, "hbm_bytes_per_launch": int((2 * fm + wm) * 1024)}
+    out[k] = {"launches": len(f[k]["FETCH_SIZE"]), "fetch_size_kb_median": fm, "write_size_kb_median": wm, "hbm_bytes_per_launch": int((2 * fm + wm) * 1024)}
 json.dump({"per_kernel": out,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no trace domains) over tools/prof_embed.py 128 2; median over "
                    "all launches of a kernel symbol; FETCH_SIZE doubled per MI355X_MICROARCH.md; WRITE_SIZE uncorrected (uncalibrated)"},
           open(sys.argv[1], "w"), indent=1)
-EOF
+names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]
+m = per_kernel("SQ_VALU_MFMA_BUSY_CYCLES", names)
+mo = {}
+for k, v in m.items():
+    if k.startswith("conv"):
+        mo[k] = {cn: statistics.median(v[cn].values()) for cn in names if cn in v}
+        mo[k]["launches"] = len(next(iter(v.values())))
+json.dump({"per_kernel": mo, "note": "rocprofv3 --pmc (one pass) over tools/prof_embed.py 128 2, medians per launch, summed over the chip by rocprofv3; "
+           "SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD with the matrix pipe busy (1024 SIMDs), GRBM_GUI_ACTIVE is per-XCD busy cycles (8 XCDs)"},
+          open(sys.argv[2], "w"), indent=1)
+PYEOF
 cp "$OUT/${TAG}_pmc_hbm.json" "$ROOT/profiles/" 2>/dev/null   # bench.py reads the newest profiles/*_pmc_hbm.json for roofline.traffic
 cd "$ROOT"
-python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.stderr"
+# 3. the benchmark: driver-style line, default line (+ stage breakdown), power/clock trace over a long region
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver.json" 2> "$OUT/${TAG}_bench_driver.stderr"
+python bench.py --stage-profile "$OUT/${TAG}_stages.json" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.stderr"
+python bench.py --steps 4000 --warmup 5 --no-cpu-baseline --no-extras --no-profile --smi-trace "$OUT/${TAG}_power_clock_trace.json" > "$OUT/${TAG}_bench_long.json" 2>/dev/null
+python bench.py --mode ir_se --no-cpu-baseline > "$OUT/${TAG}_bench_ir_se.json" 2>/dev/null
+python bench.py --frame 1920x1080 --no-cpu-baseline > "$OUT/${TAG}_bench_1080p.json" 2>/dev/null
+python bench.py --batch 1 --gallery 10000 --no-cpu-baseline > "$OUT/${TAG}_bench_config1.json" 2>/dev/null
+python bench.py --faces 1 --no-cpu-baseline > "$OUT/${TAG}_bench_k1.json" 2>/dev/null
+FRT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_rccl_1rank.json"
+FRT_BENCH_FORCE_DIST=1 python bench.py --sharded-gallery --batch 64 --gallery 1250000 --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_sharded_1rank.json"
 ls -la "$OUT"
