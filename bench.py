@@ -220,11 +220,6 @@ def main():
         raise SystemExit("bench.py needs a HIP device (libfrt has no CPU path)")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("FRT_BENCH_FORCE_DIST") == "1"  # the env switch exercises the RCCL path on one GPU
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
     s = frt.synth
     K, H, W = args.faces, 640, 640   # detector input
     FW, FH = (int(v) for v in args.frame.lower().split("x"))
@@ -258,7 +253,13 @@ def main():
         rec.setGallery(gallery)  # bulk initKnownEmbeds + addEmbedding x N through the streaming loader (pinned chunks, async copies)
         rec.initMatMul()
     gallery_load_s = time.perf_counter() - t_load
-    pipe = frt.Pipeline(det, rec, B)
+    pipe = frt.Pipeline(det, rec, B, match=not args.sharded_gallery)  # sharded gallery: the pipeline produces embeddings, match + merge follow below
+    if use_dist:
+        # AFTER the pipeline exists: RCCL creates streams of its own, and a stream created before the pipeline's stage streams can change
+        # how ROCm maps those onto hardware queues (the stages then share a queue with somebody's pending waits and stop overlapping)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # two alternating batches so that consecutive steps never see the same pixels
     batches = [s.make_frames(B, FH, FW, start=frame_start), s.make_frames(B, FH, FW, start=frame_start + 4096)]
@@ -286,11 +287,8 @@ def main():
     ev_side = [torch.cuda.Event() for _ in range(NRING)] if use_dist else None
     gather = use_dist and not args.no_gather
 
-    # ---- sharded-gallery mode (configs[4]): second pipeline without a matcher produces embeddings; match + merge follow here
+    # ---- sharded-gallery mode (configs[4]): the pipeline has no matcher stage and produces embeddings; match + merge follow here
     if args.sharded_gallery:
-        pipe.close()
-        pipe = frt.Pipeline(det, rec, B, match=False)
-        pipe.set_stream(stream.cuda_stream)
         d_emb = [torch.zeros(F, 512, device="cuda") for _ in range(NRING)]
         d_idx = torch.zeros(world * F, dtype=torch.int32, device="cuda")
         d_sim = torch.zeros(world * F, dtype=torch.float32, device="cuda")
@@ -489,6 +487,15 @@ def main():
                                       "ms_per_step": round(1e3 * dtb / n_ss, 4),
                                       "note": "same loop as the timed region over %d steps, no profiled step (the %d-step contract region "
                                               "carries pipeline fill + drain + one serial profiled step)" % (n_ss, args.steps)}
+    if not use_dist and not args.no_extras and not args.sharded_gallery:
+        # ---- latency of ONE synchronous call (frt_pipeline_run: pinned host frames in, host records out, nothing else in flight)
+        lat = []
+        for i in range(12):
+            tl = time.perf_counter()
+            pipe.run(h_np[i & 1], want_embeds=False)
+            lat.append(time.perf_counter() - tl)
+        extras["sync_call_latency_ms"] = {"median": round(1e3 * float(np.median(lat[2:])), 3), "min": round(1e3 * float(np.min(lat[2:])), 3),
+                                          "note": "frt_pipeline_run, one %d-frame batch at a time (no batches in flight): the reference's request/reply shape" % B}
     if use_dist and not args.strong and not args.sharded_gallery and not args.no_extras:
         # ---- BASELINE configs[3] as written: ONE 32-frame batch split over the ranks (strong scaling), gallery replicated
         sb, se = fd.shard_range(args.batch, rank, world)

@@ -907,7 +907,10 @@ struct frt_matcher {
     }
     void load_begin(int cap, int cols) {
         if (ld.active) load_abort();
-        if (!ld.s) HIPCHK(hipStreamCreateWithFlags(&ld.s, hipStreamNonBlocking));
+        // The load runs on the matcher's own stream.  NOT on a stream of its own: one more hipStreamCreateWithFlags(hipStreamNonBlocking)
+        // stream in the process before the pipeline's stage streams exist changes how ROCm maps those onto hardware queues, and the
+        // stages of consecutive calls stop overlapping (measured: batch-1 step 0.56 -> 1.39 ms, batch-32 step +10 %).
+        ld.s = stream;
         const size_t need = (size_t)Load::CH_ROWS * cols;
         if (ld.stage_floats != need) {
             load_release_staging();
@@ -1753,7 +1756,6 @@ void frt_matcher_destroy(frt_matcher *m) {
     }
     m->load_abort();
     m->load_release_staging();
-    if (m->ld.s) (void)hipStreamDestroy(m->ld.s);
     if (m->ev_busy) (void)hipEventDestroy(m->ev_busy);
     for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full, (void *)m->d_g16})
         if (p) (void)hipFree(p);

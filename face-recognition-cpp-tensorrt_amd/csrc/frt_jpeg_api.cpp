@@ -100,6 +100,12 @@ struct frt_jpeg_decoder {
     // encoder scratch (reply step)
     uint16_t *d_q = nullptr;
     int q_quality = -1;
+    // A private stream only when a caller really passes NULL: an extra non-blocking stream created before a pipeline's stage streams
+    // disturbs ROCm's stream -> hardware-queue mapping (see frt_matcher::load_begin); callers that feed a pipeline pass their producer stream.
+    hipStream_t ensure_stream() {
+        if (!own_stream) HIPCHK(hipStreamCreate(&own_stream));
+        return own_stream;
+    }
     frtjpeg::EncTables enc{};
     uint8_t *d_crops = nullptr;
     int16_t *d_eblocks = nullptr, *h_eblocks = nullptr;
@@ -204,7 +210,7 @@ int frt_jpeg_decoder_create(int max_images, int max_width, int max_height, int n
         d->pool.reset(new Pool(n_threads > 1 ? n_threads : 0));
         d->blocks_per_image = blocks_for(max_width, max_height);
         d->plane_bytes_per_image = d->blocks_per_image * 64;
-        HIPCHK(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
+        // (own_stream is created on first use with a NULL caller stream: see ensure_stream)
         for (frt_jpeg_decoder::Set &s : d->set) {
             const size_t cb = d->blocks_per_image * max_images * 128;
             HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&s.h_coef), cb, hipHostMallocDefault));
@@ -246,7 +252,7 @@ int frt_jpeg_decode_batch_dev(frt_jpeg_decoder *d, const uint8_t *const *data, c
         if (n > d->max_images) raise(FRT_ERR_CAPACITY, "jpeg decode: more images than the decoder was created for");
         std::lock_guard<std::mutex> lk(d->mu);
         use_device(d->device);
-        hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : d->own_stream;
+        hipStream_t st = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : d->ensure_stream();
         frt_jpeg_decoder::Set &s = d->set[d->cur];
         d->cur = (d->cur + 1) % frt_jpeg_decoder::NSET;
         if (s.pending) {  // the staging set's previous batch must have left the host buffers
@@ -332,7 +338,7 @@ int frt_jpeg_decode(frt_jpeg_decoder *d, const uint8_t *data, size_t size, uint8
         std::string msg = frthost::last_error();
         hipError_t e = hipSuccess;
         if (rc == FRT_OK) {
-            e = hipStreamSynchronize(d->own_stream);
+            e = hipStreamSynchronize(d->ensure_stream());
             if (e == hipSuccess) e = hipMemcpy(bgr_out, dev, (size_t)w * h * 3, hipMemcpyDeviceToHost);
         }
         (void)hipFree(dev);
@@ -378,7 +384,7 @@ int frt_jpeg_encode_batch(frt_jpeg_decoder *d, const void *bgr, int device_input
         std::lock_guard<std::mutex> lk(d->mu);
         use_device(d->device);
         encode_setup(d, quality, n, rows, cols);
-        hipStream_t st = d->own_stream;
+        hipStream_t st = d->ensure_stream();
         const uint8_t *src = reinterpret_cast<const uint8_t *>(bgr);
         if (!device_input) {
             HIPCHK(hipMemcpyAsync(d->d_crops, bgr, (size_t)n * rows * cols * 3, hipMemcpyHostToDevice, st));

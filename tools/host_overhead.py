@@ -6,17 +6,19 @@ frt = entry.load_pkg(); s = frt.synth
 tmp = tempfile.mkdtemp()
 dp = frt.write_weights(os.path.join(tmp, "d.frtw"), s.retinaface_state(1), 1)
 rp = frt.write_weights(os.path.join(tmp, "r.frtw"), s.arcface_state(2, "ir", calib=s.load_calibration("ir")), 2)
-B, K = 32, 4
+B, K = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 4
+_pre = [torch.cuda.Stream() for _ in range(int(os.environ.get("N_PRE", "0")))]
 det = frt.RetinaFace(dp, 640, 640, (3, 640, 640), B, K, 0.4, 0.6)
 rec = frt.ArcFaceIR50(rp, 640, 640, (3, 112, 112), 512, B * K, K, 0.65)
-rec.setGallery(s.make_gallery(100000)); rec.initMatMul()
+rec.setGallery(s.make_gallery(int(sys.argv[2]) if len(sys.argv) > 2 else 100000)); rec.initMatMul()
 pipe = frt.Pipeline(det, rec, B)
 fr = torch.from_numpy(s.make_frames(B, 640, 640)).cuda()
 res = torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
-pipe.set_stream(torch.cuda.current_stream().cuda_stream)
+_mid = [torch.cuda.Stream() for _ in range(int(os.environ.get("N_MID", "0")))]
+st = torch.cuda.Stream(); torch.cuda.set_stream(st); pipe.set_stream(st.cuda_stream)
 for _ in range(5): pipe.run_dev(fr.data_ptr(), B, res.data_ptr(), None)
 torch.cuda.synchronize()
-for graph in (0, 1):
+for graph in (0,):
     pipe.set_graph(graph)
     for _ in range(6): pipe.run_dev(fr.data_ptr(), B, res.data_ptr(), None)
     torch.cuda.synchronize()
