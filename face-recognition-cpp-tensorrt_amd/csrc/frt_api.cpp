@@ -648,7 +648,8 @@ void frt_embedder::build(const frt::Blob &b) {
             {  // conv1 is always stride 1; conv2 only in the units that keep the resolution
                 const std::vector<uint16_t> f1 = conv_w_f16_frag(b, p + ".res_layer.1.weight", a.depth, a.cin);
                 if (!f1.empty()) a.w1f = reinterpret_cast<half_t *>(arena.upload(f1));
-                const std::vector<uint16_t> f2 = conv_w_f16_frag(b, p + ".res_layer.3.weight", a.depth, a.depth, a.stride == 2);
+                // the 64 -> 64 stride-2 layer has its own kernel that stages rows in natural order and walks the taps in tap order
+                const std::vector<uint16_t> f2 = conv_w_f16_frag(b, p + ".res_layer.3.weight", a.depth, a.depth, a.stride == 2 && a.depth != 64);
                 if (!f2.empty()) (a.stride == 1 ? a.w2f : a.w2f2) = reinterpret_cast<half_t *>(arena.upload(f2));
             }
             a.prelu = arena.upload(vec_of(b, p + ".res_layer.2.weight", a.depth));

@@ -171,7 +171,7 @@ struct ConvMfmaArgs {
     const half_t *zeros;  // >= 16 bytes of zeros (source of padded taps for the LDS-DMA path)
 };
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
-bool conv_s2_applies(const ConvMfmaArgs &a);                // kernels_arc_s2.hip: 3x3 stride 2, Cout % 128 == 0
+bool conv_s2_applies(const ConvMfmaArgs &a);                // kernels_arc_s2.hip: 3x3 stride 2, Cout % 128 == 0 or 64 -> 64 at 112 -> 56
 bool launch_conv_s2(const ConvMfmaArgs &a, hipStream_t s);
 const char *conv_s2_label(const ConvMfmaArgs &a);
 bool conv64_applies(const ConvMfmaArgs &a);                 // kernels_arc_c64.hip: Cin = Cout = 64, 3x3, stride 1

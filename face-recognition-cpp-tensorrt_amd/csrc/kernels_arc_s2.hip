@@ -260,6 +260,188 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 64 -> 64, stride 2 (112 -> 56)
+// The second conv of the very first unit has ONE 64-channel chunk and 64 output channels: 72 MFMAs per wave between a patch load and
+// an epilogue, nothing to software-pipeline - the layer is a stream of 360 MB (205 MB in, shortcut, two outputs).  The overlap comes
+// from co-resident workgroups instead: small persistent ones (2 waves = the two 32-cout blocks) at three per CU, each walking a
+// contiguous range of output rows (one row = 2 pixel tiles per step).
+//  * the wave's 36 weight fragments (fragment-ordered, 36 contiguous KB) stay in 144 registers for the kernel's lifetime: a first
+//    version that fetched them per output row moved 516 MB through L2 and was bound by exactly that (42 us with everything else off);
+//  * input rows are staged in their NATURAL order (three 113-pixel row slots of 128 B pixels, no phase planes): a row is 14 LDS-DMA
+//    instructions of one contiguous kilobyte each (phase planes made every request a 128-byte piece at a 256-byte stride: 2.6 TB/s
+//    with nothing else running).  The 16-byte pieces of pixel x sit at piece ^ ((x + 1) / 2 % 8) - applied on the DMA's SOURCE side,
+//    the request stays one contiguous kilobyte - so the stride-2 fragment reads are two-way instead of eight-way bank conflicts;
+//  * row 2 oy + 1 of one step is row 2 oy' - 1 of the next: slot(y) = (y + 1) % 3, two new rows per step;
+//  * the next step's rows are requested right behind the barrier that ends the MFMA loop and land under the epilogue (its transpose
+//    tiles have their own 9 KB: 52.6 KB per workgroup - 53 248 is the most that still fits three per CU).
+// 135 us (im2col kernel) -> 100 - 105 us = 3.5 TB/s on the 360 MB.  What bounds it now is the dependent chain of a step (row fetch ->
+// 72 MFMAs -> shortcut load -> stores) at three chains per CU; the staging alone streams at 4.8 TB/s (43 us).
+constexpr int C64_ROW = 113 * 128;               // one input row: x = -1 .. 111, 128 bytes per pixel (x = 112 is only read by dead pixel slots)
+constexpr int C64_LDS = 3 * C64_ROW + 2 * 32 * 36 * 4;  // + the epilogue tiles with the channel parameters in their pad columns (the dead pixel slots' read overrun, pixel index <= 128, lands there)
+__global__ __launch_bounds__(128, 2) void conv_s2c64_kernel(ConvMfmaArgs p, int n_rows) {
+    constexpr int Wo = 56, Ho = 56, W = 112, H = 112;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int nblk = gridDim.x, bq = nblk >> 3, brem = nblk & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int lid = (xcd < brem ? xcd * (bq + 1) : brem * (bq + 1) + (xcd - brem) * bq) + slot;  // neighbouring ranges share an L2
+    const int row_begin = (int)((long)lid * n_rows / nblk), row_end = (int)((long)(lid + 1) * n_rows / nblk);
+
+    constexpr int EROW = 36;  // floats per pixel row of the epilogue tile (32 + 4 pad)
+    float *ep = reinterpret_cast<float *>(smem + 3 * C64_ROW) + wave * (32 * EROW);
+    const int chunk = lane & 3;
+    const int cch = wave * 32 + chunk * 8;  // this lane's 8 couts in the epilogue
+
+    half8 areg[9][4];  // [kh * 3 + kw][kk]: the fragment-ordered copy in tap order (wf, not the phase-plane order)
+    {
+        const half_t *wfrag = p.wf + (long)wave * (9 * 4 * 512) + lane * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) areg[t][kk] = *reinterpret_cast<const half8 *>(wfrag + (t * 4 + kk) * 512);
+    }
+    // channel parameters p0 | p1 | p2 | p3 (64 floats each) live in the 4 pad columns of the two epilogue tiles: parameter t of array a
+    // at tile (a >> 1), row ((a & 1) * 64 + t) >> 2, column 32 + (t & 3)
+    auto prm = [&](int a, int t) -> float * {
+        return reinterpret_cast<float *>(smem + 3 * C64_ROW) + (a >> 1) * (32 * EROW) + ((((a & 1) << 6) + t) >> 2) * EROW + 32 + (t & 3);
+    };
+    if (tid < 64) {
+        const bool two0 = p.mode == EPI_BN_ADD_BN && p.out1;
+        *prm(0, tid) = p.p0[tid];
+        *prm(1, tid) = p.p1[tid];
+        *prm(2, tid) = two0 ? p.p2[tid] : 0.f;
+        *prm(3, tid) = two0 ? p.p3[tid] : 0.f;
+    }
+    if (tid < 24) {  // the x = -1 column of the three slots stays zero (the DMA writes pixels 1 .. 112 only)
+        const int sl = tid >> 3, c = tid & 7;
+        *reinterpret_cast<floatx4 *>(smem + sl * C64_ROW + c * 16) = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    // DMA: instruction k of a row moves pixels 8 k .. 8 k + 7 (x) = LDS pixels 1 + 8 k ..; lane = (pixel, LDS chunk c), source piece c ^ swizzle
+    const int dpx = lane >> 3, dc = lane & 7;
+    const int src_even = dpx * 64 + ((dc ^ (((1 + dpx) >> 1) & 7)) << 3);      // k even: ((1 + 8 k + dpx) >> 1) & 7 = ((1 + dpx) >> 1) & 7
+    const int src_odd = dpx * 64 + ((dc ^ ((((1 + dpx) >> 1) + 4) & 7)) << 3);  // k odd: + 4
+    auto fetch_row = [&](const half_t *img, int y, int k0, int k1) {
+        char *dst = smem + ((y + 1) % 3) * C64_ROW + 128;
+        const bool row_ok = y >= 0;
+        const half_t *rowp = img + y * (W * 64);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) {
+            if (k < k0 || k >= k1) continue;
+            const half_t *src = row_ok ? rowp + k * 512 + ((k & 1) ? src_odd : src_even) : p.zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
+        }
+    };
+    auto fetch = [&](int row, bool fresh) {  // input rows of output row `row`: wave 0 the even row 2 oy, wave 1 the odd row 2 oy + 1
+        const int b = row / Ho, oy = row - b * Ho;
+        const half_t *img = p.x + (long)b * (H * W * 64);
+        if (fresh) fetch_row(img, 2 * oy - 1, wave * 7, wave * 7 + 7);  // otherwise inherited from the previous step
+        fetch_row(img, 2 * oy + wave, 0, 14);
+    };
+
+    if (row_begin < row_end) fetch(row_begin, true);
+    // fragment read: pixel x = 2 sl + kw - 1 -> LDS pixel 2 sl + kw, piece pc = 2 kk + hi at chunk pc ^ ((sl + (kw >> 1)) & 7)
+    int boff[2][2];  // [tile][kw >> 1]: byte offset of kk = 0 inside a row slot, without the kw pixel offset
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sl = j * 32 + r;
+            boff[j][h] = sl * 256 + ((hi ^ ((sl + h) & 7)) << 4);
+        }
+    for (int row = row_begin; row < row_end; ++row) {
+        const int b = row / Ho, oy = row - b * Ho;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        floatx16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const char *rowb = smem + ((2 * oy + kh) % 3) * C64_ROW;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const half8 bf = *reinterpret_cast<const half8 *>(rowb + ((boff[j][kw >> 1] ^ (kk << 5)) + kw * 128));
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[kh * 3 + kw][kk], bf, acc[j], 0, 0, 0);
+                    }
+        }
+        __syncthreads();  // every row read has been consumed: rows 2 oy - 1 and 2 oy are free
+        if (row + 1 < row_end) fetch(row + 1, oy + 1 == Ho);
+
+        // epilogue (per wave: 32 couts x 2 pixel tiles) through a wave-private fp32 tile in LDS, as in the kernel above
+        const bool two = p.mode == EPI_BN_ADD_BN && p.out1;
+        const long m0 = ((long)b * Ho + oy) * Wo;
+        const long s0 = p.mode == EPI_BN_ADD_BN ? ((long)b * p.sc_h + oy * p.sc_stride) * p.sc_w : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // per tile: the shortcut and the channel parameters are (re)loaded here (L1 hits) - with the 144 weight registers the
+            // kernel has no room to keep them across the MFMA loop, and a compiler barrier keeps them from being hoisted
+            asm volatile("" ::: "memory");
+            half8 sc8[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int sl = j * 32 + (lane >> 2) + 16 * it;
+                if (p.mode == EPI_BN_ADD_BN) sc8[it] = *reinterpret_cast<const half8 *>(p.sc + (s0 + (sl < Wo ? sl * p.sc_stride : 0)) * 64 + cch);
+            }
+            floatx4 q0[2], q1[2], q2[2], q3[2];  // channel parameters from their LDS copy
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                q0[h] = *reinterpret_cast<const floatx4 *>(prm(0, cch + 4 * h));
+                q1[h] = *reinterpret_cast<const floatx4 *>(prm(1, cch + 4 * h));
+                q2[h] = *reinterpret_cast<const floatx4 *>(prm(2, cch + 4 * h));
+                q3[h] = *reinterpret_cast<const floatx4 *>(prm(3, cch + 4 * h));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = v;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int px = (lane >> 2) + 16 * it;
+                const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
+                const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
+                const int sl = j * 32 + px;
+                if (sl >= Wo) continue;
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3];
+                if (p.mode == EPI_BN_ADD_BN) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)sc8[it][e];
+                }
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                *reinterpret_cast<half8 *>(p.out0 + (m0 + sl) * 64 + cch) = o;
+                if (two) {
+                    half8 z;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) z[e] = (half_t)(v[e] * q2[e >> 2][e & 3] + q3[e >> 2][e & 3]);
+                    *reinterpret_cast<half8 *>(p.out1 + (m0 + sl) * 64 + cch) = z;
+                }
+            }
+        }
+    }
+}
+
+bool s2c64_applies(const ConvMfmaArgs &a) {
+    if (!a.wf2 || a.ks != 3 || a.stride != 2 || a.pad != 1 || a.Cout != 64 || a.Cin != 64 || a.splits != 1 || (a.H & 1) || (a.W & 1)) return false;
+    if (a.Ho * 2 != a.H || a.Wo * 2 != a.W || a.Wo != 56 || a.Ho != 56) return false;
+    if (a.mode != EPI_BN && a.mode != EPI_BN_ADD_BN) return false;
+    if (a.mode == EPI_BN_ADD_BN && !a.sc) return false;
+    static const bool off = frt_tuning_env("FRT_CONV_S2") && frt_tuning_env("FRT_CONV_S2")[0] == '0';
+    return !off;
+}
+
 template <int NT, int PP>
 void launch_s2_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
     constexpr size_t lds = (size_t)4 * PP * 4096;
@@ -305,11 +487,12 @@ bool s2_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &nt, int &pp) {
 
 bool conv_s2_applies(const ConvMfmaArgs &a) {
     int R, n_img, nt, pp;
-    return s2_geometry(a, R, n_img, nt, pp);
+    return s2c64_applies(a) || s2_geometry(a, R, n_img, nt, pp);
 }
 
 const char *conv_s2_label(const ConvMfmaArgs &a) {
     int R, n_img, nt, pp;
+    if (s2c64_applies(a)) return "conv_s2c64_kernel";
     if (!s2_geometry(a, R, n_img, nt, pp)) return nullptr;
     if (nt == 7) return "conv_s2_kernel<7, 9>";
     if (nt == 4) return pp <= 5 ? "conv_s2_kernel<4, 5>" : "conv_s2_kernel<4, 9>";
@@ -318,6 +501,16 @@ const char *conv_s2_label(const ConvMfmaArgs &a) {
 
 bool launch_conv_s2(const ConvMfmaArgs &a0, hipStream_t s) {
     int R, n_img, nt, pp;
+    if (s2c64_applies(a0)) {
+        ConvMfmaArgs a = a0;
+        a.wf = a0.wf2;  // tap order for this kernel (the host packs wf2 in tap order when Cout == 64, frt_api.cpp)
+        static bool attr_done[FRT_MAX_DEVICES] = {};
+        if (frt_first_use_on_device(attr_done))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s2c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS);
+        const int n_rows = a.B * a.Ho;
+        hipLaunchKernelGGL(conv_s2c64_kernel, dim3(n_rows < 768 ? n_rows : 768), dim3(128), C64_LDS, s, a, n_rows);
+        return true;
+    }
     if (!s2_geometry(a0, R, n_img, nt, pp)) return false;
     ConvMfmaArgs a = a0;
     a.wf = a0.wf2;  // the kernel streams the stride-2 step order
