@@ -350,10 +350,10 @@ __global__ __launch_bounds__(128, 2) void conv_s2c64_kernel(ConvMfmaArgs p, int 
             const int sl = j * 32 + r;
             boff[j][h] = sl * 256 + ((hi ^ ((sl + h) & 7)) << 4);
         }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int row = row_begin; row < row_end; ++row) {
         const int b = row / Ho, oy = row - b * Ho;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();  // this wave's rows have landed (waited for at the end of the previous step): now everybody's have
 
         floatx16 acc[2];
 #pragma unroll
@@ -382,8 +382,9 @@ __global__ __launch_bounds__(128, 2) void conv_s2c64_kernel(ConvMfmaArgs p, int 
         const long s0 = p.mode == EPI_BN_ADD_BN ? ((long)b * p.sc_h + oy * p.sc_stride) * p.sc_w : 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            // per tile: the shortcut and the channel parameters are (re)loaded here (L1 hits) - with the 144 weight registers the
-            // kernel has no room to keep them across the MFMA loop, and a compiler barrier keeps them from being hoisted
+            // per tile: the shortcut and the channel parameters are (re)loaded here - with the 144 weight registers the kernel has no
+            // room to keep them across the MFMA loop (requesting the shortcut in front of the row fetch, so that it does not return
+            // behind it, was measured: 16 spilled registers, no gain); a compiler barrier keeps them from being hoisted
             asm volatile("" ::: "memory");
             half8 sc8[2];
 #pragma unroll
@@ -430,6 +431,10 @@ __global__ __launch_bounds__(128, 2) void conv_s2c64_kernel(ConvMfmaArgs p, int 
                 }
             }
         }
+        // wait for the next step's rows but not for this step's stores: memory operations retire in order and the stores (4 per output
+        // tensor, issued by every lane group) are the youngest ones - anything else the compiler added only makes the wait stricter
+        if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
 }
 
