@@ -1071,10 +1071,10 @@ struct frt_pipeline {
     int max_frames, max_faces, F_cap;
     hipStream_t stream = nullptr, own_stream = nullptr;
     // Three-stage software pipeline over consecutive calls: detector of call b+1 (det_stream), crop + recogniser of call b
-    // (emb_stream), match + pack of call b-1 (match_stream) - three stages with different bottlenecks (latency / MFMA+LDS / HBM)
-    // that overlap on the same CUs.  `stream` (the caller's) only joins.  Fork/join with events; boxes, embeddings and validity
+    // (emb_stream / emb_stream2 alternately), match + pack of call b-1 (behind its recogniser pass on the same stream, i.e. beside
+    // the other set's pass) - three stages with different bottlenecks (latency / MFMA+LDS / HBM) that overlap on the same CUs.  `stream` (the caller's) only joins.  Fork/join with events; boxes, embeddings and validity
     // flags of a call live in one of two slots so that a later stage of the previous call can still read them.
-    hipStream_t det_stream = nullptr, emb_stream = nullptr, emb_stream2 = nullptr, match_stream = nullptr;
+    hipStream_t det_stream = nullptr, emb_stream = nullptr, emb_stream2 = nullptr;
     bool dual_embed = true;   // recogniser passes of consecutive calls on two streams with two activation sets (FRT_PIPELINE_DUAL_EMBED=0: one)
     float *d_chw2 = nullptr;
     hipEvent_t ev_serial = nullptr;  // end of the last serial (profiled) call while overlap is on
@@ -1216,11 +1216,13 @@ struct frt_pipeline {
             HIPCHK(hipStreamWaitEvent(det_stream, ev_serial, 0));
             HIPCHK(hipStreamWaitEvent(emb_stream, ev_serial, 0));
             HIPCHK(hipStreamWaitEvent(emb_stream2, ev_serial, 0));
-            HIPCHK(hipStreamWaitEvent(match_stream, ev_serial, 0));
             serial_pending = false;
         }
         const int eset = (pipe3 && dual_embed && F <= emb->max_batch) ? (int)(call & 1u) : 0;  // activation set / stream of this call's recogniser pass
-        hipStream_t ds = pipe3 ? det_stream : s, es = pipe3 ? (eset ? emb_stream2 : emb_stream) : s, ms = pipe3 ? match_stream : s;
+        hipStream_t ds = pipe3 ? det_stream : s, es = pipe3 ? (eset ? emb_stream2 : emb_stream) : s;
+        // match + pack follow the recogniser pass on ITS stream (they overlap the other set's pass and the next detector pass): a stream
+        // of their own measured 0.6 % slower and is one more stream competing for the four hardware queues
+        hipStream_t ms = es;
         float *chw = eset ? d_chw2 : d_chw;
         if (pipe3 && call >= (unsigned)NSLOT) {
             // slot buffers are free again once M of the call two back is done.  NB the frames must be valid when the call is made:
@@ -1959,7 +1961,6 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
             e->ensure_alt();
             p->d_chw2 = p->arena.alloc<float>((size_t)max_frames * d->g.max_faces * 3 * 112 * 112);
         }
-        mk(&p->match_stream);
         const size_t F = (size_t)p->F_cap;
         HIPCHK(hipEventCreateWithFlags(&p->ev_serial, hipEventDisableTiming));
         for (int i = 0; i < frt_pipeline::NSLOT; ++i) {
@@ -1992,14 +1993,12 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     if (p->det_stream) (void)hipStreamSynchronize(p->det_stream);
     if (p->emb_stream) (void)hipStreamSynchronize(p->emb_stream);
     if (p->emb_stream2) (void)hipStreamSynchronize(p->emb_stream2);
-    if (p->match_stream) (void)hipStreamSynchronize(p->match_stream);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     p->drop_graphs();
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->det_stream) (void)hipStreamDestroy(p->det_stream);
     if (p->emb_stream) (void)hipStreamDestroy(p->emb_stream);
     if (p->emb_stream2) (void)hipStreamDestroy(p->emb_stream2);
-    if (p->match_stream) (void)hipStreamDestroy(p->match_stream);
     if (p->ev_serial) (void)hipEventDestroy(p->ev_serial);
     if (p->ev_input) (void)hipEventDestroy(p->ev_input);
     if (p->copy_stream) {
@@ -2072,7 +2071,6 @@ int frt_pipeline_sync(frt_pipeline *p) {
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
-        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
     });
 }
@@ -2085,7 +2083,6 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
-        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : p->own_stream;  // null own_stream: created at the next run
     });
@@ -2099,7 +2096,6 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable) {
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
-        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->overlap = enable != 0;
         p->seq = 0;
@@ -2115,7 +2111,6 @@ int frt_pipeline_set_graph(frt_pipeline *p, int enable) {
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
-        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->use_graphs = enable != 0;
         p->drop_graphs();
@@ -2131,7 +2126,6 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable) {
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
-        HIPCHK(hipStreamSynchronize(p->match_stream));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->align = enable != 0;
     });
