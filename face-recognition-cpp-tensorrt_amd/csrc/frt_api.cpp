@@ -703,7 +703,8 @@ void frt_embedder::build(const frt::Blob &b) {
     SC = arena.alloc<half_t>(F * 28 * 28 * 128);  // largest conv-shortcut output (56->28, 128 ch)
     if (se) {
         RES = arena.alloc<half_t>(F * 56 * 56 * 64);
-        se_pool = arena.alloc<float>(F * 512 * 4);  // SE_SPLIT partial sums per (face, channel)
+        se_pool = arena.alloc<float>(F * 512 * 4 + F);  // SE_SPLIT partial sums per (face, channel) + the per-face arrival counters
+        HIPCHK(hipMemset(se_pool + F * 512 * 4, 0, F * sizeof(int)));  // (kept at zero between launches by the kernel)
         se_gate = arena.alloc<float>(F * 512);
     }
     fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);
@@ -730,7 +731,8 @@ void frt_embedder::ensure_alt() {
     alt.se_pool = alt.se_gate = nullptr;
     if (se) {
         alt.RES = arena.alloc<half_t>(F * 56 * 56 * 64);
-        alt.se_pool = arena.alloc<float>(F * 512 * 4);
+        alt.se_pool = arena.alloc<float>(F * 512 * 4 + F);
+        HIPCHK(hipMemset(alt.se_pool + F * 512 * 4, 0, F * sizeof(int)));
         alt.se_gate = arena.alloc<float>(F * 512);
     }
     alt.fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);
@@ -808,7 +810,8 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
                 launch_conv_mfma(a, s);
             }
             if (se) {
-                SeArgs sa{RES, u.se_w1, u.se_w2, sc_t, sc_h, sc_h, sc_stride, u.sn, u.bn, Y[cur ^ 1], Z[cur ^ 1], se_pool, se_gate, F, ho, ho, u.depth};
+                SeArgs sa{RES, u.se_w1, u.se_w2, sc_t, sc_h, sc_h, sc_stride, u.sn, u.bn, Y[cur ^ 1], Z[cur ^ 1], se_pool, se_gate, F, ho, ho, u.depth,
+                          reinterpret_cast<int *>(se_pool + (size_t)max_batch * 512 * 4)};
                 launch_se(sa, s);
             }
         }

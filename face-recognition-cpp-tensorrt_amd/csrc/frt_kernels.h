@@ -203,5 +203,6 @@ struct SeArgs {
     float *pool;         // scratch [4][F][C] (partial sums over pixel ranges)
     float *gate;         // scratch [F][C]
     int F, H, W, C;
+    int *counter;        // [F] arrival counters of the pooling pass, zero between launches
 };
 void launch_se(const SeArgs &a, hipStream_t s);

@@ -804,11 +804,57 @@ __global__ __launch_bounds__(512) void fc_finalize_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------- SE tail (IR-SE): model_irse.py:22-45
-constexpr int SE_SPLIT = 4;  // pixel ranges per face (partial sums, summed in fixed order by the gate kernel: deterministic)
-__global__ __launch_bounds__(256) void se_pool_kernel(const half_t *__restrict__ res, int HW, int C, int F, float *__restrict__ partial) {
-    // grid (SE_SPLIT, F).  thread = (channel octet, pixel lane): 16-byte loads, consecutive threads read one pixel's contiguous NHWC
-    // row (the first version walked HW serially with one 2-byte load per step per channel: 154 us per call)
+constexpr int SE_SPLIT = 4;  // pixel ranges per face (partial sums, summed in fixed order: deterministic)
+// fc1 -> ReLU -> fc2 -> sigmoid on the pooled vector sp[C] (LDS), 256 threads.  Both layers are a few thousand MACs: what costs is
+// the dependent chain, so every hidden unit gets 256 / R threads that each take a contiguous run of channels (all loads of a thread
+// are independent 16-byte loads in flight at once), then a fixed-order shuffle reduction; the output layer is a thread per channel
+// with its R weights as float4 loads.  (A wave per hidden unit walking the channels and a scalar loop over R: 5 - 11 us per call.)
+__device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const float *__restrict__ w1, const float *__restrict__ w2, int C, int f,
+                                           float *__restrict__ gate) {
+    const int R = C / 16;            // hidden units: 4 .. 32
+    const int G = 256 / R;           // threads per hidden unit: 64 .. 8 (a power of two, inside one wave)
+    const int per = C / G;           // channels per thread: 1, 4, 16, 64
+    const int h = threadIdx.x / G, g = threadIdx.x % G;
+    float a = 0.f;
+    if (per == 1) {
+        a = w1[(long)h * C + g] * sp[g];
+    } else {
+        const float *wp = w1 + (long)h * C + g * per;
+        const float *xp = sp + g * per;
+        for (int i = 0; i < per; i += 4) {
+            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
+            a = fmaf(w[0], xp[i], a);
+            a = fmaf(w[1], xp[i + 1], a);
+            a = fmaf(w[2], xp[i + 2], a);
+            a = fmaf(w[3], xp[i + 3], a);
+        }
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (g == 0) shid[h] = fmaxf(a, 0.f);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float *wp = w2 + (long)c * R;
+        float o = 0.f;
+        for (int i = 0; i < R; i += 4) {
+            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
+            o = fmaf(w[0], shid[i], o);
+            o = fmaf(w[1], shid[i + 1], o);
+            o = fmaf(w[2], shid[i + 2], o);
+            o = fmaf(w[3], shid[i + 3], o);
+        }
+        gate[(long)f * C + c] = 1.f / (1.f + expf(-o));
+    }
+}
+// Pooling + gate in one launch.  grid (SE_SPLIT, F): every block sums its pixel range per channel; the block that arrives LAST for a
+// face (device-scope counter; the partial sums travel as device-scope stores / loads) adds the SE_SPLIT partial sums in range order and runs the two tiny FC layers - so the result does
+// not depend on which block that is.  (A separate gate kernel cost 5 - 11 us + a dependent launch per unit, 24 units per pass; pool +
+// gate in ONE block per face had measured 18.6 us against 6.0 + 5.0: 128 blocks walking 100 KB each are latency-bound.)
+__global__ __launch_bounds__(256) void se_pool_gate_kernel(const half_t *__restrict__ res, int HW, int C, int F, float *__restrict__ partial,
+                                                           const float *__restrict__ w1, const float *__restrict__ w2, float *__restrict__ gate,
+                                                           int *__restrict__ counter) {
+    // thread = (channel octet, pixel lane): 16-byte loads, consecutive threads read one pixel's contiguous NHWC row
     __shared__ float red[256 * 8];
+    __shared__ int s_last;
     const int f = blockIdx.y, part = blockIdx.x;
     const int C8 = C >> 3, NP = 256 / C8;          // C in {64, 128, 256, 512}: C8 <= 64
     const int oct = threadIdx.x % C8, pl = threadIdx.x / C8;
@@ -825,52 +871,33 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const half_t *__restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
     __syncthreads();
-    if (threadIdx.x < C) {  // channel c = octet * 8 + e: sum over the NP pixel lanes in lane order
-        const int c = threadIdx.x, o = c >> 3, e = c & 7;
+    for (int c = threadIdx.x; c < C; c += 256) {  // channel c = octet * 8 + e: sum over the NP pixel lanes in lane order
+        const int o = c >> 3, e = c & 7;
         float t = 0.f;
         for (int q = 0; q < NP; ++q) t += red[(q * C8 + o) * 8 + e];
-        partial[((long)part * F + f) * C + c] = t;
+        // device-scope store (written through this XCD's L2): the block that gathers the partial sums may sit on another XCD
+        __hip_atomic_store(&partial[((long)part * F + f) * C + c], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (C > 256 && threadIdx.x + 256 < C) {
-        const int c = threadIdx.x + 256, o = c >> 3, e = c & 7;
-        float t = 0.f;
-        for (int q = 0; q < NP; ++q) t += red[(q * C8 + o) * 8 + e];
-        partial[((long)part * F + f) * C + c] = t;
-    }
-}
-// fc1 -> ReLU -> fc2 -> sigmoid on the pooled vector sp[C] (LDS): a wave per hidden unit (lanes stride over the channels, shuffle
-// reduction in a fixed order), then a thread per output channel
-__device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const float *__restrict__ w1, const float *__restrict__ w2, int C, int f,
-                                           float *__restrict__ gate) {
-    const int R = C / 16, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int h = wave; h < R; h += 4) {
-        float a = 0.f;
-        for (int c = lane; c < C; c += 64) a = fmaf(w1[(long)h * C + c], sp[c], a);
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-        if (lane == 0) shid[h] = fmaxf(a, 0.f);
+    // every store above has been acknowledged before this block announces its arrival.  NOT __threadfence(): a device-scope fence
+    // writes back / invalidates the whole L2 (measured: 50 us per launch instead of 6)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(&counter[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == SE_SPLIT - 1;
+        if (s_last) __hip_atomic_store(&counter[f], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = 0.f;
-        for (int h = 0; h < R; ++h) a = fmaf(w2[(long)c * R + h], shid[h], a);
-        gate[(long)f * C + c] = 1.f / (1.f + expf(-a));
-    }
-}
-__global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ pool, const float *__restrict__ w1, const float *__restrict__ w2,
-                                                      int C, int F, int HW, float *__restrict__ gate) {
-    // one block per face
-    extern __shared__ float sh[];  // [C] pooled + [C/16] hidden
-    const int f = blockIdx.x;
-    float *sp = sh, *shid = sh + C;
+    if (!s_last) return;
+    float *sp = red, *shid = red + 512;
     for (int c = threadIdx.x; c < C; c += 256) {
         float t = 0.f;
-        for (int part = 0; part < SE_SPLIT; ++part) t += pool[((long)part * F + f) * C + c];
+        for (int q = 0; q < SE_SPLIT; ++q) t += __hip_atomic_load(&partial[((long)q * F + f) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sp[c] = t / (float)HW;
     }
     __syncthreads();
     se_fc_gate(sp, shid, w1, w2, C, f, gate);
 }
-// (pool + gate fused into one block per face measured 18.6 us against 6.0 + 5.0 us: 128 blocks walking 100 KB each are latency-bound)
 __global__ __launch_bounds__(256) void se_apply_kernel(SeArgs a) {
     // thread = 8 channels of one pixel
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1121,8 +1148,7 @@ void launch_fc_finalize(const float *partial, int splits, int F, const float *bi
 }
 
 void launch_se(const SeArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(se_pool_kernel, dim3(SE_SPLIT, a.F), dim3(256), 0, s, a.res, a.H * a.W, a.C, a.F, a.pool);
-    hipLaunchKernelGGL(se_gate_kernel, dim3(a.F), dim3(256), (a.C + a.C / 16) * sizeof(float), s, a.pool, a.w1, a.w2, a.C, a.F, a.H * a.W, a.gate);
+    hipLaunchKernelGGL(se_pool_gate_kernel, dim3(SE_SPLIT, a.F), dim3(256), 0, s, a.res, a.H * a.W, a.C, a.F, a.pool, a.w1, a.w2, a.gate, a.counter);
     const long total = (long)a.F * a.H * a.W * (a.C / 8);
     hipLaunchKernelGGL(se_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
