@@ -848,7 +848,9 @@ __device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const f
 // Pooling + gate in one launch.  grid (SE_SPLIT, F): every block sums its pixel range per channel; the block that arrives LAST for a
 // face (device-scope counter; the partial sums travel as device-scope stores / loads) adds the SE_SPLIT partial sums in range order and runs the two tiny FC layers - so the result does
 // not depend on which block that is.  (A separate gate kernel cost 5 - 11 us + a dependent launch per unit, 24 units per pass; pool +
-// gate in ONE block per face had measured 18.6 us against 6.0 + 5.0: 128 blocks walking 100 KB each are latency-bound.)
+// gate in ONE block per face had measured 18.6 us against 6.0 + 5.0: 128 blocks walking 100 KB each are latency-bound.  Folding the
+// apply pass in as well - every block waits for its face's gate, then scales its own pixel range - measured 25 us against
+// 10 + 13: the wait costs what the dependent launch did.)
 __global__ __launch_bounds__(256) void se_pool_gate_kernel(const half_t *__restrict__ res, int HW, int C, int F, float *__restrict__ partial,
                                                            const float *__restrict__ w1, const float *__restrict__ w2, float *__restrict__ gate,
                                                            int *__restrict__ counter) {
