@@ -805,6 +805,13 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
                 a.mode = EPI_BN;
                 a.out0 = RES;
             }
+            if (se) {  // the strip kernel's main variant pools + computes the gate in its epilogue (conv_se_fused)
+                a.se_pool = se_pool;
+                a.se_w1 = u.se_w1;
+                a.se_w2 = u.se_w2;
+                a.se_gate = se_gate;
+                a.se_counter = reinterpret_cast<int *>(se_pool + (size_t)max_batch * 512 * 4);
+            }
             {
                 ProfScope pk(1, conv_kernel_label(a), 2.0 * 9 * u.depth * u.depth * (double)F * ho * ho, s);
                 launch_conv_mfma(a, s);
@@ -812,7 +819,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             if (se) {
                 SeArgs sa{RES, u.se_w1, u.se_w2, sc_t, sc_h, sc_h, sc_stride, u.sn, u.bn, Y[cur ^ 1], Z[cur ^ 1], se_pool, se_gate, F, ho, ho, u.depth,
                           reinterpret_cast<int *>(se_pool + (size_t)max_batch * 512 * 4)};
-                launch_se(sa, s);
+                launch_se(sa, s, conv_se_fused(a));
             }
         }
         cur ^= 1;

@@ -169,7 +169,14 @@ struct ConvMfmaArgs {
     float *outf;       // EPI_PARTIAL: [splits][M][Cout]
     int splits;
     const half_t *zeros;  // >= 16 bytes of zeros (source of padded taps for the LDS-DMA path)
+    // IR-SE, conv2 of a unit (mode EPI_BN): when set and conv_se_fused(args), the launch also pools its output per (face, channel) and
+    // leaves the SE gate in se_gate (scratch as in SeArgs: pool [4][B][Cout], counter [B] zero between launches)
+    float *se_pool;
+    const float *se_w1, *se_w2;
+    float *se_gate;
+    int *se_counter;
 };
+bool conv_se_fused(const ConvMfmaArgs &a);
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
 bool conv_s2_applies(const ConvMfmaArgs &a);                // kernels_arc_s2.hip: 3x3 stride 2, Cout % 128 == 0 or 64 -> 64 at 112 -> 56
 bool launch_conv_s2(const ConvMfmaArgs &a, hipStream_t s);
@@ -205,4 +212,4 @@ struct SeArgs {
     int F, H, W, C;
     int *counter;        // [F] arrival counters of the pooling pass, zero between launches
 };
-void launch_se(const SeArgs &a, hipStream_t s);
+void launch_se(const SeArgs &a, hipStream_t s, bool gate_ready = false);  // gate_ready: the conv launch computed the gate (conv_se_fused)

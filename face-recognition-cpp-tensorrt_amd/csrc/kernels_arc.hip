@@ -437,6 +437,48 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvMfmaArgs p) {
     }
 }
 
+constexpr int SE_SPLIT = 4;  // pixel ranges per face (partial sums, summed in fixed order: deterministic)
+// fc1 -> ReLU -> fc2 -> sigmoid on the pooled vector sp[C] (LDS), 256 threads.  Both layers are a few thousand MACs: what costs is
+// the dependent chain, so every hidden unit gets 256 / R threads that each take a contiguous run of channels (all loads of a thread
+// are independent 16-byte loads in flight at once), then a fixed-order shuffle reduction; the output layer is a thread per channel
+// with its R weights as float4 loads.  (A wave per hidden unit walking the channels and a scalar loop over R: 5 - 11 us per call.)
+__device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const float *__restrict__ w1, const float *__restrict__ w2, int C, int f,
+                                           float *__restrict__ gate) {
+    const int R = C / 16;            // hidden units: 4 .. 32
+    const int G = 256 / R;           // threads per hidden unit: 64 .. 8 (a power of two, inside one wave)
+    const int per = C / G;           // channels per thread: 1, 4, 16, 64
+    const int h = threadIdx.x / G, g = threadIdx.x % G;
+    float a = 0.f;
+    if (per == 1) {
+        a = w1[(long)h * C + g] * sp[g];
+    } else {
+        const float *wp = w1 + (long)h * C + g * per;
+        const float *xp = sp + g * per;
+        for (int i = 0; i < per; i += 4) {
+            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
+            a = fmaf(w[0], xp[i], a);
+            a = fmaf(w[1], xp[i + 1], a);
+            a = fmaf(w[2], xp[i + 2], a);
+            a = fmaf(w[3], xp[i + 3], a);
+        }
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if (g == 0) shid[h] = fmaxf(a, 0.f);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float *wp = w2 + (long)c * R;
+        float o = 0.f;
+        for (int i = 0; i < R; i += 4) {
+            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
+            o = fmaf(w[0], shid[i], o);
+            o = fmaf(w[1], shid[i + 1], o);
+            o = fmaf(w[2], shid[i + 2], o);
+            o = fmaf(w[3], shid[i + 3], o);
+        }
+        gate[(long)f * C + c] = 1.f / (1.f + expf(-o));
+    }
+}
+
 // ---------------------------------------------------------------- v3: LDS-resident halo patch ("strip") kernel, 3x3 / stride 1 / pad 1
 // The im2col kernels above move every input pixel through the L2->LDS path 9 times (once per tap); the v2 ablation showed that
 // path, not the matrix pipe, bounds them (DMA-only 45 us vs MFMA-only 37 us on the 14x14 layers).  Here a workgroup owns a
@@ -454,7 +496,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvMfmaArgs p) {
 // PAIR (Cout == 64, Cin == 64): one workgroup handles TWO strips; waves (0,1) own the first, waves (2,3) the second, each wave
 // one 32-cout fragment of its strip.  Each half stages its own patch (128 threads per patch image); the whole K loop (9 taps)
 // runs on that single resident patch.
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7, int BFD = 2, int WR = 3>  // WR: weight register ring depth in steps (3 or 9); NT pixel tiles per strip; PPS patch DMA pieces per thread per step during taps 0..PT-1; BFD: depth (kk-slots) of the B fragment ring
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7, int BFD = 2, int WR = 3, bool SEP = false>  // SEP: SE pooling + gate in the epilogue (below); WR: weight register ring depth in steps (3 or 9); NT pixel tiles per strip; PPS patch DMA pieces per thread per step during taps 0..PT-1; BFD: depth (kk-slots) of the B fragment ring
 __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
     // linear != 0: pixel slots are enumerated over the PADDED row width (slot == patch row of tap (0,0), slots in the two halo
     // columns are dead).  The 32 lanes of a fragment read then touch 32 consecutive patch rows -> no LDS bank conflicts; the
@@ -669,6 +711,7 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
         m = m0 + sl;
         return strip_ok && sl < n_valid && m < Mtot;
     };
+    float se_sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (SEP) this lane's channel sums over its pixels
     half8 sc8[NT][2];
     if (p.mode == EPI_BN_ADD_BN) {  // stride 1: the shortcut has the output's geometry; all 14 loads in flight before the transposes
 #pragma unroll
@@ -712,6 +755,10 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
             *reinterpret_cast<half8 *>(p.out0 + m * p.Cout + cch) = o;
+            if constexpr (SEP) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) se_sum[e] += (float)o[e];  // the pooled value is the mean of the STORED (fp16) activations
+            }
             if (p.mode == EPI_BN_ADD_BN && p.out1) {
                 half8 z;
 #pragma unroll
@@ -719,6 +766,42 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
                 *reinterpret_cast<half8 *>(p.out1 + m * p.Cout + cch) = z;
             }
         }
+    }
+    if constexpr (SEP) {
+        // IR-SE (model_irse.py:22-45): the strip is a range of rows of ONE image (n_img == 1), so this workgroup holds, per channel of its
+        // cout tile, the sum over its pixels - the SE pooling pass for free.  Partial sums go to pool[strip of the image][face][channel]
+        // as device-scope stores; the workgroup that arrives LAST for the face (counter) adds them in strip order - the result does not
+        // depend on which one that is - and runs the two small FC layers.  Only the apply pass is left as a separate launch.
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) se_sum[e] += __shfl_xor(se_sum[e], off);
+        const int part = strip % strips_per_img;
+        if ((lane >> 2) == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                __hip_atomic_store(&p.se_pool[((long)part * p.B + img0) * p.Cout + cch + e], se_sum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before the arrival is announced (no device-scope fence: see se_pool_gate_kernel)
+        __syncthreads();
+        int *flag_l = reinterpret_cast<int *>(smem + 4 * 32 * EROW * 4);
+        if (tid == 0) {
+            const int expect = strips_per_img * n_co_tiles;
+            const int prev = __hip_atomic_fetch_add(&p.se_counter[img0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag_l = prev == expect - 1;
+            if (prev == expect - 1) __hip_atomic_store(&p.se_counter[img0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!*flag_l) return;
+        float *sp = reinterpret_cast<float *>(smem + 4 * 32 * EROW * 4 + 64), *shid = sp + 512;
+        for (int c = tid; c < p.Cout; c += 256) {
+            float t = 0.f;
+            for (int q = 0; q < strips_per_img; ++q)
+                t += __hip_atomic_load(&p.se_pool[((long)q * p.B + img0) * p.Cout + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sp[c] = t / (float)(H * W);
+        }
+        __syncthreads();
+        se_fc_gate(sp, shid, p.se_w1, p.se_w2, p.Cout, img0, p.se_gate);
     }
 }
 
@@ -804,47 +887,6 @@ __global__ __launch_bounds__(512) void fc_finalize_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------- SE tail (IR-SE): model_irse.py:22-45
-constexpr int SE_SPLIT = 4;  // pixel ranges per face (partial sums, summed in fixed order: deterministic)
-// fc1 -> ReLU -> fc2 -> sigmoid on the pooled vector sp[C] (LDS), 256 threads.  Both layers are a few thousand MACs: what costs is
-// the dependent chain, so every hidden unit gets 256 / R threads that each take a contiguous run of channels (all loads of a thread
-// are independent 16-byte loads in flight at once), then a fixed-order shuffle reduction; the output layer is a thread per channel
-// with its R weights as float4 loads.  (A wave per hidden unit walking the channels and a scalar loop over R: 5 - 11 us per call.)
-__device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const float *__restrict__ w1, const float *__restrict__ w2, int C, int f,
-                                           float *__restrict__ gate) {
-    const int R = C / 16;            // hidden units: 4 .. 32
-    const int G = 256 / R;           // threads per hidden unit: 64 .. 8 (a power of two, inside one wave)
-    const int per = C / G;           // channels per thread: 1, 4, 16, 64
-    const int h = threadIdx.x / G, g = threadIdx.x % G;
-    float a = 0.f;
-    if (per == 1) {
-        a = w1[(long)h * C + g] * sp[g];
-    } else {
-        const float *wp = w1 + (long)h * C + g * per;
-        const float *xp = sp + g * per;
-        for (int i = 0; i < per; i += 4) {
-            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
-            a = fmaf(w[0], xp[i], a);
-            a = fmaf(w[1], xp[i + 1], a);
-            a = fmaf(w[2], xp[i + 2], a);
-            a = fmaf(w[3], xp[i + 3], a);
-        }
-    }
-    for (int off = G >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off);
-    if (g == 0) shid[h] = fmaxf(a, 0.f);
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float *wp = w2 + (long)c * R;
-        float o = 0.f;
-        for (int i = 0; i < R; i += 4) {
-            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
-            o = fmaf(w[0], shid[i], o);
-            o = fmaf(w[1], shid[i + 1], o);
-            o = fmaf(w[2], shid[i + 2], o);
-            o = fmaf(w[3], shid[i + 3], o);
-        }
-        gate[(long)f * C + c] = 1.f / (1.f + expf(-o));
-    }
-}
 // Pooling + gate in one launch.  grid (SE_SPLIT, F): every block sums its pixel range per channel; the block that arrives LAST for a
 // face (device-scope counter; the partial sums travel as device-scope stores / loads) adds the SE_SPLIT partial sums in range order and runs the two tiny FC layers - so the result does
 // not depend on which block that is.  (A separate gate kernel cost 5 - 11 us + a dependent launch per unit, 24 units per pass; pool +
@@ -1016,19 +1058,19 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     return true;
 }
 
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7, int BFD = 2, int WR = 3>
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7, int BFD = 2, int WR = 3, bool SEP = false>
 void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
     const size_t lds = PAIR ? (size_t)2 * 34 * 2048 : (size_t)(SINGLE ? 1 : 2) * PT * PPS * 4096;  // patch buffers only (weights live in registers)
     static_assert(PAIR || ((SINGLE ? 1 : 2) * PT * PPS * 4096 <= 160 * 1024 && PT * PPS * 4096 >= 4 * 32 * 36 * 4), "LDS budget / epilogue scratch");
     static bool attr_done[FRT_MAX_DEVICES] = {};
     if (frt_first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     }
     const int strips = ((a.B + n_img - 1) / n_img) * (a.H / R);
     dim3 grid(PAIR ? (strips + 1) / 2 : strips * (a.Cout / 128));
     const int linear = (n_img == 1 && R * (a.W + 2) <= NT * 32) ? 1 : 0;
-    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR>), grid, dim3(256), lds, s, a, R, n_img, linear);
+    hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR, SEP>), grid, dim3(256), lds, s, a, R, n_img, linear);
 }
 
 int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage (default: 64 KB ring, 2 workgroups per CU), 3 = LDS-DMA 3-stage
@@ -1077,6 +1119,14 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
     return names[conv_variant(a, R, n_img)];
 }
 
+// IR-SE: does the launch of `a` (conv2 of a unit, EPI_BN, se_* set) leave the gate in a.se_gate?  (Only the strip kernel's main variant
+// with row-range strips of single images does; everything else needs launch_se's pooling pass.)
+bool conv_se_fused(const ConvMfmaArgs &a) {
+    if (!a.se_pool || a.mode != EPI_BN || conv64_applies(a) || conv_s2_applies(a)) return false;
+    int R = 0, n_img = 0;
+    return conv_variant(a, R, n_img) == CV_P_255 && n_img == 1 && a.H / R <= SE_SPLIT;
+}
+
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
     if (launch_conv64(a, s)) return;  // dedicated 64 -> 64 stride-1 kernel (kernels_arc_c64.hip)
     if (launch_conv_s2(a, s)) return;  // stride-2 strip kernel on de-interleaved phase planes (kernels_arc_s2.hip)
@@ -1110,6 +1160,8 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 24) return launch_patch_t<10, 1, 5, false, 4, false, 7, 1>(a, R, n_img, s);
             if (abl == 29) return launch_patch_t<10, 1, 5, false, 9, false, 7, 1>(a, R, n_img, s);
 #endif
+            if (a.se_pool && a.mode == EPI_BN && n_img == 1 && a.H / R <= SE_SPLIT)  // IR-SE conv2: pooling + gate in the epilogue
+                return launch_patch_t<10, 1, 5, false, 0, false, 7, 1, 3, true>(a, R, n_img, s);
             return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
         case CV_P_255_NT4:
@@ -1149,8 +1201,9 @@ void launch_fc_finalize(const float *partial, int splits, int F, const float *bi
     hipLaunchKernelGGL(fc_finalize_kernel, dim3(F), dim3(512), 0, st, partial, splits, F, bias, s, b, valid, out);
 }
 
-void launch_se(const SeArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(se_pool_gate_kernel, dim3(SE_SPLIT, a.F), dim3(256), 0, s, a.res, a.H * a.W, a.C, a.F, a.pool, a.w1, a.w2, a.gate, a.counter);
+void launch_se(const SeArgs &a, hipStream_t s, bool gate_ready) {
+    if (!gate_ready)  // (the conv2 launch already pooled and computed the gate: conv_se_fused)
+        hipLaunchKernelGGL(se_pool_gate_kernel, dim3(SE_SPLIT, a.F), dim3(256), 0, s, a.res, a.H * a.W, a.C, a.F, a.pool, a.w1, a.w2, a.gate, a.counter);
     const long total = (long)a.F * a.H * a.W * (a.C / 8);
     hipLaunchKernelGGL(se_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
