@@ -535,6 +535,7 @@ struct frt_embedder {
     float *d_in = nullptr;  // [max_batch][3][112][112]
     half_t *Y[2], *Z[2], *T, *SC, *RES = nullptr, *zeros = nullptr;
     float *fc_partial, *d_out, *se_pool = nullptr, *se_gate = nullptr;
+    int se_epoch = 0;  // launch counter of the fused SE tails (their gate-ready flags carry the launch number)
     uint8_t *d_crops = nullptr;
     int *d_valid = nullptr;
     frt_bbox *d_boxes = nullptr;
@@ -703,8 +704,8 @@ void frt_embedder::build(const frt::Blob &b) {
     SC = arena.alloc<half_t>(F * 28 * 28 * 128);  // largest conv-shortcut output (56->28, 128 ch)
     if (se) {
         RES = arena.alloc<half_t>(F * 56 * 56 * 64);
-        se_pool = arena.alloc<float>(F * 512 * 4 + F);  // SE_SPLIT partial sums per (face, channel) + the per-face arrival counters
-        HIPCHK(hipMemset(se_pool + F * 512 * 4, 0, F * sizeof(int)));  // (kept at zero between launches by the kernel)
+        se_pool = arena.alloc<float>(F * 512 * 4 + 2 * F);  // SE_SPLIT partial sums per (face, channel) + per-face arrival counters + gate-ready flags
+        HIPCHK(hipMemset(se_pool + F * 512 * 4, 0, 2 * F * sizeof(int)));  // (kept at zero between launches by the kernel)
         se_gate = arena.alloc<float>(F * 512);
     }
     fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);
@@ -731,8 +732,8 @@ void frt_embedder::ensure_alt() {
     alt.se_pool = alt.se_gate = nullptr;
     if (se) {
         alt.RES = arena.alloc<half_t>(F * 56 * 56 * 64);
-        alt.se_pool = arena.alloc<float>(F * 512 * 4 + F);
-        HIPCHK(hipMemset(alt.se_pool + F * 512 * 4, 0, F * sizeof(int)));
+        alt.se_pool = arena.alloc<float>(F * 512 * 4 + 2 * F);
+        HIPCHK(hipMemset(alt.se_pool + F * 512 * 4, 0, 2 * F * sizeof(int)));
         alt.se_gate = arena.alloc<float>(F * 512);
     }
     alt.fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);
@@ -793,33 +794,45 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             a.p1 = u.b2;
             a.splits = 1;
             a.zeros = zeros;
-            if (!se) {
-                a.mode = EPI_BN_ADD_BN;
-                a.p2 = u.sn;
-                a.p3 = u.bn;
-                a.sc = sc_t;
-                a.sc_h = sc_h; a.sc_w = sc_h; a.sc_stride = sc_stride;
-                a.out0 = Y[cur ^ 1];
-                a.out1 = Z[cur ^ 1];
-            } else {
-                a.mode = EPI_BN;
-                a.out0 = RES;
-            }
-            if (se) {  // the strip kernel's main variant pools + computes the gate in its epilogue (conv_se_fused)
+            a.mode = EPI_BN_ADD_BN;
+            a.p2 = u.sn;
+            a.p3 = u.bn;
+            a.sc = sc_t;
+            a.sc_h = sc_h; a.sc_w = sc_h; a.sc_stride = sc_stride;
+            a.out0 = Y[cur ^ 1];
+            a.out1 = Z[cur ^ 1];
+            bool se_tail = false;  // IR-SE: the SE tail as separate launches behind conv2
+            if (se) {
+                int *cnt = reinterpret_cast<int *>(se_pool + (size_t)max_batch * 512 * 4);
                 a.se_pool = se_pool;
                 a.se_w1 = u.se_w1;
                 a.se_w2 = u.se_w2;
-                a.se_gate = se_gate;
-                a.se_counter = reinterpret_cast<int *>(se_pool + (size_t)max_batch * 512 * 4);
+                a.se_counter = cnt;
+                a.se_flag_off = max_batch;
+                if (conv_se_fused(a)) {  // the strip kernel runs the whole tail in its epilogue
+                    if (se_epoch >= (1 << 30)) {  // the flags carry launch numbers: start over with clean flags (both scratch sets)
+                        HIPCHK(hipMemsetAsync(cnt + max_batch, 0, (size_t)max_batch * sizeof(int), s));
+                        if (has_alt) HIPCHK(hipMemsetAsync(reinterpret_cast<int *>(alt.se_pool + (size_t)max_batch * 512 * 4) + max_batch, 0, (size_t)max_batch * sizeof(int), s));
+                        se_epoch = 0;
+                    }
+                    a.se_epoch = ++se_epoch;
+                    a.mode = EPI_BN_SE;
+                } else {
+                    a.mode = EPI_BN;
+                    a.out0 = RES;
+                    a.out1 = nullptr;
+                    a.sc = nullptr;
+                    se_tail = true;
+                }
             }
             {
                 ProfScope pk(1, conv_kernel_label(a), 2.0 * 9 * u.depth * u.depth * (double)F * ho * ho, s);
                 launch_conv_mfma(a, s);
             }
-            if (se) {
+            if (se_tail) {
                 SeArgs sa{RES, u.se_w1, u.se_w2, sc_t, sc_h, sc_h, sc_stride, u.sn, u.bn, Y[cur ^ 1], Z[cur ^ 1], se_pool, se_gate, F, ho, ho, u.depth,
                           reinterpret_cast<int *>(se_pool + (size_t)max_batch * 512 * 4)};
-                launch_se(sa, s, conv_se_fused(a));
+                launch_se(sa, s);
             }
         }
         cur ^= 1;

@@ -154,7 +154,7 @@ void launch_heads(const HeadArgs &a, hipStream_t s);
 void launch_heads_multi(const HeadArgs *a, int n, hipStream_t s);
 
 // ---------------------------------------------------------------- recogniser network (kernels_arc.hip), fp16 NHWC + MFMA
-enum { EPI_PRELU = 0, EPI_BN = 1, EPI_BN_ADD_BN = 2, EPI_PARTIAL = 3 };
+enum { EPI_PRELU = 0, EPI_BN = 1, EPI_BN_ADD_BN = 2, EPI_PARTIAL = 3, EPI_BN_SE = 4 };  // EPI_BN_SE: BN -> SE gate -> + shortcut -> BN_next (IR-SE unit tail)
 struct ConvMfmaArgs {
     const half_t *x;   // [B][H][W][Cin]
     const half_t *w;   // [Cout][ks*ks*Cin]
@@ -169,14 +169,15 @@ struct ConvMfmaArgs {
     float *outf;       // EPI_PARTIAL: [splits][M][Cout]
     int splits;
     const half_t *zeros;  // >= 16 bytes of zeros (source of padded taps for the LDS-DMA path)
-    // IR-SE, conv2 of a unit (mode EPI_BN): when set and conv_se_fused(args), the launch also pools its output per (face, channel) and
-    // leaves the SE gate in se_gate (scratch as in SeArgs: pool [4][B][Cout], counter [B] zero between launches)
-    float *se_pool;
+    // IR-SE unit tail inside conv2's epilogue (mode EPI_BN_SE; only when conv_se_fused(args) - the strip kernel's main variant): y (out0) =
+    // BN(conv) * gate + sc, z (out1) = y * p2 + p3, gate from the image-wide channel means through fc1 [C/16][C] / fc2 [C][C/16].
+    float *se_pool;      // scratch [4][B][Cout] partial channel sums
     const float *se_w1, *se_w2;
-    float *se_gate;
-    int *se_counter;
+    int *se_counter;     // [>= B] arrival counters, zero between launches; the gate-ready flags sit se_flag_off ints behind
+    int se_flag_off;
+    int se_epoch;        // launch number (> 0, different from every earlier launch's on this scratch): what the flags are set to
 };
-bool conv_se_fused(const ConvMfmaArgs &a);
+bool conv_se_fused(const ConvMfmaArgs &a);  // a: the unit's conv2 described as EPI_BN_ADD_BN + the se_* scratch
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
 bool conv_s2_applies(const ConvMfmaArgs &a);                // kernels_arc_s2.hip: 3x3 stride 2, Cout % 128 == 0 or 64 -> 64 at 112 -> 56
 bool launch_conv_s2(const ConvMfmaArgs &a, hipStream_t s);
@@ -212,4 +213,4 @@ struct SeArgs {
     int F, H, W, C;
     int *counter;        // [F] arrival counters of the pooling pass, zero between launches
 };
-void launch_se(const SeArgs &a, hipStream_t s, bool gate_ready = false);  // gate_ready: the conv launch computed the gate (conv_se_fused)
+void launch_se(const SeArgs &a, hipStream_t s);

@@ -442,8 +442,7 @@ constexpr int SE_SPLIT = 4;  // pixel ranges per face (partial sums, summed in f
 // the dependent chain, so every hidden unit gets 256 / R threads that each take a contiguous run of channels (all loads of a thread
 // are independent 16-byte loads in flight at once), then a fixed-order shuffle reduction; the output layer is a thread per channel
 // with its R weights as float4 loads.  (A wave per hidden unit walking the channels and a scalar loop over R: 5 - 11 us per call.)
-__device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const float *__restrict__ w1, const float *__restrict__ w2, int C, int f,
-                                           float *__restrict__ gate) {
+__device__ __forceinline__ void se_fc1(const float *sp, float *shid, const float *__restrict__ w1, int C) {  // 256 threads; caller syncs afterwards
     const int R = C / 16;            // hidden units: 4 .. 32
     const int G = 256 / R;           // threads per hidden unit: 64 .. 8 (a power of two, inside one wave)
     const int per = C / G;           // channels per thread: 1, 4, 16, 64
@@ -464,19 +463,25 @@ __device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const f
     }
     for (int off = G >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off);
     if (g == 0) shid[h] = fmaxf(a, 0.f);
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float *wp = w2 + (long)c * R;
-        float o = 0.f;
-        for (int i = 0; i < R; i += 4) {
-            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
-            o = fmaf(w[0], shid[i], o);
-            o = fmaf(w[1], shid[i + 1], o);
-            o = fmaf(w[2], shid[i + 2], o);
-            o = fmaf(w[3], shid[i + 3], o);
-        }
-        gate[(long)f * C + c] = 1.f / (1.f + expf(-o));
+}
+__device__ __forceinline__ float se_fc2(const float *shid, const float *__restrict__ w2, int C, int c) {  // gate of channel c
+    const int R = C / 16;
+    const float *wp = w2 + (long)c * R;
+    float o = 0.f;
+    for (int i = 0; i < R; i += 4) {
+        const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
+        o = fmaf(w[0], shid[i], o);
+        o = fmaf(w[1], shid[i + 1], o);
+        o = fmaf(w[2], shid[i + 2], o);
+        o = fmaf(w[3], shid[i + 3], o);
     }
+    return 1.f / (1.f + expf(-o));
+}
+__device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const float *__restrict__ w1, const float *__restrict__ w2, int C, int f,
+                                           float *__restrict__ gate) {
+    se_fc1(sp, shid, w1, C);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) gate[(long)f * C + c] = se_fc2(shid, w2, C, c);
 }
 
 // ---------------------------------------------------------------- v3: LDS-resident halo patch ("strip") kernel, 3x3 / stride 1 / pad 1
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
         q1[0] = *reinterpret_cast<const floatx4 *>(p.p1 + cch);
         q1[1] = *reinterpret_cast<const floatx4 *>(p.p1 + cch + 4);
     }
-    if (p.mode == EPI_BN_ADD_BN && p.out1) {
+    if (p.mode == EPI_BN_ADD_BN && p.out1 && !SEP) {
         q2[0] = *reinterpret_cast<const floatx4 *>(p.p2 + cch);
         q2[1] = *reinterpret_cast<const floatx4 *>(p.p2 + cch + 4);
         q3[0] = *reinterpret_cast<const floatx4 *>(p.p3 + cch);
@@ -711,7 +716,128 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
         m = m0 + sl;
         return strip_ok && sl < n_valid && m < Mtot;
     };
-    float se_sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (SEP) this lane's channel sums over its pixels
+    if constexpr (SEP) {
+        // IR-SE unit tail (model_irse.py:22-45, 58-66) inside conv2's epilogue: y = BN(conv2) * gate + shortcut, z = BN_next(y), where
+        // gate = sigmoid(fc2(relu(fc1(mean over the image of BN(conv2))))) needs the WHOLE image and all channels.  The strip is a range of
+        // rows of ONE image (n_img == 1) and the accumulators stay in registers, so:
+        //   pass 1  transposes the accumulators once just to sum the (fp16-rounded, as the stand-alone path stores them) BN outputs per
+        //           channel; the partial sums go to pool[strip of the image][face][channel] as device-scope stores;
+        //   meet    the workgroups of the face (strips x cout tiles; adjacent in launch order) count themselves in; the last one resets
+        //           the counter and publishes the launch number in the face's flag, everybody waits for it (bounded spin);
+        //   gate    every workgroup adds the partial sums in strip order and runs fc1 and its 128 channels of fc2 itself (a few
+        //           thousand MACs: cheaper than another hand-over);
+        //   pass 2  transposes again and writes y and z - exactly se_apply_kernel's arithmetic, without the res tensor's round trip,
+        //           the pooling pass and the apply pass (10 + 13 us and two dependent launches per unit before).
+        // No device-scope fence anywhere (see se_pool_gate_kernel); nothing a workgroup waits for depends on a workgroup that is
+        // dispatched more than (strips x cout tiles - 1) x 8 block indices later, so the wait cannot starve the launch.
+        float se_sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = v;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int px = (lane >> 2) + 16 * it;
+                const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
+                const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
+                long m;
+                if (!slot_pixel(j * 32 + px, m)) continue;
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) se_sum[e] += (float)(half_t)(v[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) se_sum[e] += __shfl_xor(se_sum[e], off);
+        const int part = strip % strips_per_img;
+        if ((lane >> 2) == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                __hip_atomic_store(&p.se_pool[((long)part * p.B + img0) * p.Cout + cch + e], se_sum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before the arrival is announced
+        __syncthreads();
+        if (tid == 0) {
+            const int expect = strips_per_img * n_co_tiles;
+            int *flag = p.se_counter + p.se_flag_off;
+            const int prev = __hip_atomic_fetch_add(&p.se_counter[img0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == expect - 1) {
+                __hip_atomic_store(&p.se_counter[img0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&flag[img0], p.se_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (int spin = 0; spin < (1 << 22); ++spin) {
+                    if (__hip_atomic_load(&flag[img0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.se_epoch) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        }
+        __syncthreads();
+        // the first tile's shortcut values are requested here and land under the gate arithmetic
+        auto load_sc = [&](int j, half8 (&dst)[2]) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                long m;
+                const bool ok = slot_pixel(j * 32 + (lane >> 2) + 16 * it, m);
+                dst[it] = *reinterpret_cast<const half8 *>(p.sc + (ok ? m : 0) * p.Cout + cch);
+            }
+        };
+        half8 scs[2][2];  // shortcut values one pixel tile ahead (all 7 tiles at once: 56 live registers, spills)
+        load_sc(0, scs[0]);
+        float *sp = reinterpret_cast<float *>(smem + 4 * 32 * EROW * 4), *shid = sp + 512, *sgate = sp + 576;
+        const int C = p.Cout;
+        for (int c = tid; c < C; c += 256) {
+            float t = 0.f;
+            for (int q = 0; q < strips_per_img; ++q)
+                t += __hip_atomic_load(&p.se_pool[((long)q * p.B + img0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sp[c] = t / (float)(H * W);
+        }
+        __syncthreads();
+        se_fc1(sp, shid, p.se_w1, C);
+        __syncthreads();
+        if (tid < 128) sgate[tid] = se_fc2(shid, p.se_w2, C, co_base + tid);
+        __syncthreads();
+        q2[0] = *reinterpret_cast<const floatx4 *>(p.p2 + cch);  // (only needed from here on)
+        q2[1] = *reinterpret_cast<const floatx4 *>(p.p2 + cch + 4);
+        q3[0] = *reinterpret_cast<const floatx4 *>(p.p3 + cch);
+        q3[1] = *reinterpret_cast<const floatx4 *>(p.p3 + cch + 4);
+        float g8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g8[e] = sgate[cow + chunk * 8 + e];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j + 1 < NT) load_sc(j + 1, scs[(j + 1) & 1]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = v;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int px = (lane >> 2) + 16 * it;
+                const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
+                const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
+                long m;
+                if (!slot_pixel(j * 32 + px, m)) continue;
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                half8 y8, z8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float res = (float)(half_t)(v[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3]);
+                    const float y = res * g8[e] + (float)scs[j & 1][it][e];
+                    y8[e] = (half_t)y;
+                    z8[e] = (half_t)(y * q2[e >> 2][e & 3] + q3[e >> 2][e & 3]);
+                }
+                *reinterpret_cast<half8 *>(p.out0 + m * C + cch) = y8;
+                *reinterpret_cast<half8 *>(p.out1 + m * C + cch) = z8;
+            }
+        }
+        return;
+    }
     half8 sc8[NT][2];
     if (p.mode == EPI_BN_ADD_BN) {  // stride 1: the shortcut has the output's geometry; all 14 loads in flight before the transposes
 #pragma unroll
@@ -755,10 +881,6 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
             *reinterpret_cast<half8 *>(p.out0 + m * p.Cout + cch) = o;
-            if constexpr (SEP) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) se_sum[e] += (float)o[e];  // the pooled value is the mean of the STORED (fp16) activations
-            }
             if (p.mode == EPI_BN_ADD_BN && p.out1) {
                 half8 z;
 #pragma unroll
@@ -766,42 +888,6 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
                 *reinterpret_cast<half8 *>(p.out1 + m * p.Cout + cch) = z;
             }
         }
-    }
-    if constexpr (SEP) {
-        // IR-SE (model_irse.py:22-45): the strip is a range of rows of ONE image (n_img == 1), so this workgroup holds, per channel of its
-        // cout tile, the sum over its pixels - the SE pooling pass for free.  Partial sums go to pool[strip of the image][face][channel]
-        // as device-scope stores; the workgroup that arrives LAST for the face (counter) adds them in strip order - the result does not
-        // depend on which one that is - and runs the two small FC layers.  Only the apply pass is left as a separate launch.
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) se_sum[e] += __shfl_xor(se_sum[e], off);
-        const int part = strip % strips_per_img;
-        if ((lane >> 2) == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                __hip_atomic_store(&p.se_pool[((long)part * p.B + img0) * p.Cout + cch + e], se_sum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before the arrival is announced (no device-scope fence: see se_pool_gate_kernel)
-        __syncthreads();
-        int *flag_l = reinterpret_cast<int *>(smem + 4 * 32 * EROW * 4);
-        if (tid == 0) {
-            const int expect = strips_per_img * n_co_tiles;
-            const int prev = __hip_atomic_fetch_add(&p.se_counter[img0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag_l = prev == expect - 1;
-            if (prev == expect - 1) __hip_atomic_store(&p.se_counter[img0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (!*flag_l) return;
-        float *sp = reinterpret_cast<float *>(smem + 4 * 32 * EROW * 4 + 64), *shid = sp + 512;
-        for (int c = tid; c < p.Cout; c += 256) {
-            float t = 0.f;
-            for (int q = 0; q < strips_per_img; ++q)
-                t += __hip_atomic_load(&p.se_pool[((long)q * p.B + img0) * p.Cout + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sp[c] = t / (float)(H * W);
-        }
-        __syncthreads();
-        se_fc_gate(sp, shid, p.se_w1, p.se_w2, p.Cout, img0, p.se_gate);
     }
 }
 
@@ -1007,7 +1093,7 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     if (!a.wf) return false;  // the strip kernel streams the fragment-ordered weight copy
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || (a.Cout % 128 && !pair) || a.Cin % 64 || a.splits != 1 || a.H != a.W) return false;
     if (a.mode == EPI_PARTIAL) return false;
-    if (a.mode == EPI_BN_ADD_BN && !(a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
+    if ((a.mode == EPI_BN_ADD_BN || a.mode == EPI_BN_SE) && !(a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
     single = a.Cin == 64;
     const int co_tiles = pair ? 1 : a.Cout / 128;
     static const bool small_ok = !(frt_tuning_env("FRT_CONV_SMALL_BATCH") && frt_tuning_env("FRT_CONV_SMALL_BATCH")[0] == '0');
@@ -1119,10 +1205,13 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
     return names[conv_variant(a, R, n_img)];
 }
 
-// IR-SE: does the launch of `a` (conv2 of a unit, EPI_BN, se_* set) leave the gate in a.se_gate?  (Only the strip kernel's main variant
-// with row-range strips of single images does; everything else needs launch_se's pooling pass.)
-bool conv_se_fused(const ConvMfmaArgs &a) {
-    if (!a.se_pool || a.mode != EPI_BN || conv64_applies(a) || conv_s2_applies(a)) return false;
+// IR-SE: can the launch of `a` (conv2 of a unit described as EPI_BN_ADD_BN, se_* scratch set) run the whole SE tail in its epilogue
+// (mode EPI_BN_SE)?  Only the strip kernel's main variant with row-range strips of single images can; everything else writes the BN
+// output and leaves the tail to launch_se.
+bool conv_se_fused(const ConvMfmaArgs &a0) {
+    ConvMfmaArgs a = a0;
+    a.mode = EPI_BN_ADD_BN;  // same eligibility as the plain unit tail (shortcut with the output's geometry)
+    if (!a.se_pool || !a.sc || !a.out1 || conv64_applies(a) || conv_s2_applies(a)) return false;
     int R = 0, n_img = 0;
     return conv_variant(a, R, n_img) == CV_P_255 && n_img == 1 && a.H / R <= SE_SPLIT;
 }
@@ -1160,7 +1249,7 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             if (abl == 24) return launch_patch_t<10, 1, 5, false, 4, false, 7, 1>(a, R, n_img, s);
             if (abl == 29) return launch_patch_t<10, 1, 5, false, 9, false, 7, 1>(a, R, n_img, s);
 #endif
-            if (a.se_pool && a.mode == EPI_BN && n_img == 1 && a.H / R <= SE_SPLIT)  // IR-SE conv2: pooling + gate in the epilogue
+            if (a.mode == EPI_BN_SE)  // IR-SE conv2 with the whole SE tail in the epilogue (the caller checked conv_se_fused)
                 return launch_patch_t<10, 1, 5, false, 0, false, 7, 1, 3, true>(a, R, n_img, s);
             return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
@@ -1201,9 +1290,8 @@ void launch_fc_finalize(const float *partial, int splits, int F, const float *bi
     hipLaunchKernelGGL(fc_finalize_kernel, dim3(F), dim3(512), 0, st, partial, splits, F, bias, s, b, valid, out);
 }
 
-void launch_se(const SeArgs &a, hipStream_t s, bool gate_ready) {
-    if (!gate_ready)  // (the conv2 launch already pooled and computed the gate: conv_se_fused)
-        hipLaunchKernelGGL(se_pool_gate_kernel, dim3(SE_SPLIT, a.F), dim3(256), 0, s, a.res, a.H * a.W, a.C, a.F, a.pool, a.w1, a.w2, a.gate, a.counter);
+void launch_se(const SeArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(se_pool_gate_kernel, dim3(SE_SPLIT, a.F), dim3(256), 0, s, a.res, a.H * a.W, a.C, a.F, a.pool, a.w1, a.w2, a.gate, a.counter);
     const long total = (long)a.F * a.H * a.W * (a.C / 8);
     hipLaunchKernelGGL(se_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
