@@ -770,9 +770,10 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
                 __hip_atomic_store(&p.se_counter[img0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&flag[img0], p.se_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                for (int spin = 0; spin < (1 << 22); ++spin) {
-                    if (__hip_atomic_load(&flag[img0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.se_epoch) break;
+                int spin = 0;
+                while (__hip_atomic_load(&flag[img0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.se_epoch) {
                     __builtin_amdgcn_s_sleep(1);
+                    if (++spin > (1 << 25)) __builtin_trap();  // seconds: the hand-over is broken - fail the launch loudly, never continue on a stale gate
                 }
             }
         }
