@@ -443,7 +443,8 @@ bool s2c64_applies(const ConvMfmaArgs &a) {
     if (a.Ho * 2 != a.H || a.Wo * 2 != a.W || a.Wo != 56 || a.Ho != 56) return false;
     if (a.mode != EPI_BN && a.mode != EPI_BN_ADD_BN) return false;
     if (a.mode == EPI_BN_ADD_BN && !a.sc) return false;
-    static const bool off = frt_tuning_env("FRT_CONV_S2") && frt_tuning_env("FRT_CONV_S2")[0] == '0';
+    static const bool off = (frt_tuning_env("FRT_CONV_S2") && frt_tuning_env("FRT_CONV_S2")[0] == '0') ||
+                            (frt_tuning_env("FRT_CONV_S2C64") && frt_tuning_env("FRT_CONV_S2C64")[0] == '0');
     return !off;
 }
 

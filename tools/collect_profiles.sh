@@ -66,4 +66,8 @@ python bench.py --batch 1 --gallery 10000 --no-cpu-baseline > "$OUT/${TAG}_bench
 python bench.py --faces 1 --no-cpu-baseline > "$OUT/${TAG}_bench_k1.json" 2>/dev/null
 FRT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_rccl_1rank.json"
 FRT_BENCH_FORCE_DIST=1 python bench.py --sharded-gallery --batch 64 --gallery 1250000 --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_sharded_1rank.json"
+# 4. the microbenchmarks DESIGN.md quotes (sources in tools/ubench/*.hip)
+for P in clock_probe occ_probe; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/$P "$ROOT/tools/ubench/$P.hip" 2>/dev/null && timeout 120 /tmp/$P > "$OUT/${TAG}_$P.txt" 2>&1
+done
 ls -la "$OUT"
