@@ -682,10 +682,15 @@ void frt_embedder::build(const frt::Blob &b) {
     // output layer (model_irse.py:143-147): Linear over the NCHW flatten (index c*49 + hw) re-ordered to NHWC (hw*512 + c)
     {
         const float *src = b.get("output_layer.3.weight", (size_t)512 * 25088).data;
+        // ... and packed in MFMA-fragment order for kernels_arc_fc.hip: [output block o / 32][k step k / 16][lane = (k half, o % 32)][8]
         std::vector<uint16_t> w((size_t)512 * 25088);
         for (int o = 0; o < 512; ++o)
             for (int c = 0; c < 512; ++c)
-                for (int hw = 0; hw < 49; ++hw) w[(size_t)o * 25088 + (size_t)hw * 512 + c] = frt::f32_to_f16(src[(size_t)o * 25088 + (size_t)c * 49 + hw]);
+                for (int hw = 0; hw < 49; ++hw) {
+                    const size_t k = (size_t)hw * 512 + c;
+                    const size_t off = ((((size_t)(o >> 5) * (25088 / 16) + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (o & 31)) * 8 + (k & 7);
+                    w[off] = frt::f32_to_f16(src[(size_t)o * 25088 + (size_t)c * 49 + hw]);
+                }
         wfc = reinterpret_cast<half_t *>(arena.upload(w));
         fc_bias = arena.upload(vec_of(b, "output_layer.3.bias", 512));
         frt::bn_fold(b, "output_layer.4", 512, sc, bi);
@@ -837,16 +842,8 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
         }
         cur ^= 1;
     }
-    {  // Linear 25088 -> 512 as a split-K GEMM over the NHWC-flattened BN2d output (Z), then bias + BN1d + L2 norm
-        ConvMfmaArgs a{};
-        a.x = Z[cur];
-        a.w = wfc;
-        a.B = F; a.H = 1; a.W = 1; a.Cin = 25088; a.Ho = 1; a.Wo = 1; a.Cout = 512; a.ks = 1; a.stride = 1; a.pad = 0;
-        a.mode = EPI_PARTIAL;
-        a.outf = fc_partial;
-        a.splits = FC_SPLITS;
-        a.zeros = zeros;
-        launch_conv_mfma(a, s);
+    {  // Linear 25088 -> 512 as 49 K-slices over the NHWC-flattened BN2d output (Z), then slice sum + bias + BN1d + L2 norm
+        launch_fc_slices(Z[cur], wfc, F, fc_partial, s);
         launch_fc_finalize(fc_partial, FC_SPLITS, F, fc_bias, bn_s, bn_b, valid_dev, out_dev, s);
     }
     HIPCHK(hipGetLastError());

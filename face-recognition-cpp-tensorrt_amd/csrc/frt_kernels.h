@@ -197,6 +197,9 @@ struct ArcInputArgs {
 };
 void launch_arc_input(const ArcInputArgs &a, hipStream_t s);
 bool launch_arc_input_mfma(const ArcInputArgs &a, hipStream_t s);  // kernels_arc_input.hip; false: shape not covered
+// output Linear 25088 -> 512 as 49 K-slices (kernels_arc_fc.hip): z [F][25088] fp16, wfrag = weights in MFMA-fragment order
+// [512/32 output blocks][25088/16 k steps][64 lanes][8 halfs] (lane = (output row r, k half hi)), partial [49][F][512] fp32
+void launch_fc_slices(const half_t *z, const half_t *wfrag, int F, float *partial, hipStream_t s);
 // partial [splits][F][512] -> +bias -> BN1d -> L2 normalise -> out [F][512] fp32; rows with valid[f]==0 become zeros.
 void launch_fc_finalize(const float *partial, int splits, int F, const float *bias, const float *s, const float *b, const int *valid,
                         float *out, hipStream_t s_);
