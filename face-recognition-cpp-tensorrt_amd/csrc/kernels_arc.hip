@@ -1196,7 +1196,7 @@ static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
 const char *conv_kernel_label(const ConvMfmaArgs &a) {
     static const char *names[] = {"conv_mfma_kernel<2, 2>", "conv_mfma_kernel<1, 4>", "conv_glds_kernel<2, 2, 2, 0>", "conv_glds_kernel<1, 4, 2, 0>",
                                   "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true, 7, 2, 3>",
-                                  "conv_patch_kernel<3, 5, 5, true, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 7, 1, 3>",
+                                  "conv_patch_kernel<3, 5, 5, true, 0, false, 7, 1, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 7, 1, 3>",
                                   "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3>",
                                   "conv_patch_kernel<5, 1, 5, false, 0, false, 2, 1, 3>", "conv_patch_kernel<5, 1, 5, false, 0, false, 1, 1, 3>"};
     if (const char *l2 = conv_s2_label(a)) return l2;
@@ -1227,7 +1227,7 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
 #endif
     switch (v) {
         case CV_P_PAIR: return launch_patch_t<3, 5, 5, true, 0, true>(a, R, n_img, s);
-        case CV_P_SINGLE: return launch_patch_t<3, 5, 5, true>(a, R, n_img, s);
+        case CV_P_SINGLE: return launch_patch_t<3, 5, 5, true, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_255:
 #ifdef FRT_ABLATE
             if (abl == 1) return launch_patch_t<2, 5, 5, false, 1>(a, R, n_img, s);
