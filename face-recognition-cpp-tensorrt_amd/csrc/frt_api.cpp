@@ -1300,6 +1300,10 @@ struct frt_pipeline {
             HIPCHK(hipEventRecord(ev_emb[slot], es));
             HIPCHK(hipStreamWaitEvent(ms, ev_emb[slot], 0));
         }
+        // consecutive calls' match stages sit on DIFFERENT streams (their recogniser passes') but share the matcher's scratch and this
+        // pipeline's d_idx / d_sim: each one starts behind the previous one's end (they rarely meet: 0.3 ms every 3.3 ms, half a
+        // period apart - which is exactly why an unordered pair showed up as one failing equality test in several hundred)
+        if (pipe3 && mat && mat->busy) HIPCHK(hipStreamWaitEvent(ms, mat->ev_busy, 0));
         run_part(GraphKey{2, nullptr, results_dev, embeds_dev, n, slot, align ? 1 : 0, gen}, ms, [&](hipStream_t st) {
             if (have_gallery) mat->top1_dev(emb_slot, F, d_idx, d_sim, st);
             {

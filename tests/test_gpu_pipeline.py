@@ -275,6 +275,40 @@ def test_ir_se_batches_in_flight_equal_one_at_a_time(frt, synth, blobs):
     small.close()
 
 
+@pytest.mark.timeout(300)  # (unordered match stages corrupt the candidate list and the re-rank kernel then spins for minutes)
+def test_match_stages_of_consecutive_calls_are_ordered(frt, synth, blobs):
+    """Consecutive calls run their match + pack behind their recogniser pass on two different streams but share the matcher's scratch:
+    with one frame per call and a large gallery the match is as long as everything else of a call, so two unordered match stages
+    would overlap all the time.  40 calls, three in flight, two alternating frames: every call must return what it returns alone."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 1, 4, 320, 320
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    rec.setGallery(synth.make_gallery(400000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    batches = [synth.make_frames(B, H, W, start=11 * i) for i in range(2)]
+    want = [tuple(a.copy() for a in pipe.run(b)) for b in batches]
+    assert not np.array_equal(want[0][0]["match_idx"], want[1][0]["match_idx"])  # the two frames must not match the same rows
+    n_sub = 40
+    pinned = [torch.from_numpy(b).pin_memory() for b in batches]
+    res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in range(n_sub)]
+    tickets = []
+    for i in range(n_sub):
+        if i >= 3:
+            pipe.wait(tickets[i - 3])
+        tickets.append(pipe.submit(pinned[i & 1].numpy(), res[i].numpy().view(frt.RESULT_DTYPE), None))
+    for t in tickets[-3:]:
+        pipe.wait(t)
+    for i in range(n_sub):
+        assert np.array_equal(res[i].numpy().view(frt.RESULT_DTYPE), want[i & 1][0]), i
+    pipe.close()
+    det.close()
+    rec.close()
+
+
 def test_pipeline_run_from_several_threads(frt, synth, blobs):
     """frt_pipeline_run is the entry point a multithreaded server (src/app.cpp:367) would call concurrently.  Every call
     takes its own staging set, so four threads hammering it must each get exactly the single-threaded answer for their frames."""
