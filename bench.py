@@ -454,7 +454,7 @@ def main():
                                                                     "achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 1)} for k, v in live.items()}},
                         "note": "achieved/frac/avg_launch_us: live HIP-event durations of every launch of the kernel in ONE step (step %d of %d) "
                                 "inside the timed region; that call runs serially on the pipeline stream so that the events bracket the kernel "
-                                "alone (events on every step would cost 11 %% of the step time, and under the 4-stream pipeline the bracketed "
+                                "alone (events on every step would cost 11 %% of the step time, and under the stage-stream pipeline the bracketed "
                                 "time includes other streams' dispatches)" % (args.steps, args.steps)}
             try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_profiles.sh)
                 import glob
