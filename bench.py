@@ -424,7 +424,7 @@ def main():
     def conv_table(labels, ms, work):
         t = {}
         for l, m, w in zip(labels, ms, work):
-            if m > 0 and l.startswith("conv_"):
+            if m > 0 and l.startswith("conv"):  # conv_patch / conv_s2 / conv_s2c64 / conv64 / conv_glds (3x3 and the 1x1 shortcuts)
                 e = t.setdefault(l, [0.0, 0.0, 0])
                 e[0] += float(m)
                 e[1] += float(w)
@@ -543,6 +543,10 @@ def main():
             roofline["serial_achieved"] = round(ach, 2)
             roofline["serial_frac"] = round(ach / PEAK_FP16_MFMA_TFLOPS, 4)
             roofline["serial_avg_launch_us"] = round(1e3 * ser[dom][0] / ser[dom][2], 2)
+        # live (two earlier steps still in flight on the stage streams) against alone, per kernel: how much each loses to co-runners
+        for k, e in roofline["all_3x3_conv_kernels"]["per_kernel"].items():
+            if k in ser:
+                e["alone_avg_launch_us"] = round(1e3 * ser[k][0] / ser[k][2], 2)
 
     if args.stage_profile and rank == 0:  # extra, untimed steps with stage-level HIP events -> a side file (not the JSON line)
         frt.profile_enable(2)

@@ -276,6 +276,9 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
 //    tiles have their own 9 KB: 52.6 KB per workgroup - 53 248 is the most that still fits three per CU).
 // 135 us (im2col kernel) -> 100 - 105 us = 3.5 TB/s on the 360 MB.  What bounds it now is the dependent chain of a step (row fetch ->
 // 72 MFMAs -> shortcut load -> stores) at three chains per CU; the staging alone streams at 4.8 TB/s (43 us).
+// Next to co-runners (the pipelined benchmark) a launch lasts 220 - 335 us: with their LDS taken fewer of the three chains per CU are
+// resident.  Handing the rows out dynamically (chunks of 4 from a device counter instead of a static split) did not help - 126 us
+// alone, 241 us live - so it is not a load-balance effect; at the headline this kernel and the im2col kernel it replaces are equal.
 constexpr int C64_ROW = 113 * 128;               // one input row: x = -1 .. 111, 128 bytes per pixel (x = 112 is only read by dead pixel slots)
 constexpr int C64_LDS = 3 * C64_ROW + 2 * 32 * 36 * 4;  // + the epilogue tiles with the channel parameters in their pad columns (the dead pixel slots' read overrun, pixel index <= 128, lands there)
 __global__ __launch_bounds__(128, 2) void conv_s2c64_kernel(ConvMfmaArgs p, int n_rows) {
