@@ -181,6 +181,7 @@ bool conv_se_fused(const ConvMfmaArgs &a);  // a: the unit's conv2 described as 
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);
 bool conv_s2_applies(const ConvMfmaArgs &a);                // kernels_arc_s2.hip: 3x3 stride 2, Cout % 128 == 0 or 64 -> 64 at 112 -> 56
 bool launch_conv_s2(const ConvMfmaArgs &a, hipStream_t s);
+bool conv_s2_se_fused(const ConvMfmaArgs &a);  // IR-SE tail in the stride-2 strip kernel's epilogue (see conv_se_fused)
 const char *conv_s2_label(const ConvMfmaArgs &a);
 bool conv64_applies(const ConvMfmaArgs &a);                 // kernels_arc_c64.hip: Cin = Cout = 64, 3x3, stride 1
 bool launch_conv64(const ConvMfmaArgs &a, hipStream_t s);

@@ -23,6 +23,7 @@
 //   EPI_PARTIAL    outf[split][pixel][cout] = acc                                (split-K partial sums for the final Linear)
 // MaxPool2d(1, stride) shortcuts are pure indexing: the shortcut operand is sampled at (oh*stride, ow*stride).
 #include "frt_kernels.h"
+#include "frt_se_device.h"
 
 #include <stdlib.h>
 
@@ -437,46 +438,6 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(ConvMfmaArgs p) {
     }
 }
 
-constexpr int SE_SPLIT = 4;  // pixel ranges per face (partial sums, summed in fixed order: deterministic)
-// fc1 -> ReLU -> fc2 -> sigmoid on the pooled vector sp[C] (LDS), 256 threads.  Both layers are a few thousand MACs: what costs is
-// the dependent chain, so every hidden unit gets 256 / R threads that each take a contiguous run of channels (all loads of a thread
-// are independent 16-byte loads in flight at once), then a fixed-order shuffle reduction; the output layer is a thread per channel
-// with its R weights as float4 loads.  (A wave per hidden unit walking the channels and a scalar loop over R: 5 - 11 us per call.)
-__device__ __forceinline__ void se_fc1(const float *sp, float *shid, const float *__restrict__ w1, int C) {  // 256 threads; caller syncs afterwards
-    const int R = C / 16;            // hidden units: 4 .. 32
-    const int G = 256 / R;           // threads per hidden unit: 64 .. 8 (a power of two, inside one wave)
-    const int per = C / G;           // channels per thread: 1, 4, 16, 64
-    const int h = threadIdx.x / G, g = threadIdx.x % G;
-    float a = 0.f;
-    if (per == 1) {
-        a = w1[(long)h * C + g] * sp[g];
-    } else {
-        const float *wp = w1 + (long)h * C + g * per;
-        const float *xp = sp + g * per;
-        for (int i = 0; i < per; i += 4) {
-            const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
-            a = fmaf(w[0], xp[i], a);
-            a = fmaf(w[1], xp[i + 1], a);
-            a = fmaf(w[2], xp[i + 2], a);
-            a = fmaf(w[3], xp[i + 3], a);
-        }
-    }
-    for (int off = G >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off);
-    if (g == 0) shid[h] = fmaxf(a, 0.f);
-}
-__device__ __forceinline__ float se_fc2(const float *shid, const float *__restrict__ w2, int C, int c) {  // gate of channel c
-    const int R = C / 16;
-    const float *wp = w2 + (long)c * R;
-    float o = 0.f;
-    for (int i = 0; i < R; i += 4) {
-        const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + i);
-        o = fmaf(w[0], shid[i], o);
-        o = fmaf(w[1], shid[i + 1], o);
-        o = fmaf(w[2], shid[i + 2], o);
-        o = fmaf(w[3], shid[i + 3], o);
-    }
-    return 1.f / (1.f + expf(-o));
-}
 __device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const float *__restrict__ w1, const float *__restrict__ w2, int C, int f,
                                            float *__restrict__ gate) {
     se_fc1(sp, shid, w1, C);
@@ -1212,7 +1173,8 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
 bool conv_se_fused(const ConvMfmaArgs &a0) {
     ConvMfmaArgs a = a0;
     a.mode = EPI_BN_ADD_BN;  // same eligibility as the plain unit tail (shortcut with the output's geometry)
-    if (!a.se_pool || !a.sc || !a.out1 || conv64_applies(a) || conv_s2_applies(a)) return false;
+    if (!a.se_pool || !a.sc || !a.out1 || conv64_applies(a)) return false;
+    if (conv_s2_applies(a)) return conv_s2_se_fused(a);
     int R = 0, n_img = 0;
     return conv_variant(a, R, n_img) == CV_P_255 && n_img == 1 && a.H / R <= SE_SPLIT;
 }
