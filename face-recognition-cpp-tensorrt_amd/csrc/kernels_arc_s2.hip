@@ -213,127 +213,13 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
         m = ((long)img0 * Ho + oy0) * Wo + sl;
         return sl < n_valid && m < Mtot;
     };
-    if constexpr (SEP) {
-        // IR-SE unit tail inside conv2's epilogue, exactly as in conv_patch_kernel<..., SEP = true> (kernels_arc.hip; comments there): y = BN(conv2) * gate + shortcut, z = BN_next(y), where
-        // gate = sigmoid(fc2(relu(fc1(mean over the image of BN(conv2))))) needs the WHOLE image and all channels.  The strip is a range of
-        // rows of ONE image (n_img == 1) and the accumulators stay in registers, so:
-        //   pass 1  transposes the accumulators once just to sum the (fp16-rounded, as the stand-alone path stores them) BN outputs per
-        //           channel; the partial sums go to pool[strip of the image][face][channel] as device-scope stores;
-        //   meet    the workgroups of the face (strips x cout tiles; adjacent in launch order) count themselves in; the last one resets
-        //           the counter and publishes the launch number in the face's flag, everybody waits for it (bounded spin);
-        //   gate    every workgroup adds the partial sums in strip order and runs fc1 and its 128 channels of fc2 itself (a few
-        //           thousand MACs: cheaper than another hand-over);
-        //   pass 2  transposes again and writes y and z - exactly se_apply_kernel's arithmetic, without the res tensor's round trip,
-        //           the pooling pass and the apply pass (10 + 13 us and two dependent launches per unit before).
-        // No device-scope fence anywhere (see se_pool_gate_kernel); nothing a workgroup waits for depends on a workgroup that is
-        // dispatched more than (strips x cout tiles - 1) x 8 block indices later, so the wait cannot starve the launch.
-        float se_sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = v;
-            }
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int px = (lane >> 2) + 16 * it;
-                const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
-                const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
-                long m;
-                if (!slot_pixel(j * 32 + px, m)) continue;
-                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) se_sum[e] += (float)(half_t)(v[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) se_sum[e] += __shfl_xor(se_sum[e], off);
-        const int part = strip % strips_per_img;
-        if ((lane >> 2) == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                __hip_atomic_store(&p.se_pool[((long)part * p.B + img0) * p.Cout + cch + e], se_sum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged before the arrival is announced
-        __syncthreads();
-        if (tid == 0) {
-            const int expect = strips_per_img * n_co_tiles;
-            int *flag = p.se_counter + p.se_flag_off;
-            const int prev = __hip_atomic_fetch_add(&p.se_counter[img0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev == expect - 1) {
-                __hip_atomic_store(&p.se_counter[img0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&flag[img0], p.se_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                int spin = 0;
-                while (__hip_atomic_load(&flag[img0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.se_epoch) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spin > (1 << 25)) __builtin_trap();  // seconds: the hand-over is broken - fail the launch loudly, never continue on a stale gate
-                }
-            }
-        }
-        __syncthreads();
-        // the first tile's shortcut values are requested here and land under the gate arithmetic
-        auto load_sc = [&](int j, half8 (&dst)[2]) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                long m;
-                const bool ok = slot_pixel(j * 32 + (lane >> 2) + 16 * it, m);
-                dst[it] = *reinterpret_cast<const half8 *>(p.sc + (ok ? m : 0) * p.Cout + cch);
-            }
-        };
-        half8 scs[2][2];  // shortcut values one pixel tile ahead (all 7 tiles at once: 56 live registers, spills)
-        load_sc(0, scs[0]);
-        float *sp = reinterpret_cast<float *>(smem + 4 * 32 * EROW * 4), *shid = sp + 512, *sgate = sp + 576;
-        const int C = p.Cout;
-        for (int c = tid; c < C; c += 256) {
-            float t = 0.f;
-            for (int q = 0; q < strips_per_img; ++q)
-                t += __hip_atomic_load(&p.se_pool[((long)q * p.B + img0) * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sp[c] = t / (float)(Ho * Wo);
-        }
-        __syncthreads();
-        se_fc1(sp, shid, p.se_w1, C);
-        __syncthreads();
-        if (tid < 128) sgate[tid] = se_fc2(shid, p.se_w2, C, co_base + tid);
-        __syncthreads();
-        q2[0] = *reinterpret_cast<const floatx4 *>(p.p2 + cch);  // (only needed from here on)
-        q2[1] = *reinterpret_cast<const floatx4 *>(p.p2 + cch + 4);
-        q3[0] = *reinterpret_cast<const floatx4 *>(p.p3 + cch);
-        q3[1] = *reinterpret_cast<const floatx4 *>(p.p3 + cch + 4);
-        float g8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g8[e] = sgate[cow + chunk * 8 + e];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (j + 1 < NT) load_sc(j + 1, scs[(j + 1) & 1]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = v;
-            }
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int px = (lane >> 2) + 16 * it;
-                const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
-                const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
-                long m;
-                if (!slot_pixel(j * 32 + px, m)) continue;
-                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                half8 y8, z8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float res = (float)(half_t)(v[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3]);
-                    const float y = res * g8[e] + (float)scs[j & 1][it][e];
-                    y8[e] = (half_t)y;
-                    z8[e] = (half_t)(y * q2[e >> 2][e & 3] + q3[e >> 2][e & 3]);
-                }
-                *reinterpret_cast<half8 *>(p.out0 + m * C + cch) = y8;
-                *reinterpret_cast<half8 *>(p.out1 + m * C + cch) = z8;
-            }
-        }
+    if constexpr (SEP) {  // IR-SE: the whole SE tail here (frt_se_device.h)
+        const int per_img = R * Wo;
+        se_tail_epilogue<NT, (NT == 4 ? 2 : 1)>(p, acc, ep, reinterpret_cast<float *>(smem + 4 * 32 * EROW * 4), strip % strips_per_img, strips_per_img,
+                                               n_co_tiles, img0, n_img, Ho * Wo, co_base, cow, [&](int sl, long &m, int &il) -> bool {
+                                                   il = (NT == 4 && !linear && sl >= per_img) ? 1 : 0;
+                                                   return slot_pixel(sl, m);
+                                               });
         return;
     }
     half8 sc8[NT][2];
@@ -622,7 +508,9 @@ bool s2_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &nt, int &pp) {
 bool conv_s2_se_fused(const ConvMfmaArgs &a) {
     int R, n_img, nt, pp;
     if (s2c64_applies(a) || !s2_geometry(a, R, n_img, nt, pp)) return false;
-    return nt == 7 && n_img == 1 && a.Ho / R <= SE_SPLIT;
+    if (nt == 7) return n_img == 1 && a.Ho / R <= SE_SPLIT;
+    if (nt == 4 && pp <= 5) return n_img == 2 ? R == a.Ho : (n_img == 1 && a.Ho / R <= SE_SPLIT);
+    return false;
 }
 
 bool conv_s2_applies(const ConvMfmaArgs &a) {
@@ -656,6 +544,7 @@ bool launch_conv_s2(const ConvMfmaArgs &a0, hipStream_t s) {
     a.wf = a0.wf2;  // the kernel streams the stride-2 step order
     if (nt == 7 && a.mode == EPI_BN_SE) launch_s2_t<7, 9, true>(a, R, n_img, s);  // (the caller checked conv_s2_se_fused)
     else if (nt == 7) launch_s2_t<7, 9>(a, R, n_img, s);
+    else if (nt == 4 && pp <= 5 && a.mode == EPI_BN_SE) launch_s2_t<4, 5, true>(a, R, n_img, s);
     else if (nt == 4 && pp <= 5) launch_s2_t<4, 5>(a, R, n_img, s);
     else if (nt == 4) launch_s2_t<4, 9>(a, R, n_img, s);
     else if (pp <= 5) launch_s2_t<2, 5>(a, R, n_img, s);
