@@ -89,3 +89,24 @@ def test_batch_of_128_equals_small_batches(frt, synth, blobs):
         assert np.abs(e[f0:f0 + 8] - es).max() < 2e-6, (f0, np.abs(e[f0:f0 + 8] - es).max())
     big.close()
     small.close()
+
+
+@pytest.mark.parametrize("mode", ["ir", "ir_se"])
+def test_every_batch_size_class_embeds_alike(frt, synth, blobs, mode):
+    """The strip heights, images per strip and (IR-SE) which units run the SE tail inside conv2's epilogue all follow the batch size;
+    odd batch sizes leave a last strip with a single image.  The same faces must embed alike (fp16 rounding flips only) whatever
+    batch they travel in."""
+    path, _ = blobs(mode)
+    x = np.random.default_rng(17).standard_normal((100, 3, 112, 112)).astype(np.float32) * 0.5
+    ref = frt.ArcFaceIR50(path, maxBatchSize=8)
+    want = np.concatenate([ref.doInference(x[i:i + 8]) for i in (0, 24, 92)])  # faces 0-7, 24-31, 92-99
+    ref.close()
+    for F in (1, 3, 16, 33, 64, 100):
+        rec = frt.ArcFaceIR50(path, maxBatchSize=F)
+        e = rec.doInference(x[:F])
+        rec.close()
+        assert np.isfinite(e).all() and np.allclose((e.astype(np.float64) ** 2).sum(1), 1, atol=1e-5), F
+        for lo, k in ((0, 0), (24, 8), (92, 16)):
+            n = min(8, F - lo)
+            if n > 0:
+                assert (e[lo:lo + n] * want[k:k + n]).sum(1).min() > 1 - 1e-5, (F, lo)
