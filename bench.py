@@ -15,8 +15,11 @@ through frt_pipeline_submit / frt_pipeline_wait with three batches in flight (H2
 its own 32 frames (weak scaling; `--strong` splits ONE 32-frame batch over the ranks - BASELINE configs[3] as written, also reported
 as a side object of every N > 1 run).  Frames are independent, so there is NO collective on the data path; with N > 1 the per-face
 result records of every step are all-gathered over RCCL on a side stream inside the timed region (configs[3]'s exchange step).
-`--sharded-gallery` runs configs[4] instead: the gallery is row-sharded over the ranks and stored as fp16, embeddings are
-all-gathered, every rank searches its shard, the (index, similarity) winners are all-gathered and merged (first maximum wins).
+`--sharded-gallery` runs configs[4] instead: the gallery is row-sharded over the ranks and stored as fp16, the embeddings are rounded to
+fp16 and all-gathered, every rank searches its shard for its top-k lists (global indices), the lists are all-gathered and merged on the
+device (higher similarity first, lower global index on ties).  Every data-path exchange is an ncclAllGather issued by libfrt.so itself
+(frt_comm_*, the C-ABI a C++ host binds); torch.distributed only hands the communicator id to the ranks and carries the benchmark's
+barrier / max-over-ranks bookkeeping.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      dominant kernel family = the ArcFace 3x3 implicit-GEMM convs; achieved = algorithmic FLOPs of those launches /
@@ -203,6 +206,9 @@ def main():
     ap.add_argument("--sharded-gallery", action="store_true",
                     help="BASELINE configs[4]: gallery row-sharded over the ranks and stored as fp16; RCCL all-gather of embeddings and of the top-1 winners")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step RCCL all-gather of the result records")
+    ap.add_argument("--topk", type=int, default=5, help="--sharded-gallery: length of the per-query lists every rank answers with (1..16)")
+    ap.add_argument("--dump-final", default=None, help="--sharded-gallery: write the last step's gathered fp16 queries and merged top-k lists (npz) "
+                                                       "for an external check against the oracle (tests/test_gpu_dist.py)")
     ap.add_argument("--stage-profile", default=None, help="write a per-stage HIP-event breakdown (extra untimed steps) to this file")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (no side measurements)")
@@ -266,6 +272,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+        def bcast_id(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        # the data-path communicator: RCCL through the C ABI (created last: it owns a stream)
+        cg = fd.CommGroup(frt, rank, world, local_rank, bcast_id if world > 1 else None)
+
     # two alternating batches so that consecutive steps never see the same pixels
     batches = [s.make_frames(B, FH, FW, start=frame_start), s.make_frames(B, FH, FW, start=frame_start + 4096)]
     h_frames = [torch.from_numpy(b).pin_memory() for b in batches]
@@ -284,15 +298,22 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     pipe.set_stream(stream.cuda_stream)
-    side = torch.cuda.Stream() if use_dist else None       # RCCL all-gather + D2H of the gathered records
+    side = torch.cuda.ExternalStream(cg.stream) if use_dist else None   # the communicator's own stream: H2D of the records, ncclAllGather, D2H
     ev_side = [torch.cuda.Event() for _ in range(NRING)] if use_dist else None
     gather = use_dist and not args.no_gather
 
     # ---- sharded-gallery mode (configs[4]): the pipeline has no matcher stage and produces embeddings; match + merge follow here
     if args.sharded_gallery:
+        TK = args.topk
         d_emb = [torch.zeros(F, 512, device="cuda") for _ in range(NRING)]
-        d_idx = torch.zeros(world * F, dtype=torch.int32, device="cuda")
-        d_sim = torch.zeros(world * F, dtype=torch.float32, device="cuda")
+        d_emb16 = torch.zeros(F, 512, dtype=torch.float16, device="cuda")            # what travels: fp16 embeddings
+        d_q16 = torch.zeros(world * F, 512, dtype=torch.float16, device="cuda")      # every rank's queries
+        d_li = torch.zeros(world * F, TK, dtype=torch.int32, device="cuda")          # this rank's lists for ALL queries
+        d_ls = torch.zeros(world * F, TK, dtype=torch.float32, device="cuda")
+        d_gi = torch.zeros(world, world * F, TK, dtype=torch.int32, device="cuda")   # every rank's lists
+        d_gs = torch.zeros(world, world * F, TK, dtype=torch.float32, device="cuda")
+        d_fi = torch.zeros(world * F, TK, dtype=torch.int32, device="cuda")          # merged
+        d_fs = torch.zeros(world * F, TK, dtype=torch.float32, device="cuda")
         final = [None]
 
     # ---------------------------------------------------------------------------------------------------- step bodies
@@ -323,7 +344,7 @@ def main():
             with torch.cuda.stream(side):
                 d_res[slot].copy_(h_res[slot], non_blocking=True)
                 if gather:
-                    dist.all_gather_into_tensor(d_all[slot], d_res[slot])
+                    cg.all_gather(d_res[slot], d_all[slot], side.cuda_stream)   # ncclAllGather from libfrt (frt_comm_all_gather)
                     h_all[slot].copy_(d_all[slot], non_blocking=True)
                 ev_side[slot].record(side)
 
@@ -361,13 +382,22 @@ def main():
             pipe.run_dev(d_frames[i & 1].data_ptr(), B, d_res[r].data_ptr(), d_emb[r].data_ptr())
             if i == profile_step:
                 frt.profile_enable(-1)
-            q_all = fd.all_gather_embeddings(d_emb[r]) if use_dist else d_emb[r]      # exchange 1: every rank gets every query
-            nq = q_all.shape[0]
-            rec.matmul.top1_dev(q_all.data_ptr(), nq, d_idx.data_ptr(), d_sim.data_ptr(), stream.cuda_stream)
+            cs = stream.cuda_stream
+            nq = world * F
+            frt.embeds_to_half_dev(d_emb[r].data_ptr(), F * 512, d_emb16.data_ptr(), cs)    # fp16 embeddings (configs[4])
             if use_dist:
-                final[0] = fd.sharded_top1(d_idx[:nq], d_sim[:nq])                       # exchange 2: winners, first maximum wins
+                cg.all_gather(d_emb16, d_q16, cs)                                          # exchange 1: every rank gets every query
+                q_ptr = d_q16.data_ptr()
             else:
-                final[0] = (d_idx[:nq], d_sim[:nq])
+                q_ptr = d_emb16.data_ptr()
+            rec.matmul.topk_dev(q_ptr, nq, TK, d_li.data_ptr(), d_ls.data_ptr(), cs, fp16=True)   # this shard's lists, global indices
+            if use_dist:
+                cg.all_gather(d_li, d_gi, cs)                                              # exchange 2: the top-k lists
+                cg.all_gather(d_ls, d_gs, cs)
+                frt.merge_topk_dev(world, nq, TK, d_gi.data_ptr(), d_gs.data_ptr(), d_fi.data_ptr(), d_fs.data_ptr(), cs)
+                final[0] = (d_fi, d_fs)
+            else:
+                final[0] = (d_li, d_ls)
 
     if args.sharded_gallery:
         run = run_sharded
@@ -461,7 +491,10 @@ def main():
                 for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
                     with open(path) as f:
                         pmc = json.load(f)
-                    ent = pmc.get("per_kernel", {}).get(dom) or (pmc if pmc.get("kernel") == dom else None)
+                    per = pmc.get("per_kernel", {})
+                    # (profiler symbols may carry trailing template arguments the label lacks: match on the common prefix)
+                    ent = per.get(dom) or next((v for k, v in per.items() if k.startswith(dom.rstrip(">")) or dom.startswith(k.rstrip(">"))), None) \
+                        or (pmc if pmc.get("kernel") == dom else None)
                     if ent:
                         roofline["traffic"] = ent["hbm_bytes_per_launch"]
                         roofline["traffic_note"] = os.path.basename(path) + ": " + pmc["note"]
@@ -548,7 +581,8 @@ def main():
             if k in ser:
                 e["alone_avg_launch_us"] = round(1e3 * ser[k][0] / ser[k][2], 2)
 
-    if args.stage_profile and rank == 0:  # extra, untimed steps with stage-level HIP events -> a side file (not the JSON line)
+    overlap_eff = None
+    if (args.stage_profile or not args.no_extras) and rank == 0:  # extra, untimed SERIAL steps with stage-level HIP events
         frt.profile_enable(2)
         for i in range(3):
             pipe.run_dev(d_frames[i & 1].data_ptr(), B, d_res[0].data_ptr(), d_emb[0].data_ptr() if args.sharded_gallery else None)
@@ -561,14 +595,26 @@ def main():
             a[0] += m
             a[1] += w
             a[2] += 1
-        with open(args.stage_profile, "w") as f:
-            json.dump({k: {"ms_per_step": v[0] / 3, "work_per_step": v[1] / 3, "launch_groups_per_step": v[2] / 3} for k, v in agg.items()}, f, indent=1)
+        if args.stage_profile:
+            with open(args.stage_profile, "w") as f:
+                json.dump({k: {"ms_per_step": v[0] / 3, "work_per_step": v[1] / 3, "launch_groups_per_step": v[2] / 3} for k, v in agg.items()}, f, indent=1)
+        st = {k: v[0] / 3 for k, v in agg.items()}
+        stage_ms = {"detector": st.get("det_preprocess", 0) + st.get("det_network", 0) + st.get("det_postprocess", 0),
+                    "recogniser": st.get("crop_faces", 0) + st.get("align_faces", 0) + st.get("embed_network", 0),
+                    "match": st.get("match_top1", 0) + st.get("match_topk", 0) + st.get("pack_results", 0)}
+        step_ms = 1e3 * dt / args.steps
+        if max(stage_ms.values()) > 0:
+            overlap_eff = {"value": round(max(stage_ms.values()) / step_ms, 4), "serial_stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                           "serial_sum_ms": round(sum(stage_ms.values()), 4), "step_ms": round(step_ms, 4),
+                           "note": "max(serial stage time) / pipelined step time: 1.0 = the step costs what its slowest stage costs alone "
+                                   "(stage times: HIP events around each stage in 3 extra serial steps on this rank)"}
 
     if rank == 0:
         if args.sharded_gallery:
             boundary = "HBM-resident frames -> merged top-1 on the device"
-            par = ("frames sharded dp%d, gallery ROW-sharded over %d rank(s) (%d rows each, fp16-stored), RCCL all-gather of embeddings, per-shard "
-                   "top-1 with global indices, RCCL all-gather of (idx, sim) + first-maximum merge" % (world, world, (args.gallery + world - 1) // world))
+            par = ("frames sharded dp%d, gallery ROW-sharded over %d rank(s) (%d rows each, fp16-stored), ncclAllGather (libfrt frt_comm) of fp16 "
+                   "embeddings, per-shard exact top-%d lists with global indices, ncclAllGather of the lists + device merge (higher similarity, "
+                   "then lower global index)" % (world, world, (args.gallery + world - 1) // world, args.topk))
         else:
             boundary = ("HBM-resident frames -> HBM-resident records (frt_pipeline_run_dev)" if args.resident else
                         "pinned host frames -> host records, %d batches in flight (frt_pipeline_submit/wait)" % DEPTH)
@@ -600,6 +646,8 @@ def main():
             "cpu_baseline": None,
         }
         out.update(extras)
+        if overlap_eff:
+            out["overlap_efficiency"] = overlap_eff
         if smi and smi.samples:
             pw = [x["power_w"] for x in smi.samples if "power_w" in x]
             ck = [x["sclk_mhz"] for x in smi.samples if "sclk_mhz" in x]
@@ -613,8 +661,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.sharded_gallery:
             out["cpu_baseline"] = cpu_baseline(det_sd, rec_sd, gallery, batches[0], K)
         print(json.dumps(out), file=json_out, flush=True)
+    if args.sharded_gallery and args.dump_final and rank == 0:
+        torch.cuda.synchronize()
+        fi, fs = final[0]
+        nq = world * F
+        np.savez(args.dump_final, queries_f16=(d_q16 if use_dist else d_emb16).cpu().numpy()[:nq], idx=fi.cpu().numpy()[:nq], sim=fs.cpu().numpy()[:nq],
+                 gallery_rows=args.gallery, world=world, k=args.topk, gallery_seed=3)
     if use_dist:
         dist.barrier()
+        cg.close()
         dist.destroy_process_group()
 
 

@@ -73,12 +73,30 @@ ABI = {
     "frt_matcher_calculate": (_i, [_vp, _vp, _i, _vp]),
     "frt_matcher_top1": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_merge_top1": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "frt_matcher_topk": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "frt_matcher_topk_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "frt_merge_topk": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "frt_merge_topk_dev": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "frt_embeds_to_half_dev": (_i, [_vp, _sz, _vp, _vp]),
+    "frt_comm_get_unique_id": (_i, [_vp]),
+    "frt_comm_create": (_i, [_vp, _i, _i, _i, ctypes.POINTER(_vp)]),
+    "frt_comm_create_all": (_i, [_i, _vp, _vp]),
+    "frt_comm_destroy": (None, [_vp]),
+    "frt_comm_rank": (_i, [_vp]),
+    "frt_comm_world": (_i, [_vp]),
+    "frt_comm_stream": (_vp, [_vp]),
+    "frt_comm_all_gather": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "frt_comm_all_gather_multi": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+    "frt_comm_sync": (_i, [_vp]),
+    "frt_embedder_set_se_fused": (_i, [_vp, _i]),
+    "frt_jpeg_encode_batch_after": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "frt_pipeline_create": (_i, [_vp, _vp, _vp, _i, ctypes.POINTER(_vp)]),
     "frt_pipeline_destroy": (None, [_vp]),
     "frt_pipeline_run": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_pipeline_run_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
     "frt_pipeline_run_dev_after": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "frt_pipeline_set_input_sync": (_i, [_vp, _i]),
+    "frt_pipeline_check_overlap": (_i, [_vp, _vp]),
     "frt_pipeline_submit": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(ctypes.c_long)]),
     "frt_pipeline_wait": (_i, [_vp, ctypes.c_long]),
     "frt_pipeline_sync": (_i, [_vp]),
@@ -177,6 +195,19 @@ class MatMul:
         """Asynchronous, raw device addresses (queries fp32 [n][k], idx int32 [n], sim fp32 [n])."""
         _check(lib.frt_matcher_top1_dev(self._h, _vp(embeds_ptr), int(n), _vp(idx_ptr), _vp(sim_ptr), _vp(hip_stream) if hip_stream else None))
 
+    def topk(self, embeds, k):
+        """Exact top-k lists [n, k] (entry 0 == top1; ties: lower index first; -1 / -inf when the gallery has fewer than k rows)."""
+        e = np.ascontiguousarray(embeds, np.float32).reshape(-1, self.k)
+        idx = np.empty((e.shape[0], int(k)), np.int32)
+        sim = np.empty((e.shape[0], int(k)), np.float32)
+        _check(lib.frt_matcher_topk(self._h, _ptr(e), e.shape[0], int(k), _ptr(idx), _ptr(sim)))
+        return idx, sim
+
+    def topk_dev(self, embeds_ptr, n, k, idx_ptr, sim_ptr, hip_stream=None, fp16=False):
+        """Asynchronous, raw device addresses: queries fp32 (or IEEE fp16 with ``fp16=True``) [n][k_dim], idx int32 [n][k], sim fp32 [n][k]."""
+        _check(lib.frt_matcher_topk_dev(self._h, _vp(embeds_ptr), 1 if fp16 else 0, int(n), int(k), _vp(idx_ptr), _vp(sim_ptr),
+                                        _vp(hip_stream) if hip_stream else None))
+
     def setRowOffset(self, row_offset):
         """Sharded gallery: local row 0 is global row ``row_offset`` (top-1 indices become global)."""
         _check(lib.frt_matcher_set_row_offset(self._h, int(row_offset)))
@@ -214,6 +245,68 @@ def merge_top1(idx_a, sim_a, idx_b, sim_b):
     io, so = np.empty(n, np.int32), np.empty(n, np.float32)
     _check(lib.frt_merge_top1(n, _ptr(ia), _ptr(sa), _ptr(ib), _ptr(sb), _ptr(io), _ptr(so)))
     return io, so
+
+
+def merge_topk(idx_all, sim_all):
+    """Host k-way merge of per-shard top-k lists [shards, n, k] with global indices -> ([n, k], [n, k])."""
+    ia = np.ascontiguousarray(idx_all, np.int32)
+    sa = np.ascontiguousarray(sim_all, np.float32)
+    shards, n, k = ia.shape
+    io, so = np.empty((n, k), np.int32), np.empty((n, k), np.float32)
+    _check(lib.frt_merge_topk(shards, n, k, _ptr(ia), _ptr(sa), _ptr(io), _ptr(so)))
+    return io, so
+
+
+def merge_topk_dev(shards, n, k, idx_all_ptr, sim_all_ptr, idx_out_ptr, sim_out_ptr, hip_stream=None):
+    _check(lib.frt_merge_topk_dev(int(shards), int(n), int(k), _vp(idx_all_ptr), _vp(sim_all_ptr), _vp(idx_out_ptr), _vp(sim_out_ptr),
+                                  _vp(hip_stream) if hip_stream else None))
+
+
+def embeds_to_half_dev(src_ptr, n_values, dst_ptr, hip_stream=None):
+    _check(lib.frt_embeds_to_half_dev(_vp(src_ptr), int(n_values), _vp(dst_ptr), _vp(hip_stream) if hip_stream else None))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RCCL communicator behind the C ABI (frt_comm_*): the exchange step of the multi-GPU path from C++, no torch.distributed
+# ----------------------------------------------------------------------------------------------------------------------
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    b = np.zeros(COMM_ID_BYTES, np.uint8)
+    _check(lib.frt_comm_get_unique_id(_ptr(b)))
+    return b.tobytes()
+
+
+class Comm:
+    def __init__(self, unique_id, rank, world, device=0):
+        self._h = _vp()
+        b = np.frombuffer(bytes(unique_id), np.uint8)
+        assert b.size == COMM_ID_BYTES
+        _check(lib.frt_comm_create(_ptr(b), int(rank), int(world), int(device), ctypes.byref(self._h)))
+        self.rank, self.world = int(rank), int(world)
+
+    @property
+    def stream(self):
+        """raw hipStream_t of the communicator's exchange stream"""
+        return int(lib.frt_comm_stream(self._h) or 0)
+
+    def all_gather(self, send_ptr, recv_ptr, bytes_per_rank, hip_stream=None):
+        _check(lib.frt_comm_all_gather(self._h, _vp(send_ptr), _vp(recv_ptr), int(bytes_per_rank), _vp(hip_stream) if hip_stream else None))
+
+    def sync(self):
+        _check(lib.frt_comm_sync(self._h))
+
+    def close(self):
+        if self._h:
+            lib.frt_comm_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -349,6 +442,10 @@ class ArcFaceIR50:
         self.classCount = 0
         self._known = None
         self._embeds = np.zeros((0, self.outputDim), np.float32)
+
+    def setSeFused(self, enable):
+        """IR-SE only: SE tail inside conv2's epilogue (default) or as stand-alone launches; bit-identical results."""
+        _check(lib.frt_embedder_set_se_fused(self._h, 1 if enable else 0))
 
     def preprocessFace(self, face):
         face = np.ascontiguousarray(face, np.uint8)
@@ -501,6 +598,13 @@ class Pipeline:
     def set_input_sync(self, enable):
         """Safe mode: order every run_dev call behind the work already queued on the pipeline stream (see include/frt.h)."""
         _check(lib.frt_pipeline_set_input_sync(self._h, 1 if enable else 0))
+
+    def check_overlap(self):
+        """-> (ratio, warning): ratio ~1 = the stage streams (and the caller's) run side by side, ~n = n of them share a hardware queue;
+        warning = the library's message when ratio > 1.5, else ''."""
+        r = ctypes.c_float(0)
+        _check(lib.frt_pipeline_check_overlap(self._h, ctypes.byref(r)))
+        return float(r.value), lib.frt_last_error().decode(errors="replace")
 
     def sync(self):
         _check(lib.frt_pipeline_sync(self._h))

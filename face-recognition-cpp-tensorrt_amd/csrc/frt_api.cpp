@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -536,6 +537,17 @@ struct frt_embedder {
     half_t *Y[2], *Z[2], *T, *SC, *RES = nullptr, *zeros = nullptr;
     float *fc_partial, *d_out, *se_pool = nullptr, *se_gate = nullptr;
     int se_epoch = 0;  // launch counter of the fused SE tails (their gate-ready flags carry the launch number)
+    bool se_fused = true;        // IR-SE: run the SE tail inside conv2's epilogue where the strip kernels allow it (FRT_SE_FUSED=0 /
+                                 // frt_embedder_set_se_fused(e, 0): always the stand-alone pool + gate + apply launches)
+    int *h_se_error = nullptr;   // error word of the fused tail's cross-workgroup hand-over (pinned, mapped; 0 = fine)
+    int *d_se_error = nullptr;   // ... its device address
+    void check_se_error() {      // after a host synchronisation: a timed-out hand-over must not pass as a result
+        if (h_se_error && *reinterpret_cast<volatile int *>(h_se_error) != 0) {
+            *h_se_error = 0;
+            raise(FRT_ERR_DEVICE, "IR-SE: the fused SE tail's cross-workgroup hand-over timed out (embeddings of that pass are invalid); "
+                                  "frt_embedder_set_se_fused(e, 0) selects the stand-alone tail");
+        }
+    }
     uint8_t *d_crops = nullptr;
     int *d_valid = nullptr;
     frt_bbox *d_boxes = nullptr;
@@ -712,6 +724,11 @@ void frt_embedder::build(const frt::Blob &b) {
         se_pool = arena.alloc<float>(F * 512 * 4 + 2 * F);  // SE_SPLIT partial sums per (face, channel) + per-face arrival counters + gate-ready flags
         HIPCHK(hipMemset(se_pool + F * 512 * 4, 0, 2 * F * sizeof(int)));  // (kept at zero between launches by the kernel)
         se_gate = arena.alloc<float>(F * 512);
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_se_error), sizeof(int), hipHostMallocMapped));
+        *h_se_error = 0;
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_se_error), h_se_error, 0));
+        const char *sf = getenv("FRT_SE_FUSED");
+        se_fused = !(sf && sf[0] == '0');
     }
     fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);
     d_out = arena.alloc<float>(F * 512);
@@ -814,7 +831,8 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
                 a.se_w2 = u.se_w2;
                 a.se_counter = cnt;
                 a.se_flag_off = max_batch;
-                if (conv_se_fused(a)) {  // the strip kernel runs the whole tail in its epilogue
+                a.se_error = d_se_error;
+                if (se_fused && conv_se_fused(a)) {  // the strip kernel runs the whole tail in its epilogue
                     if (se_epoch >= (1 << 30)) {  // the flags carry launch numbers: start over with clean flags (both scratch sets)
                         HIPCHK(hipMemsetAsync(cnt + max_batch, 0, (size_t)max_batch * sizeof(int), s));
                         if (has_alt) HIPCHK(hipMemsetAsync(reinterpret_cast<int *>(alt.se_pool + (size_t)max_batch * 512 * 4) + max_batch, 0, (size_t)max_batch * sizeof(int), s));
@@ -863,8 +881,9 @@ struct frt_matcher {
     int N = 0, D = 0;
     int row_offset = 0;  // global index of local row 0 (sharded galleries)
     // scratch (grown on demand)
-    float *d_q = nullptr, *d_sim = nullptr, *d_full = nullptr;
+    float *d_q = nullptr, *d_sim = nullptr, *d_full = nullptr, *d_kth = nullptr;
     int32_t *d_idx = nullptr;
+    static constexpr int KCAP = 16;  // d_sim / d_idx hold [q_cap][KCAP] (top-k lists of the host entry point)
     MatchPartial *d_partial = nullptr;
     int q_cap = 0;
     size_t full_cap = 0;
@@ -1050,10 +1069,15 @@ struct frt_matcher {
         if (d_q) (void)hipFree(d_q);
         if (d_sim) (void)hipFree(d_sim);
         if (d_idx) (void)hipFree(d_idx);
+        if (d_kth) (void)hipFree(d_kth);
         if (d_partial) (void)hipFree(d_partial);
+        d_q = d_sim = d_kth = nullptr;
+        d_idx = nullptr;
+        d_partial = nullptr;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_q), (size_t)cap * D * sizeof(float)));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_sim), (size_t)cap * sizeof(float)));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_idx), (size_t)cap * sizeof(int32_t)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_sim), (size_t)cap * KCAP * sizeof(float)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_idx), (size_t)cap * KCAP * sizeof(int32_t)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_kth), (size_t)cap * sizeof(float)));
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_partial), (size_t)blocks * cap * sizeof(MatchPartial)));
         if (screen) {
             const size_t tiles = ((size_t)N + 127) / 128;
@@ -1077,6 +1101,12 @@ struct frt_matcher {
             launch_match_top1_h(d_g16, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
         else
             launch_match_top1(d_gallery, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
+        HIPCHK(hipGetLastError());
+    }
+    // exact top-k lists [F][k] (idx_dev / sim_dev device pointers); queries fp32 on the device
+    void topk_dev(const float *queries_dev, int F, int k, int32_t *idx_dev, float *sim_dev, hipStream_t s) {
+        ProfScope ps(2, "match_topk", 2.0 * D * (double)N * F, s);
+        launch_match_topk(d_gallery, d_g16, N, D, queries_dev, F, k, screen, gmax_norm, scr, d_kth, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
         HIPCHK(hipGetLastError());
     }
 };
@@ -1208,6 +1238,62 @@ struct frt_pipeline {
             HIPCHK(ie);
         }
         HIPCHK(hipGraphLaunch(e->exec, st));
+    }
+
+    // ---- stream-overlap self-check.  The three-stage pipeline only overlaps when its stage streams (and the caller's joining stream)
+    //      sit on different hardware queues: ROCm maps streams round-robin onto GPU_MAX_HW_QUEUES (4) queues per priority level, a
+    //      queue is in-order, and one extra stream created before the pipeline has been seen to cost 7 % - 2.5x.
+    //      Measured, not assumed: one 150 us single-wave spin kernel per stream, started together; `ratio` = elapsed / 150 us is ~1 when
+    //      they run side by side and ~n when n streams share a queue.
+    std::string warning;      // last self-check verdict ("" = fine); frt_pipeline_check_overlap returns it through frt_last_error
+    float overlap_ratio = 0.f;
+    float check_streams(const std::vector<hipStream_t> &sts, double us = 150.0) {
+        std::vector<hipEvent_t> a(sts.size()), b(sts.size());
+        for (size_t i = 0; i < sts.size(); ++i) {
+            HIPCHK(hipEventCreate(&a[i]));
+            HIPCHK(hipEventCreate(&b[i]));
+            HIPCHK(hipStreamSynchronize(sts[i]));
+        }
+        for (size_t i = 0; i < sts.size(); ++i) launch_spin(5.0, sts[i]);  // first use of the kernel: code load off the clock
+        for (size_t i = 0; i < sts.size(); ++i) HIPCHK(hipStreamSynchronize(sts[i]));
+        float worst = 0.f;
+        for (int rep = 0; rep < 3; ++rep) {  // best of three: a late host thread inflates a run, nothing deflates it
+            for (size_t i = 0; i < sts.size(); ++i) {
+                HIPCHK(hipEventRecord(a[i], sts[i]));
+                launch_spin(us, sts[i]);
+                HIPCHK(hipEventRecord(b[i], sts[i]));
+            }
+            for (size_t i = 0; i < sts.size(); ++i) HIPCHK(hipEventSynchronize(b[i]));
+            float span = 0.f;  // first start -> last end
+            for (size_t i = 0; i < sts.size(); ++i) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, a[0], b[i]));
+                span = std::max(span, ms);
+            }
+            const float r = span * 1e3f / (float)us;
+            worst = rep == 0 ? r : std::min(worst, r);
+        }
+        for (size_t i = 0; i < sts.size(); ++i) {
+            (void)hipEventDestroy(a[i]);
+            (void)hipEventDestroy(b[i]);
+        }
+        return worst;
+    }
+    void self_check(bool with_caller) {
+        std::vector<hipStream_t> sts = {det_stream, emb_stream, emb_stream2};
+        if (with_caller && stream) sts.push_back(stream);
+        overlap_ratio = check_streams(sts);
+        warning.clear();
+        if (overlap_ratio > 1.5f) {
+            char buf[512];
+            snprintf(buf, sizeof(buf),
+                     "frt_pipeline: the %zu stage streams do not run side by side (150 us probe kernels took %.2fx as long together as alone): "
+                     "they share a hardware queue, consecutive batches will not overlap.  Create the pipeline before other HIP streams "
+                     "(RCCL, copy streams), keep GPU_MAX_HW_QUEUES at its default 4, see INTEGRATION.md 'Streams and hardware queues'.",
+                     sts.size(), overlap_ratio);
+            warning = buf;
+            if (!getenv("FRT_QUIET")) fprintf(stderr, "[libfrt] warning: %s\n", buf);
+        }
     }
 
     void ensure_stream() {
@@ -1627,10 +1713,19 @@ void frt_embedder_destroy(frt_embedder *e) {
         (void)hipStreamDestroy(e->stream);
     }
     if (e->d_frame) (void)hipFree(e->d_frame);
+    if (e->h_se_error) (void)hipHostFree(e->h_se_error);
     for (hipEvent_t ev : e->ev_busy)
         if (ev) (void)hipEventDestroy(ev);
     e->arena.release();
     delete e;
+}
+
+int frt_embedder_set_se_fused(frt_embedder *e, int enable) {
+    return guarded([&] {
+        if (!e) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->se_fused = enable != 0;
+    });
 }
 
 int frt_embedder_preprocess_face(frt_embedder *e, const uint8_t *bgr_crop, float *chw_out) {
@@ -1661,6 +1756,7 @@ int frt_embedder_infer(frt_embedder *e, const float *chw, int batch, float *embe
             e->forward(e->d_in, nf, nullptr, e->d_out, s);
             HIPCHK(hipMemcpyAsync(embeds_out + (size_t)f0 * 512, e->d_out, sizeof(float) * 512 * nf, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            e->check_se_error();
         }
     });
 }
@@ -1693,6 +1789,7 @@ int frt_embedder_forward(frt_embedder *e, const uint8_t *bgr, int rows, int cols
             std::vector<int> valid(nf);
             HIPCHK(hipMemcpyAsync(valid.data(), e->d_valid, sizeof(int) * nf, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            e->check_se_error();
             for (int v : valid) bad = bad || !v;
         }
         if (bad) raise(FRT_ERR_EMPTY_ROI, "forward: empty or out-of-frame ROI (embedding set to zeros)");
@@ -1754,6 +1851,7 @@ int frt_embedder_forward_aligned(frt_embedder *e, const uint8_t *bgr, int rows, 
             std::vector<int> valid(nf);
             HIPCHK(hipMemcpyAsync(valid.data(), e->d_valid, sizeof(int) * nf, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            e->check_se_error();
             for (int v : valid) bad = bad || !v;
         }
         if (bad) raise(FRT_ERR_EMPTY_ROI, "forwardAligned: degenerate landmarks (embedding set to zeros)");
@@ -1777,14 +1875,16 @@ int frt_matcher_create(int device, frt_matcher **out) {
 void frt_matcher_destroy(frt_matcher *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    // an unfinished streaming load runs on m->stream (ld.s == stream): abort it while the stream still exists
+    m->load_abort();
+    m->load_release_staging();
+    m->ld.s = nullptr;
     if (m->stream) {
         (void)hipStreamSynchronize(m->stream);
         (void)hipStreamDestroy(m->stream);
     }
-    m->load_abort();
-    m->load_release_staging();
     if (m->ev_busy) (void)hipEventDestroy(m->ev_busy);
-    for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full, (void *)m->d_g16})
+    for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full, (void *)m->d_g16, (void *)m->d_kth})
         if (p) (void)hipFree(p);
     m->free_screen_scratch();
     delete m;
@@ -1945,6 +2045,103 @@ int frt_merge_top1(int n, const int32_t *idx_a, const float *sim_a, const int32_
     });
 }
 
+static void check_k(int k) {
+    if (k < 1 || k > match_topk_max() || k > frt_matcher::KCAP) raise(FRT_ERR_INVALID, "top-k: k must be in 1..16");
+}
+
+int frt_matcher_topk(frt_matcher *m, const float *embeds, int embed_count, int k, int32_t *idx_out, float *sim_out) {
+    return guarded([&] {
+        if (!m || !embeds || !idx_out || !sim_out) raise(FRT_ERR_INVALID, "topk: null argument");
+        check_k(k);
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (m->N <= 0 || embed_count <= 0) raise(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found");
+        use_device(m->device);
+        hipStream_t s = m->stream;
+        m->wait_idle(s);
+        m->ensure_queries(embed_count);
+        HIPCHK(hipMemcpyAsync(m->d_q, embeds, sizeof(float) * (size_t)embed_count * m->D, hipMemcpyHostToDevice, s));
+        m->topk_dev(m->d_q, embed_count, k, m->d_idx, m->d_sim, s);
+        HIPCHK(hipMemcpyAsync(idx_out, m->d_idx, sizeof(int32_t) * (size_t)embed_count * k, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(sim_out, m->d_sim, sizeof(float) * (size_t)embed_count * k, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_matcher_topk_dev(frt_matcher *m, const void *embeds_dev, int embeds_fp16, int embed_count, int k, void *idx_dev, void *sim_dev, void *hip_stream) {
+    return guarded([&] {
+        if (!m || !embeds_dev || !idx_dev || !sim_dev) raise(FRT_ERR_INVALID, "topk_dev: null argument");
+        check_k(k);
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (m->N <= 0 || embed_count <= 0) raise(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found");
+        use_device(m->device);
+        hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+        m->wait_idle(s);
+        m->ensure_queries(embed_count);
+        const float *q = reinterpret_cast<const float *>(embeds_dev);
+        if (embeds_fp16) {  // exact widening into the query scratch
+            launch_half_to_float(reinterpret_cast<const half_t *>(embeds_dev), (long)embed_count * m->D, m->d_q, s);
+            q = m->d_q;
+        }
+        m->topk_dev(q, embed_count, k, reinterpret_cast<int32_t *>(idx_dev), reinterpret_cast<float *>(sim_dev), s);
+        HIPCHK(hipEventRecord(m->ev_busy, s));  // the scratch stays in use until this call has run
+        m->busy = true;
+    });
+}
+
+int frt_merge_topk(int shards, int n, int k, const int32_t *idx_all, const float *sim_all, int32_t *idx_out, float *sim_out) {
+    return guarded([&] {
+        if (shards < 1 || n < 0 || k < 1 || !idx_all || !sim_all || !idx_out || !sim_out) raise(FRT_ERR_INVALID, "merge_topk: bad argument");
+        std::vector<int> pos((size_t)shards);
+        for (int q = 0; q < n; ++q) {
+            std::fill(pos.begin(), pos.end(), 0);
+            for (int o = 0; o < k; ++o) {
+                int best = -1, bi = 0;
+                float bv = 0.f;
+                for (int sh = 0; sh < shards; ++sh) {
+                    while (pos[(size_t)sh] < k && idx_all[((size_t)sh * n + q) * k + pos[(size_t)sh]] < 0) ++pos[(size_t)sh];  // empty slots
+                    if (pos[(size_t)sh] >= k) continue;
+                    const size_t e = ((size_t)sh * n + q) * k + pos[(size_t)sh];
+                    const float v = sim_all[e];
+                    const int i = idx_all[e];
+                    if (best < 0 || v > bv || (v == bv && i < bi)) {
+                        best = sh;
+                        bv = v;
+                        bi = i;
+                    }
+                }
+                if (best < 0) {
+                    idx_out[(size_t)q * k + o] = -1;
+                    sim_out[(size_t)q * k + o] = -INFINITY;
+                } else {
+                    idx_out[(size_t)q * k + o] = bi;
+                    sim_out[(size_t)q * k + o] = bv;
+                    ++pos[(size_t)best];
+                }
+            }
+        }
+    });
+}
+
+int frt_merge_topk_dev(int shards, int n, int k, const void *idx_all_dev, const void *sim_all_dev, void *idx_out_dev, void *sim_out_dev, void *hip_stream) {
+    return guarded([&] {
+        if (shards < 1 || n < 0 || k < 1 || !idx_all_dev || !sim_all_dev || !idx_out_dev || !sim_out_dev) raise(FRT_ERR_INVALID, "merge_topk_dev: bad argument");
+        if (n == 0) return;
+        launch_merge_topk(reinterpret_cast<const int32_t *>(idx_all_dev), reinterpret_cast<const float *>(sim_all_dev), shards, n, k,
+                          reinterpret_cast<int32_t *>(idx_out_dev), reinterpret_cast<float *>(sim_out_dev), reinterpret_cast<hipStream_t>(hip_stream));
+        HIPCHK(hipGetLastError());
+    });
+}
+
+int frt_embeds_to_half_dev(const void *embeds_dev, size_t n_values, void *half_out_dev, void *hip_stream) {
+    return guarded([&] {
+        if (!embeds_dev || !half_out_dev || n_values % 8) raise(FRT_ERR_INVALID, "embeds_to_half: bad argument (n_values must be a multiple of 8)");
+        if (n_values == 0) return;
+        launch_float_to_half(reinterpret_cast<const float *>(embeds_dev), (long)n_values, reinterpret_cast<half_t *>(half_out_dev),
+                             reinterpret_cast<hipStream_t>(hip_stream));
+        HIPCHK(hipGetLastError());
+    });
+}
+
 // ------------------------------------------------------------------------------------------------------------ pipeline
 int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int max_frames, frt_pipeline **out) {
     return guarded([&] {
@@ -2007,6 +2204,10 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         p->d_chw = p->arena.alloc<float>(F * 3 * 112 * 112);
         p->d_sim = p->arena.alloc<float>(F);
         p->d_idx = p->arena.alloc<int32_t>(F);
+        if (p->overlap) {  // create-time self-check of the stage streams (~1 ms); FRT_PIPELINE_SELFCHECK=0 skips it
+            const char *sc = getenv("FRT_PIPELINE_SELFCHECK");
+            if (!(sc && sc[0] == '0')) p->self_check(false);
+        }
         *out = p.release();
     });
 }
@@ -2080,6 +2281,22 @@ int frt_pipeline_run_dev_after(frt_pipeline *p, const void *frames_dev, int n_fr
     });
 }
 
+int frt_pipeline_check_overlap(frt_pipeline *p, float *ratio_out) {
+    int rc = guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        use_device(p->det->device);
+        std::lock_guard<std::mutex> lk(p->run_mu);
+        HIPCHK(hipStreamSynchronize(p->det_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream));
+        HIPCHK(hipStreamSynchronize(p->emb_stream2));
+        if (p->stream) HIPCHK(hipStreamSynchronize(p->stream));
+        p->self_check(true);
+        if (ratio_out) *ratio_out = p->overlap_ratio;
+    });
+    if (rc == FRT_OK && p && !p->warning.empty()) frthost::last_error() = p->warning;  // FRT_OK + a message: a warning, not a failure
+    return rc;
+}
+
 int frt_pipeline_set_input_sync(frt_pipeline *p, int enable) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
@@ -2096,6 +2313,7 @@ int frt_pipeline_sync(frt_pipeline *p) {
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
         HIPCHK(hipStreamSynchronize(p->stream));
+        p->emb->check_se_error();
     });
 }
 
@@ -2197,6 +2415,7 @@ static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
         ev = b.ev_out;
     }
     HIPCHK(hipEventSynchronize(ev));
+    p->emb->check_se_error();
 }
 
 // Synchronous host entry point.  Thread-safe: every call takes its own staging set (device frames / results / embeddings) under the

@@ -43,7 +43,8 @@ int parse(const uint8_t *d, size_t n, Parsed &out, std::string &err) {
     Header &h = out.h;
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return fail(err, "jpeg: no SOI marker");
     size_t p = 2;
-    bool have_sof = false;
+    bool have_sof = false, saw_jfif = false, saw_adobe = false;
+    int adobe_transform = -1;
     while (true) {
         if (p + 4 > n) return fail(err, "jpeg: truncated before SOS");
         if (d[p] != 0xFF) return fail(err, "jpeg: marker expected");
@@ -82,6 +83,14 @@ int parse(const uint8_t *d, size_t n, Parsed &out, std::string &err) {
                     total += t.bits[i];
                 }
                 if (total > 256 || q + 17 + total > sl) return fail(err, "jpeg: bad DHT counts");
+                // Kraft limit (libjpeg's "bad Huffman table"): with `code` = first unused code of length l, more than 2^l codes of
+                // that length cannot exist.  An over-subscribed table would make build() index past fast[512] / hand out codes
+                // that overlap - reject it before it is ever built.
+                for (int l = 1, code = 0; l <= 16; ++l) {
+                    code += t.bits[l];
+                    if (code > (1 << l)) return fail(err, "jpeg: bad Huffman table (over-subscribed code lengths)");
+                    code <<= 1;
+                }
                 std::memcpy(t.vals, s + q + 17, (size_t)total);
                 t.build();
                 t.set = true;
@@ -109,6 +118,13 @@ int parse(const uint8_t *d, size_t n, Parsed &out, std::string &err) {
             have_sof = true;
         } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             return fail(err, "jpeg: lossless / arithmetic-coded / hierarchical streams are not supported");
+        } else if (m == 0xE0) {  // APP0: "JFIF\0" fixes the colour space to YCbCr (libjpeg: saw_JFIF_marker)
+            if (sl >= 5 && !std::memcmp(s, "JFIF", 5)) saw_jfif = true;
+        } else if (m == 0xEE) {  // APP14: "Adobe" + version(2) flags0(2) flags1(2) transform(1)
+            if (sl >= 12 && !std::memcmp(s, "Adobe", 5)) {
+                saw_adobe = true;
+                adobe_transform = s[11];
+            }
         } else if (m == 0xDD) {  // DRI
             if (sl < 2) return fail(err, "jpeg: short DRI");
             h.restart_interval = be16(s);
@@ -131,6 +147,14 @@ int parse(const uint8_t *d, size_t n, Parsed &out, std::string &err) {
             break;
         }
         p += len;
+    }
+    // Colour space of a 3-component stream, decided the way libjpeg's default_decompress_parms does (cv::imdecode inherits it): JFIF
+    // -> YCbCr; else Adobe transform 0 -> RGB, 1 -> YCbCr; else component ids 'R','G','B' -> RGB, anything else -> YCbCr.  The
+    // device half only implements the YCbCr -> BGR conversion, so RGB-coded streams are refused instead of decoded with wrong colours.
+    if (h.ncomp == 3 && !saw_jfif) {
+        const bool rgb_ids = h.c[0].id == 'R' && h.c[1].id == 'G' && h.c[2].id == 'B';
+        if ((saw_adobe && adobe_transform == 0) || (!saw_adobe && rgb_ids))
+            return fail(err, "jpeg: RGB-coded streams (Adobe transform 0 / component ids R,G,B) are not supported");
     }
     // geometry
     Header &g = out.h;

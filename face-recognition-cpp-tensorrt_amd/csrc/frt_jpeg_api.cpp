@@ -50,6 +50,11 @@ class Pool {
         cv_.notify_all();
         done_cv_.wait(lk, [&] { return done_ == total_; });
         fn_ = nullptr;
+        if (err_) {  // a task threw (e.g. bad_alloc while a JFIF stream grows): rethrow here, where guarded() turns it into a status
+            std::exception_ptr e = err_;
+            err_ = nullptr;
+            std::rethrow_exception(e);
+        }
     }
 
   private:
@@ -64,8 +69,14 @@ class Pool {
                 const int i = next_++;
                 const std::function<void(int)> *f = fn_;
                 lk.unlock();
-                (*f)(i);
+                std::exception_ptr ep;
+                try {
+                    (*f)(i);
+                } catch (...) {  // never let an exception leave a worker thread (std::terminate)
+                    ep = std::current_exception();
+                }
                 lk.lock();
+                if (ep && !err_) err_ = ep;
                 if (++done_ == total_) done_cv_.notify_all();
             }
         }
@@ -77,6 +88,7 @@ class Pool {
     int next_ = 0, total_ = 0, done_ = 0;
     unsigned epoch_ = 0;
     bool stop_ = false;
+    std::exception_ptr err_;
 };
 
 }  // namespace
@@ -196,6 +208,10 @@ int frt_jpeg_decoder_create(int max_images, int max_width, int max_height, int n
         if (!out) raise(FRT_ERR_INVALID, "null argument");
         *out = nullptr;
         if (max_images < 1 || max_width < 1 || max_height < 1 || max_width > 65535 || max_height > 65535) raise(FRT_ERR_INVALID, "jpeg decoder: bad limits");
+        // staging is sized for max_images x max_width x max_height (about 15 bytes per pixel over both sets, 6 of them pinned host
+        // memory): 2^31 pixels per batch = 256 8K frames is far beyond any frame ingest and keeps a typo from pinning tens of GB
+        if ((uint64_t)max_images * (uint64_t)max_width * (uint64_t)max_height > (1ull << 31))
+            raise(FRT_ERR_CAPACITY, "jpeg decoder: max_images * max_width * max_height exceeds 2^31 pixels per batch");
         use_device(device);
         std::unique_ptr<frt_jpeg_decoder> d(new frt_jpeg_decoder);
         d->device = device;
@@ -378,6 +394,13 @@ static void encode_setup(frt_jpeg_decoder *d, int quality, int n, int rows, int 
 // bgr: host (device_input = 0) or device (1) pointer, tight [n][rows][cols][3].  out: n slots of out_stride bytes; out_sizes[n].
 int frt_jpeg_encode_batch(frt_jpeg_decoder *d, const void *bgr, int device_input, int n, int rows, int cols, int quality, uint8_t *out, size_t out_stride,
                           size_t *out_sizes) {
+    return frt_jpeg_encode_batch_after(d, bgr, device_input, n, rows, cols, quality, out, out_stride, out_sizes, nullptr);
+}
+
+// Same, ordered behind the producer of a DEVICE input: ready_event (hipEvent_t as void*, may be NULL) was recorded by the caller after the
+// work that writes `bgr` (a pipeline stage, frt_embedder_forward on another stream ...); the codec's stream waits for it on the device.
+int frt_jpeg_encode_batch_after(frt_jpeg_decoder *d, const void *bgr, int device_input, int n, int rows, int cols, int quality, uint8_t *out,
+                                size_t out_stride, size_t *out_sizes, void *ready_event) {
     return guarded([&] {
         if (!d || !bgr || !out || !out_sizes || n < 0 || rows < 1 || cols < 1 || rows > 65535 || cols > 65535) raise(FRT_ERR_INVALID, "jpeg encode: bad argument");
         if (n == 0) return;
@@ -385,6 +408,7 @@ int frt_jpeg_encode_batch(frt_jpeg_decoder *d, const void *bgr, int device_input
         use_device(d->device);
         encode_setup(d, quality, n, rows, cols);
         hipStream_t st = d->ensure_stream();
+        if (ready_event) HIPCHK(hipStreamWaitEvent(st, reinterpret_cast<hipEvent_t>(ready_event), 0));
         const uint8_t *src = reinterpret_cast<const uint8_t *>(bgr);
         if (!device_input) {
             HIPCHK(hipMemcpyAsync(d->d_crops, bgr, (size_t)n * rows * cols * 3, hipMemcpyHostToDevice, st));

@@ -32,6 +32,9 @@ inline bool frt_first_use_on_device(bool (&done)[FRT_MAX_DEVICES]) {
     return true;
 }
 
+// ---------------------------------------------------------------- utilities (kernels_util.hip)
+void launch_spin(double microseconds, hipStream_t s);  // one wave busy-waiting on the constant device clock
+
 // ---------------------------------------------------------------- match (kernels_match.hip)
 struct MatchPartial {  // one per (workgroup, query)
     float sim;
@@ -54,6 +57,14 @@ void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int 
 void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
                                 const ScreenScratch &w, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
                                 int row_offset, hipStream_t s);
+// exact top-k [F][k] (k passes of the top-1 search over the rows behind the previous winner; screened galleries scan coarsely once)
+void launch_match_topk(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, int k, bool screen, float gmax_norm,
+                       const ScreenScratch &w, float *kth_scratch, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
+                       int row_offset, hipStream_t s);
+int match_topk_max();
+void launch_half_to_float(const half_t *in, long n, float *out, hipStream_t s);
+void launch_float_to_half(const float *in, long n, half_t *out, hipStream_t s);
+void launch_merge_topk(const int32_t *idx_all, const float *sim_all, int shards, int n, int k, int32_t *idx_out, float *sim_out, hipStream_t s);
 // full matrix: out[F][N]
 void launch_match_full(const float *gallery, int N, int D, const float *queries, int F, float *out, hipStream_t s);
 // fp16-STORED gallery (BASELINE config 5): same kernels, rows widened exactly to fp32 while they are staged.  For the screened
@@ -176,6 +187,7 @@ struct ConvMfmaArgs {
     int *se_counter;     // [>= B] arrival counters, zero between launches; the gate-ready flags sit se_flag_off ints behind
     int se_flag_off;
     int se_epoch;        // launch number (> 0, different from every earlier launch's on this scratch): what the flags are set to
+    int *se_error;       // error word in mapped host memory: set (to the launch number) when a hand-over wait timed out
 };
 bool conv_se_fused(const ConvMfmaArgs &a);  // a: the unit's conv2 described as EPI_BN_ADD_BN + the se_* scratch
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s);

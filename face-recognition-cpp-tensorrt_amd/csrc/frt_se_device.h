@@ -50,7 +50,7 @@ __device__ __forceinline__ float se_fc2(const float *shid, const float *__restri
 //   pass 1  transposes the accumulators once just to sum the (fp16-rounded, as the stand-alone path stores them) BN outputs per
 //           channel and image; the partial sums go to pool[part of the image][face][channel] as device-scope stores;
 //   meet    the workgroups of a face (parts x cout tiles; adjacent in launch order) count themselves in; the last one resets the
-//           counter and publishes the launch number in the face's flag, everybody waits for it (bounded spin, trap on timeout);
+//           counter and publishes the launch number in the face's flag, everybody waits for it (bounded spin; on timeout the error word is raised);
 //   gate    every workgroup adds the partial sums in part order - so the result does not depend on arrival order - and runs fc1 and
 //           its 128 channels of fc2 itself (a few thousand MACs: cheaper than another hand-over);
 //   pass 2  transposes again and writes y and z - exactly se_apply_kernel's arithmetic, without the res tensor's round trip,
@@ -129,7 +129,13 @@ __device__ __forceinline__ void se_tail_epilogue(const ConvMfmaArgs &p, const fl
             int spin = 0;
             while (__hip_atomic_load(&flag[img], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.se_epoch) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spin > (1 << 25)) __builtin_trap();  // seconds: the hand-over is broken - fail the launch loudly, never continue on a stale gate
+                if (++spin > (1 << 25)) {
+                    // seconds: the hand-over is broken.  Raise the error word (mapped host memory: every synchronising entry point of
+                    // the embedder / pipeline checks it and fails with FRT_ERR_DEVICE) and leave the loop; the gate of this face is
+                    // then stale, but the HIP context - shared by every pipeline of the process - survives (a trap would kill it).
+                    __hip_atomic_store(p.se_error, p.se_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
             }
         }
     }

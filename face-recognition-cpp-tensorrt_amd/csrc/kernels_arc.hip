@@ -22,6 +22,9 @@
 //                  be folded into the conv weights exactly - it is applied here, where the value is produced)
 //   EPI_PARTIAL    outf[split][pixel][cout] = acc                                (split-K partial sums for the final Linear)
 // MaxPool2d(1, stride) shortcuts are pure indexing: the shortcut operand is sampled at (oh*stride, ow*stride).
+#include <cstdio>
+#include <cstring>
+
 #include "frt_kernels.h"
 #include "frt_se_device.h"
 
@@ -1050,7 +1053,13 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
-    return names[conv_variant(a, R, n_img)];
+    const char *base = names[conv_variant(a, R, n_img)];
+    if (!strncmp(base, "conv_patch_kernel", 17)) {  // the strip kernel's symbol carries a tenth argument: SE tail in the epilogue or not
+        static thread_local char buf[96];
+        snprintf(buf, sizeof(buf), "%.*s, %s>", (int)strlen(base) - 1, base, a.mode == EPI_BN_SE ? "true" : "false");
+        return buf;
+    }
+    return base;
 }
 
 // IR-SE: can the launch of `a` (conv2 of a unit described as EPI_BN_ADD_BN, se_* scratch set) run the whole SE tail in its epilogue

@@ -47,10 +47,15 @@ __device__ __forceinline__ floatx4 load_g4(const half_t *G, long g, int D, int k
     return floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 
-template <int NQ, bool FULL, typename GT = float>
+// EXCL (top-k passes): only rows that come strictly AFTER the query's previous winner (prev_sim, prev_idx = its GLOBAL index) in the
+// result order "higher similarity first, lower index first on ties" take part; prev_sim == nullptr: no previous winner (first pass).
+// The similarities are the same accumulators either way, so pass j of a top-k search returns the j-th entry of the exact ranking.
+template <int NQ, bool FULL, typename GT = float, bool EXCL = false>
 __global__ __launch_bounds__(256) void match_kernel(const GT *__restrict__ G, int N, int D, const float *__restrict__ E, int F,
                                                     MatchPartial *__restrict__ partial, float *__restrict__ out_full, int num_tiles,
-                                                    int row_offset, const int *__restrict__ tile_list, const int *__restrict__ d_num_tiles) {
+                                                    int row_offset, const int *__restrict__ tile_list, const int *__restrict__ d_num_tiles,
+                                                    const float *__restrict__ prev_sim = nullptr, const int32_t *__restrict__ prev_idx = nullptr,
+                                                    int prev_stride = 1) {
     // tile_list != nullptr: run only over the listed 128-row gallery tiles (num_tiles = list length): the exact re-rank pass of
     // the screened top-1 (same code path per tile as the full scan -> bitwise-identical similarities)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,8 +107,19 @@ __global__ __launch_bounds__(256) void match_kernel(const GT *__restrict__ G, in
     floatx16 acc[NQ];
     float bv[NQ];
     int bi[NQ];
+    float ps[NQ];  // EXCL: previous winner of this lane's query n (query q0 + n*32 + r)
+    int pi[NQ];
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
+        ps[n] = INFINITY;
+        pi[n] = -1;
+        if (EXCL && prev_sim) {
+            const int q = q0 + n * 32 + r;
+            if (q < F) {
+                ps[n] = prev_sim[(long)q * prev_stride];
+                pi[n] = prev_idx[(long)q * prev_stride];
+            }
+        }
         bv[n] = -INFINITY;
         bi[n] = INT_MAX;
 #pragma unroll
@@ -159,7 +175,9 @@ __global__ __launch_bounds__(256) void match_kernel(const GT *__restrict__ G, in
                     } else {
                         const int g = gbase + rr;
                         const float v = acc[n][e];
-                        if (g < N && better(v, g, bv[n], bi[n])) {
+                        bool ok = g < N;
+                        if (EXCL) ok = ok && ((v < ps[n]) || (v == ps[n] && g + row_offset > pi[n]));
+                        if (ok && better(v, g, bv[n], bi[n])) {
                             bv[n] = v;
                             bi[n] = g;
                         }
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(256) void match_kernel(const GT *__restrict__ G, in
 
 // one wave per query: lanes stride over the workgroup partials, then a butterfly with the same first-maximum rule
 __global__ __launch_bounds__(64) void match_reduce_kernel(const MatchPartial *__restrict__ partial, int blocks, int F,
-                                                          int32_t *__restrict__ idx_out, float *__restrict__ sim_out) {
+                                                          int32_t *__restrict__ idx_out, float *__restrict__ sim_out, int out_stride = 1) {
     const int q = blockIdx.x;
     float v = -INFINITY;
     int i = INT_MAX;
@@ -235,8 +253,8 @@ __global__ __launch_bounds__(64) void match_reduce_kernel(const MatchPartial *__
         }
     }
     if (threadIdx.x == 0) {
-        idx_out[q] = i == INT_MAX ? -1 : i;
-        sim_out[q] = v;
+        idx_out[(long)q * out_stride] = i == INT_MAX ? -1 : i;
+        sim_out[(long)q * out_stride] = v;
     }
 }
 
@@ -392,16 +410,22 @@ __global__ __launch_bounds__(256) void match_segmax_kernel(const float *__restri
     if (tid == 0) segmax[q * SEL_SEG + seg] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
+// kth != nullptr (top-k): the threshold hangs on the query's k-th largest coarse entry instead of its largest.  With |S~ - S| <= delta:
+// the k-th largest coarse entry m_k is the maximum of a 32-row block, k blocks have one >= m_k, hence k distinct rows have S >= m_k -
+// delta, hence the exact k-th best similarity s_k >= m_k - delta, and every row with S >= s_k has S~ >= m_k - 2*delta: it lives in a
+// listed tile.  (k = 1 is the rule above.)
 __global__ __launch_bounds__(256) void match_select_kernel(const float *__restrict__ tilemax, int num_tiles, int sub, const float *__restrict__ segmax,
                                                            const float *__restrict__ Q, int D, float gmax_norm, int *__restrict__ tile_flags,
-                                                           int *__restrict__ tile_list, int *__restrict__ count) {
+                                                           int *__restrict__ tile_list, int *__restrict__ count, const float *__restrict__ kth = nullptr) {
     // `sub` coarse entries per 128-row tile (match_coarse_kernel writes one per wave: 4)
     __shared__ float sm[4];
     const int q = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
     const int n_ent = num_tiles * sub;
     const float *row = tilemax + (long)q * n_ent;
     float m = -INFINITY, n2 = 0.f;
-    for (int s = 0; s < SEL_SEG; ++s) m = fmaxf(m, segmax[q * SEL_SEG + s]);
+    if (kth) m = kth[q];
+    else
+        for (int s = 0; s < SEL_SEG; ++s) m = fmaxf(m, segmax[q * SEL_SEG + s]);
     for (int k = tid; k < D; k += 256) n2 += Q[(long)q * D + k] * Q[(long)q * D + k];
     for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
     if ((tid & 63) == 0) sm[tid >> 6] = n2;
@@ -409,23 +433,133 @@ __global__ __launch_bounds__(256) void match_select_kernel(const float *__restri
     const float qn = sqrtf(sm[0] + sm[1] + sm[2] + sm[3]);
     const float delta = 1.2e-3f * qn * gmax_norm;
     // fp16 overflow / non-finite inputs: no valid bound -> take every tile (degenerates to the exact full scan)
+    // (top-k with fewer than k coarse entries: kth = -inf -> every tile)
     const float thr = (qn < 6.0e4f && gmax_norm < 6.0e4f && m == m && m > -INFINITY && m < INFINITY) ? m - 2.f * delta : -INFINITY;
     const int e0 = (int)((long)n_ent * seg / SEL_SEG), e1 = (int)((long)n_ent * (seg + 1) / SEL_SEG);
     for (int t = e0 + tid; t < e1; t += 256)
         if (!(row[t] < thr) && atomicExch(&tile_flags[t / sub], 1) == 0) tile_list[atomicAdd(count, 1)] = t / sub;
 }
 
-template <int NQ, bool FULL, typename GT = float>
+// ---------------------------------------------------------------- top-k support (BASELINE configs[4]: "RCCL top-k all-gather")
+constexpr int TOPK_MAX = 16;
+
+// k-th largest coarse entry of every query (grid = queries).  Every thread keeps the TOPK_MAX largest of its strided entries in a
+// sorted register list; the block then pops the overall maximum k times (each pop removes one entry: the owner advances its list).
+__global__ __launch_bounds__(256) void match_kth_kernel(const float *__restrict__ tilemax, int n_ent, int k, float *__restrict__ kth) {
+    __shared__ float sv[4];
+    __shared__ int so[4];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *row = tilemax + (long)q * n_ent;
+    float top[TOPK_MAX];
+#pragma unroll
+    for (int i = 0; i < TOPK_MAX; ++i) top[i] = -INFINITY;
+    for (int t = tid; t < n_ent; t += 256) {
+        float v = row[t];
+        if (!(v > top[TOPK_MAX - 1])) continue;  // (NaN never enters)
+#pragma unroll
+        for (int i = 0; i < TOPK_MAX; ++i) {    // insert, keeping the list sorted (descending)
+            const float hi = fmaxf(top[i], v), lo = fminf(top[i], v);
+            top[i] = hi;
+            v = lo;
+        }
+    }
+    int pos = 0;
+    float result = -INFINITY;
+    for (int j = 0; j < k; ++j) {
+        float head = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < TOPK_MAX; ++i)
+            if (i == pos) head = top[i];
+        float v = head;
+        int o = tid;
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off);
+            const int oo = __shfl_xor(o, off);
+            if (ov > v || (ov == v && oo < o)) {
+                v = ov;
+                o = oo;
+            }
+        }
+        if (lane == 0) {
+            sv[wave] = v;
+            so[wave] = o;
+        }
+        __syncthreads();
+        v = sv[0];
+        o = so[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > v || (sv[w] == v && so[w] < o)) {
+                v = sv[w];
+                o = so[w];
+            }
+        __syncthreads();
+        result = v;
+        if (o == tid && pos < TOPK_MAX) ++pos;
+    }
+    if (tid == 0) kth[q] = result;
+}
+
+// fp16 <-> fp32 rows (the embedding exchange of configs[4] travels as fp16: half the xGMI bytes; the widening is exact)
+__global__ __launch_bounds__(256) void half_to_float_kernel(const half_t *__restrict__ in, float *__restrict__ out, long n8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const half8 h = *reinterpret_cast<const half8 *>(in + i * 8);
+    *reinterpret_cast<floatx4 *>(out + i * 8) = floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    *reinterpret_cast<floatx4 *>(out + i * 8 + 4) = floatx4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+}
+
+// k-way merge of per-shard top-k lists (each sorted: higher similarity first, lower GLOBAL index first on ties; idx < 0 = empty
+// slot): idx_all / sim_all [shards][n][k] -> [n][k].  One thread per query; shards * k is a few dozen entries.
+__global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t *__restrict__ idx_all, const float *__restrict__ sim_all, int shards, int n, int k,
+                                                        int32_t *__restrict__ idx_out, float *__restrict__ sim_out) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= n) return;
+    // the heads are found by rescanning: entry (s, j) is a candidate iff it comes strictly after the last winner in the result order
+    float lv = INFINITY;
+    int li = -1;
+    for (int o = 0; o < k; ++o) {
+        float bv = -INFINITY;
+        int bi = INT_MAX;
+        for (int s = 0; s < shards; ++s)
+            for (int j = 0; j < k; ++j) {
+                const long e = ((long)s * n + q) * k + j;
+                const int i = idx_all[e];
+                const float v = sim_all[e];
+                if (i < 0) continue;
+                if (!((v < lv) || (v == lv && i > li))) continue;
+                if (better(v, i, bv, bi)) {
+                    bv = v;
+                    bi = i;
+                }
+            }
+        idx_out[(long)q * k + o] = bi == INT_MAX ? -1 : bi;
+        sim_out[(long)q * k + o] = bi == INT_MAX ? -INFINITY : bv;
+        if (bi == INT_MAX) {  // exhausted: the remaining slots are empty too
+            for (int o2 = o + 1; o2 < k; ++o2) {
+                idx_out[(long)q * k + o2] = -1;
+                sim_out[(long)q * k + o2] = -INFINITY;
+            }
+            return;
+        }
+        lv = bv;
+        li = bi;
+    }
+}
+
+template <int NQ, bool FULL, typename GT = float, bool EXCL = false>
 void launch_t(const GT *G, int N, int D, const float *E, int F, MatchPartial *partial, float *out_full, int blocks, int row_offset,
-              hipStream_t s, const int *tile_list = nullptr, const int *d_num_tiles = nullptr) {
+              hipStream_t s, const int *tile_list = nullptr, const int *d_num_tiles = nullptr, const float *prev_sim = nullptr,
+              const int32_t *prev_idx = nullptr, int prev_stride = 1) {
     const int tiles = (N + BM - 1) / BM;
     const size_t lds = (size_t)2 * (BM + NQ * 32) * BK * sizeof(float);
     static bool attr_done[FRT_MAX_DEVICES] = {};
     if (frt_first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<NQ, FULL, GT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<NQ, FULL, GT, EXCL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     dim3 grid(blocks, (F + NQ * 32 - 1) / (NQ * 32));
-    hipLaunchKernelGGL((match_kernel<NQ, FULL, GT>), grid, dim3(256), lds, s, G, N, D, E, F, partial, out_full, tiles, row_offset, tile_list, d_num_tiles);
+    hipLaunchKernelGGL((match_kernel<NQ, FULL, GT, EXCL>), grid, dim3(256), lds, s, G, N, D, E, F, partial, out_full, tiles, row_offset, tile_list, d_num_tiles,
+                       prev_sim, prev_idx, prev_stride);
 }
 
 }  // namespace
@@ -445,7 +579,7 @@ void launch_match_top1(const float *gallery, int N, int D, const float *queries,
         launch_t<2, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
     else
         launch_t<4, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
-    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1);
 }
 
 void launch_match_top1_h(const half_t *g16, int N, int D, const float *queries, int F, MatchPartial *partial, int partial_blocks,
@@ -456,7 +590,7 @@ void launch_match_top1_h(const half_t *g16, int N, int D, const float *queries, 
         launch_t<2, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
     else
         launch_t<4, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
-    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1);
 }
 
 void launch_match_full_h(const half_t *g16, int N, int D, const float *queries, int F, float *out, hipStream_t s) {
@@ -511,6 +645,70 @@ static void launch_coarse_t(const half_t *g16, int N, const half_t *q16, int F, 
     hipLaunchKernelGGL((match_coarse_kernel<D>), g, dim3(256), lds, s, g16, N, q16, F, tilemax, tiles);
 }
 
+// coarse pass + tile selection: leaves the candidate tile list (w.tile_list, length *w.count on the device).  k > 1: the threshold hangs
+// on every query's k-th largest coarse entry (kth_scratch [F] floats).
+static void screen_tiles(const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm, const ScreenScratch &w, int k,
+                         float *kth_scratch, hipStream_t s) {
+    const int tiles = (N + BM - 1) / BM;
+    const long q8 = (long)F * D / 8;
+    const long nzero = (long)tiles + 1;  // tile flags + the candidate count behind them (ScreenScratch: count == tile_flags + tiles)
+    const long n_thr = q8 > nzero ? q8 : nzero;
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, queries, w.q16, q8, w.tile_flags, nzero);
+    switch (D) {
+        case 64: launch_coarse_t<64>(g16, N, w.q16, F, w.tilemax, tiles, s); break;
+        case 128: launch_coarse_t<128>(g16, N, w.q16, F, w.tilemax, tiles, s); break;
+        case 256: launch_coarse_t<256>(g16, N, w.q16, F, w.tilemax, tiles, s); break;
+        default: launch_coarse_t<512>(g16, N, w.q16, F, w.tilemax, tiles, s); break;  // match_screen_supported() gates the callers
+    }
+    if (k > 1) {
+        hipLaunchKernelGGL(match_kth_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles * 4, k, kth_scratch);
+        hipLaunchKernelGGL(match_select_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles, 4, w.segmax, queries, D, gmax_norm, w.tile_flags,
+                           w.tile_list, w.count, kth_scratch);
+    } else {
+        hipLaunchKernelGGL(match_segmax_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles * 4, w.segmax);
+        hipLaunchKernelGGL(match_select_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles, 4, w.segmax, queries, D, gmax_norm, w.tile_flags,
+                           w.tile_list, w.count, (const float *)nullptr);
+    }
+}
+
+// Exact top-k: idx_out / sim_out [F][k], row j of a query = the j-th entry of its exact ranking (higher similarity first, lower global
+// index first among equal similarities; -1 / -inf when the gallery has fewer than k rows).  Pass j is the top-1 search restricted to
+// the rows that come after winner j-1 - the same accumulators, the same first-maximum rule; with a screened gallery the coarse scan
+// runs ONCE (threshold on the k-th largest coarse entry) and only the short exact re-rank is repeated.
+void launch_match_topk(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, int k, bool screen, float gmax_norm,
+                       const ScreenScratch &w, float *kth_scratch, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
+                       int row_offset, hipStream_t s) {
+    if (screen) screen_tiles(g16, N, D, queries, F, gmax_norm, w, k, kth_scratch, s);
+    for (int j = 0; j < k; ++j) {
+        const float *ps = j ? sim_out + (j - 1) : nullptr;
+        const int32_t *pi = j ? idx_out + (j - 1) : nullptr;
+        if (screen) {
+            if (gallery)
+                launch_t<1, false, float, true>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count, ps, pi, k);
+            else
+                launch_t<1, false, half_t, true>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count, ps, pi, k);
+        } else if (gallery) {
+            if (F <= 32) launch_t<1, false, float, true>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k);
+            else launch_t<4, false, float, true>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k);
+        } else {
+            if (F <= 32) launch_t<1, false, half_t, true>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k);
+            else launch_t<4, false, half_t, true>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k);
+        }
+        hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out + j, sim_out + j, k);
+    }
+}
+int match_topk_max() { return TOPK_MAX; }
+
+void launch_half_to_float(const half_t *in, long n, float *out, hipStream_t s) {  // n % 8 == 0
+    hipLaunchKernelGGL(half_to_float_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, in, out, n / 8);
+}
+void launch_float_to_half(const float *in, long n, half_t *out, hipStream_t s) {  // n % 8 == 0
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, in, out, n / 8, (int *)nullptr, 0L);
+}
+void launch_merge_topk(const int32_t *idx_all, const float *sim_all, int shards, int n, int k, int32_t *idx_out, float *sim_out, hipStream_t s) {
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((n + 63) / 64), dim3(64), 0, s, idx_all, sim_all, shards, n, k, idx_out, sim_out);
+}
+
 void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
                                 const ScreenScratch &w, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
                                 int row_offset, hipStream_t s) {
@@ -527,7 +725,7 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
     }
     hipLaunchKernelGGL(match_segmax_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles * 4, w.segmax);
     hipLaunchKernelGGL(match_select_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles, 4, w.segmax, queries, D, gmax_norm, w.tile_flags, w.tile_list,
-                       w.count);
+                       w.count, (const float *)nullptr);
     // exact re-rank over the listed tiles (count lives on the device); the partial scratch is [partial_blocks][F]
     // 32 queries per workgroup (grid.y = query blocks): the list is short (a few hundred tiles), so the pass is bound by the
     // time ONE workgroup needs for a tile - 1024 fp32 MFMAs per wave with 128 queries (27 us), 256 with 32 (7 us).  Same
@@ -536,5 +734,5 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
         launch_t<1, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
     else  // fp16-stored gallery: the exact pass widens the stored rows (same per-tile code path as launch_match_top1_h's full scan)
         launch_t<1, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
-    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1);
 }

@@ -10,6 +10,10 @@ on the data path.  Two exchange patterns exist, both tiny (KiB) and latency-boun
   ``std::max_element`` first-maximum rule of ``ArcFaceIR50::getOutputs`` (/root/reference/src/arcface.cpp:210).
 
 Everything here works on CPU tensors with the ``gloo`` backend too (tests/test_distributed.py, world_size 2).
+
+Since round 3 the DATA-PATH exchanges of ``bench.py`` no longer go through ``torch.distributed``: they are ``ncclAllGather`` calls made by
+``libfrt.so`` itself (``frt_comm_*`` in ``include/frt.h``, :class:`CommGroup` below) - the path a C++ host uses.  ``torch.distributed`` only
+carries the 128-byte communicator id to the ranks and the benchmark's barrier / max-over-ranks bookkeeping.
 """
 import numpy as np
 import torch
@@ -81,3 +85,58 @@ def numpy_top1(emb, gallery_rows, row_offset):
     s = emb.astype(np.float32) @ gallery_rows.astype(np.float32).T
     a = s.argmax(1)
     return (a + row_offset).astype(np.int32), s[np.arange(len(a)), a].astype(np.float32)
+
+
+def numpy_topk(emb, gallery_rows, row_offset, k):
+    """Host stand-in for the device matcher's top-k in CPU tests (same order rule: higher similarity, then LOWER global index)."""
+    n = emb.shape[0]
+    idx = np.full((n, k), -1, np.int32)
+    sim = np.full((n, k), -np.inf, np.float32)
+    if gallery_rows.shape[0] == 0:
+        return idx, sim
+    s = emb.astype(np.float32) @ gallery_rows.astype(np.float32).T
+    order = np.argsort(-s, axis=1, kind="stable")[:, :k]
+    kk = order.shape[1]
+    idx[:, :kk] = order + row_offset
+    sim[:, :kk] = np.take_along_axis(s, order, 1)
+    return idx, sim
+
+
+def sharded_topk(local_idx, local_sim, merge, group=None):
+    """all_gather the per-shard top-k lists [F, k] (global indices) over ``torch.distributed`` and merge them with ``merge`` (the C-ABI
+    ``frt_merge_topk`` through ``frt_amd.merge_topk``); every rank returns the same ([F, k], [F, k])."""
+    world = dist.get_world_size(group)
+    F, k = local_idx.shape
+    gi = torch.empty((world * F, k), dtype=local_idx.dtype, device=local_idx.device)
+    gs = torch.empty((world * F, k), dtype=local_sim.dtype, device=local_sim.device)
+    dist.all_gather_into_tensor(gi, local_idx.contiguous(), group=group)
+    dist.all_gather_into_tensor(gs, local_sim.contiguous(), group=group)
+    return merge(gi.view(world, F, k).cpu().numpy(), gs.view(world, F, k).cpu().numpy())
+
+
+class CommGroup:
+    """One RCCL communicator per rank created through the C ABI (``frt_comm_create``).  The 128-byte id is made on rank 0 and handed to the
+    other ranks by ``broadcast`` (any callable ``bytes | None -> bytes``; bench.py passes a torch.distributed object broadcast, a C++ host
+    would use its own channel).  World size 1 needs no channel."""
+
+    def __init__(self, frt, rank, world, device, broadcast=None):
+        uid = frt.comm_unique_id() if rank == 0 else None
+        if world > 1:
+            if broadcast is None:
+                raise ValueError("CommGroup: world > 1 needs a broadcast callable for the communicator id")
+            uid = broadcast(uid)
+        self.frt, self.rank, self.world = frt, rank, world
+        self.comm = frt.Comm(uid, rank, world, device)
+
+    @property
+    def stream(self):
+        return self.comm.stream
+
+    def all_gather(self, send, recv, hip_stream=None):
+        """send: device tensor of this rank; recv: device tensor of world x send.nbytes; asynchronous on ``hip_stream`` (default: the comm's)."""
+        nbytes = send.numel() * send.element_size()
+        assert recv.numel() * recv.element_size() == nbytes * self.world
+        self.comm.all_gather(send.data_ptr(), recv.data_ptr(), nbytes, hip_stream)
+
+    def close(self):
+        self.comm.close()

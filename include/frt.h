@@ -100,6 +100,14 @@ int frt_embedder_create(const char *weights_path, int in_c, int in_h, int in_w, 
                         frt_embedder **out);
 void frt_embedder_destroy(frt_embedder *e);
 
+/* IR-SE-50 only (no reference counterpart; the reference's engine is a black box): 1 (default, env FRT_SE_FUSED=0 turns it off) runs the
+ * squeeze-and-excitation tail of a unit inside conv2's epilogue, where the workgroups of one face hand their partial channel sums
+ * over through device-scope stores and a flag; 0 always uses the stand-alone pool + gate + apply launches (no cross-workgroup wait
+ * anywhere).  Results are bit-identical.  A timed-out hand-over never kills the HIP context: the next synchronising call on the
+ * embedder / pipeline returns FRT_ERR_DEVICE and this switch is the way back.  Takes effect for passes enqueued after the call; a
+ * pipeline with hipGraph replay on must be told to re-capture (frt_pipeline_set_graph). */
+int frt_embedder_set_se_fused(frt_embedder *e, int enable);
+
 /* ArcFaceIR50::preprocessFace (src/arcface.cpp:105-114): u8 BGR [in_h][in_w][3] -> float32 planar RGB. */
 int frt_embedder_preprocess_face(frt_embedder *e, const uint8_t *bgr_crop, float *chw_out);
 /* ArcFaceIR50::doInference, both overloads (src/arcface.cpp:131-148): float32 [batch][3][112][112] -> [batch][512]
@@ -156,6 +164,49 @@ int frt_matcher_set_row_offset(frt_matcher *m, int row_offset);
 int frt_merge_top1(int n, const int32_t *idx_a, const float *sim_a, const int32_t *idx_b, const float *sim_b, int32_t *idx_out,
                    float *sim_out);
 
+/* Exact top-k (BASELINE configs[4]: "fp16 embeddings, RCCL top-k all-gather"; the reference itself only ever takes the first maximum,
+ * src/arcface.cpp:203-217, which is k = 1).  idx_out / sim_out are [embed_count][k]: entry j of a query is the j-th row of its exact
+ * ranking - higher similarity first, LOWER (global) index first among equal similarities, i.e. entry 0 is frt_matcher_top1's answer bit
+ * for bit and entry j is "std::max_element over the rows not yet taken".  Fewer than k rows: idx -1, sim -inf in the unused slots.
+ * 1 <= k <= 16. */
+int frt_matcher_topk(frt_matcher *m, const float *embeds, int embed_count, int k, int32_t *idx_out, float *sim_out);
+/* Device-resident form, asynchronous on hip_stream.  embeds_fp16 = 0: queries fp32 [n][num_col]; 1: queries IEEE fp16 [n][num_col] - what
+ * the embedding exchange of configs[4] delivers (frt_embeds_to_half_dev + all-gather); they are widened exactly, so the similarities are
+ * the fp32 dot products of the fp16-rounded embeddings with the stored rows. */
+int frt_matcher_topk_dev(frt_matcher *m, const void *embeds_dev, int embeds_fp16, int embed_count, int k, void *idx_dev, void *sim_dev, void *hip_stream);
+/* k-way merge of per-shard top-k lists with GLOBAL indices (frt_matcher_set_row_offset), idx_all / sim_all [shards][n][k] -> [n][k]:
+ * same order rule as above (the lower global index wins a tie - the first-maximum rule carried across shards); idx < 0 = empty slot. */
+int frt_merge_topk(int shards, int n, int k, const int32_t *idx_all, const float *sim_all, int32_t *idx_out, float *sim_out);
+int frt_merge_topk_dev(int shards, int n, int k, const void *idx_all_dev, const void *sim_all_dev, void *idx_out_dev, void *sim_out_dev, void *hip_stream);
+/* fp32 -> IEEE fp16 (round to nearest even) of n_values (a multiple of 8) device floats: the embeddings before they are exchanged. */
+int frt_embeds_to_half_dev(const void *embeds_dev, size_t n_values, void *half_out_dev, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange.  The reference is one single-GPU C++ process (src/app.cpp:52-57, 367); north_star shards whole
+ * frames over the GPUs of a node with an RCCL all-gather as the only exchange step.  These calls are that step for a C++ host: RCCL
+ * (bound at run time from librccl.so.1) behind plain pointers.  One communicator per device - one process per GPU (get_unique_id on
+ * rank 0, hand the 128 bytes to the other ranks by any means, frt_comm_create everywhere), or one process driving several devices
+ * (frt_comm_create_all + one thread per device, or frt_comm_all_gather_multi from one thread).  Create communicators AFTER the
+ * pipelines of the device (they own a stream; see frt_pipeline_check_overlap).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define FRT_COMM_ID_BYTES 128
+typedef struct frt_comm frt_comm;
+int frt_comm_get_unique_id(uint8_t *id_out /* [FRT_COMM_ID_BYTES] */);
+int frt_comm_create(const uint8_t *id, int rank, int world, int device, frt_comm **out);
+int frt_comm_create_all(int n_devices, const int *devices, frt_comm **out /* [n_devices] */);
+void frt_comm_destroy(frt_comm *c);
+int frt_comm_rank(const frt_comm *c);
+int frt_comm_world(const frt_comm *c);
+/* the communicator's own exchange stream (a hipStream_t as void*) */
+void *frt_comm_stream(frt_comm *c);
+/* recv_dev [world][bytes_per_rank] <- every rank's send_dev [bytes_per_rank]; asynchronous on hip_stream (NULL: the communicator's
+ * stream).  What travels: frt_face_result records (configs[3]), fp16 embeddings and (idx, sim) top-k lists (configs[4]). */
+int frt_comm_all_gather(frt_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *hip_stream);
+/* the same collective for n communicators of ONE process issued from one thread (ncclGroupStart / End around the n calls) */
+int frt_comm_all_gather_multi(int n, frt_comm *const *comms, const void *const *send_dev, void *const *recv_dev, size_t bytes_per_rank,
+                              void *const *hip_streams);
+int frt_comm_sync(frt_comm *c);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Batched device-resident pipeline (new surface; the /inference call stack of src/app.cpp:304-310 for B frames at once,
  * without host round trips between the stages).
@@ -196,6 +247,14 @@ int frt_pipeline_run_dev_after(frt_pipeline *p, const void *frames_dev, int n_fr
  * event on that stream and the stages wait for it.  Correct by construction, but the pipeline stream also carries the joins of the
  * previous calls, so consecutive calls no longer overlap - prefer frt_pipeline_run_dev_after with a separate upload stream. */
 int frt_pipeline_set_input_sync(frt_pipeline *p, int enable);
+/* Stream-overlap self-check.  The three stages only overlap across calls when the pipeline's stage streams - and the caller's stream,
+ * which carries the joins - sit on different hardware queues (ROCm maps streams round-robin onto 4 queues per priority level; a queue
+ * runs in order).  This call MEASURES it: one 150 us single-wave probe kernel per stream, started together; *ratio_out = elapsed /
+ * 150 us, about 1 when they run side by side, about n when n of them share a queue.  Above 1.5 the call still returns FRT_OK but
+ * frt_last_error() holds a warning (also printed to stderr once unless FRT_QUIET is set) naming the remedy.  The same check runs over
+ * the stage streams alone inside frt_pipeline_create (about 1 ms; env FRT_PIPELINE_SELFCHECK=0 skips it); call this one after
+ * frt_pipeline_set_stream and after every other stream of the process (RCCL, copy streams) exists.  Waits for work in flight. */
+int frt_pipeline_check_overlap(frt_pipeline *p, float *ratio_out);
 int frt_pipeline_sync(frt_pipeline *p);
 /* Run on a caller-owned HIP stream (a hipStream_t passed as void*, e.g. PyTorch's current stream, so that RCCL collectives
  * issued by the caller are ordered after the pipeline without a host synchronisation).  NULL restores the private stream. */
@@ -253,6 +312,11 @@ int frt_jpeg_read_coefficients(const uint8_t *data, size_t size, int16_t *coef_o
  * IMWRITE_JPEG_QUALITY (the reference uses the default, 95). */
 int frt_jpeg_encode_batch(frt_jpeg_decoder *d, const void *bgr, int device_input, int n, int rows, int cols, int quality, uint8_t *out, size_t out_stride,
                           size_t *out_sizes);
+/* Same, ordered behind an asynchronous producer of a DEVICE input: ready_event is a hipEvent_t (as void*, NULL = none) the caller
+ * recorded after the work that writes `bgr` (a pipeline stage, another stream's forward ...); the codec's stream waits for it on the
+ * device.  frt_jpeg_encode_batch itself only orders against work the caller has already synchronised. */
+int frt_jpeg_encode_batch_after(frt_jpeg_decoder *d, const void *bgr, int device_input, int n, int rows, int cols, int quality, uint8_t *out,
+                                size_t out_stride, size_t *out_sizes, void *ready_event);
 /* host half only: quantised blocks in zigzag order (all luma blocks [2*mcuy][2*mcux], then Cb, then Cr [mcuy][mcux]) -> JFIF stream */
 int frt_jpeg_write_jfif(int quality, int width, int height, const int16_t *coef_zigzag, uint8_t *out, size_t capacity, size_t *size_out);
 /* crow::utility::base64encode (src/app.cpp:331): standard alphabet with '=' padding, NUL-terminated.  Returns the string length, or

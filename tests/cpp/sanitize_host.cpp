@@ -35,6 +35,39 @@ int main(int argc, char **argv) {
             std::vector<uint8_t> t(good.begin(), good.begin() + cut);
             rejected += try_jpeg(t) != 0;
         }
+        // targeted DHT damage (round-2 advisor finding): the code-length COUNTS are rewritten so that the segment length and the
+        // 256-symbol total stay consistent - random byte damage almost never does that - with over-subscribed, all-ones and
+        // count-swapped tables.  parse() must reject what violates the Kraft limit before HuffTable::build() runs.
+        for (size_t q = 2; q + 4 < good.size(); ++q) {
+            if (good[q] != 0xFF || good[q + 1] != 0xC4) continue;
+            const size_t len = ((size_t)good[q + 2] << 8) | good[q + 3], tab = q + 4;  // first table of the segment
+            if (len < 19 || tab + 17 > good.size()) continue;
+            int total = 0;
+            for (int l = 1; l <= 16; ++l) total += good[tab + l];
+            for (int variant = 0; variant < 40; ++variant) {
+                std::vector<uint8_t> t = good;
+                uint8_t *bits = t.data() + tab;  // bits[1..16]
+                if (variant == 0) {              // everything on length 1: 2^1 codes cannot hold `total` symbols
+                    for (int l = 2; l <= 16; ++l) bits[l] = 0;
+                    bits[1] = (uint8_t)(total > 255 ? 255 : total);
+                } else if (variant == 1) {       // the advisor's reproducer shape: bits[1] = 255
+                    bits[1] = 255;
+                } else if (variant == 2) {       // all ones (16 symbols, valid Kraft sum) - must not crash either way
+                    for (int l = 1; l <= 16; ++l) bits[l] = 1;
+                } else if (variant < 20) {       // swap two counts (total unchanged)
+                    const int a = 1 + rng() % 16, b = 1 + rng() % 16;
+                    std::swap(bits[a], bits[b]);
+                } else {                         // move symbols towards the short lengths (total unchanged)
+                    const int from = 5 + rng() % 12, to = 1 + rng() % 4;
+                    const int n = bits[from];
+                    if (bits[to] + n <= 255) {
+                        bits[to] = (uint8_t)(bits[to] + n);
+                        bits[from] = 0;
+                    }
+                }
+                rejected += try_jpeg(t) != 0;
+            }
+        }
         for (int k = 0; k < 400; ++k) {  // random byte / bit damage anywhere, headers included
             std::vector<uint8_t> t = good;
             const int n = 1 + rng() % 6;

@@ -58,7 +58,16 @@ def _worker(rank, world, port, q):
     dist.all_gather(others, torch.from_numpy(ls))
     mi, ms = frt.merge_top1(other[0].numpy(), others[0].numpy(), other[1].numpy(), others[1].numpy())
     ok3 = mi.tolist() == gi.tolist() and np.array_equal(ms, gs.numpy())
-    q.put((rank, ok1, ok2, ok3))
+    # --- configs[4] as written: fp16 embeddings exchanged, per-shard top-k lists gathered and merged (frt_merge_topk) == the ranking over
+    #     the whole gallery; duplicates in different shards come out "lower global index first"
+    from oracle import match
+    k = 5
+    q16 = q_all.astype(np.float16).astype(np.float32)             # what travels
+    ti, ts = fd.numpy_topk(q16, gal[gb:ge], gb, k)
+    mi, ms = fd.sharded_topk(torch.from_numpy(ti), torch.from_numpy(ts), frt.merge_topk)
+    wi, ws = match.topk(q16, gal, k)
+    ok4 = np.array_equal(mi, wi) and np.allclose(ms, ws, atol=1e-6) and mi[0, :2].tolist() == [3, 900] and mi[2, :2].tolist() == [499, 500]
+    q.put((rank, ok1, ok2, ok3 and ok4))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -110,3 +110,23 @@ def test_batch_of_32_equals_frame_by_frame(frt, synth, blobs):
         assert np.array_equal(loc32[i], loc1[0]) and np.array_equal(conf32[i], conf1[0]), i
     det32.close()
     det1.close()
+
+
+@pytest.mark.parametrize("geo,frames,max_differing", [("640x640->640x640", 256, 0), ("640x480->320x288", 256, 1)])
+def test_box_census(frt, blobs, geo, frames, max_differing):
+    """The box-flip census (tools/box_census.py) as a test: findFace on the GPU against the fp32 oracle +
+    oracle/postproc.c on 256 synthetic frames per geometry, 1 024 boxes / 4 096 coordinates each.  Expected (profiles/r02_box_census.json,
+    512 frames): no differing coordinate at 640x640, ONE at 320x288 (an `int` truncation of a float that differs in its last bits,
+    src/retinaface.cpp:171-187) - never a different box count, never more than one detector-input pixel."""
+    import importlib.util
+    import os
+
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("box_census", os.path.join(ROOT, "tools", "box_census.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    dpath, dsd = blobs("det")
+    r = bc.census(frt, dsd, dpath, bc.GEOMETRIES[geo], frames)
+    assert r["boxes"] >= frames * 3 and r["frames_with_different_box_count"] == 0, r
+    assert r["coordinates_differing"] <= max_differing and r["max_abs_diff_px"] <= 2, r
+    assert r["max_abs_score_diff"] < 1e-5, r

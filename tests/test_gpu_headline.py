@@ -122,3 +122,112 @@ def test_1080p_frames_end_to_end_against_the_oracle(frt, orc, synth, blobs):
     pipe.close()
     det.close()
     rec.close()
+
+
+def test_ir_se_through_the_pipeline_against_the_oracle(frt, orc, synth, blobs):
+    """IR-SE-50 (the network north_star names) through frt_pipeline_submit / wait with three batches in flight - every slot, both
+    activation sets, the fused SE epilogue with its cross-workgroup hand-over under co-running passes - against the fp32 oracle run
+    stage by stage, planted gallery rows; then the same batches with the stand-alone SE tail (frt_embedder_set_se_fused(e, 0)): byte-identical."""
+    import torch
+    dpath, dsd = blobs("det")
+    rpath, rsd = blobs("ir_se")
+    B, K, H, W, N = 8, 4, 640, 640, 200_000
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    batch_a, batch_b = synth.make_frames(B, H, W, start=200), synth.make_frames(B, H, W, start=300)
+    picked = {"a": (0, 7), "b": (3,)}
+    gal = synth.make_gallery(N)
+    want, slot = {}, 777
+    for tag, frames in (("a", batch_a), ("b", batch_b)):
+        for f in picked[tag]:
+            boxes, emb = oracle_frame(orc, dsd, rsd, frames[f], H, W, K)
+            assert len(boxes) == K
+            slots = slot + 4099 * np.arange(K)
+            gal[slots] = emb
+            want[(tag, f)] = (boxes, emb, slots)
+            slot += 50021
+    rec.setGallery(gal)
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    order = ["a", "b", "a", "b", "a", "a", "b", "a"]  # >= 8 batches: every slot / activation set / staging set is reused
+    pinned = {"a": torch.from_numpy(batch_a).pin_memory(), "b": torch.from_numpy(batch_b).pin_memory()}
+
+    def run_all():
+        res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in order]
+        emb = [torch.zeros(B * K, 512).pin_memory() for _ in order]
+        tickets = []
+        for i, tag in enumerate(order):
+            if len(tickets) >= 3:
+                pipe.wait(tickets[i - 3])
+            tickets.append(pipe.submit(pinned[tag].numpy(), res[i].numpy().view(frt.RESULT_DTYPE), emb[i].numpy()))
+        for t in tickets:
+            pipe.wait(t)
+        return [r.numpy().view(frt.RESULT_DTYPE).copy() for r in res], [e.numpy().copy() for e in emb]
+
+    res, emb = run_all()
+    exact = total = 0
+    for i, tag in enumerate(order):
+        assert res[i]["valid"].all()
+        for f in picked[tag]:
+            boxes, oemb, slots = want[(tag, f)]
+            exact += check_faces(res[i], emb[i], f, K, boxes, oemb, slots)
+            total += K
+        j = order.index(tag)
+        assert np.array_equal(res[i], res[j]) and np.array_equal(emb[i], emb[j]), i  # same bytes wherever the batch sat in the pipeline
+    assert exact >= total - 2, (exact, total)
+    rec.setSeFused(False)  # stand-alone pool + gate + apply launches: the same arithmetic
+    res2, emb2 = run_all()
+    for i in range(len(order)):
+        assert np.array_equal(res2[i], res[i]) and np.array_equal(emb2[i], emb[i]), i
+    rec.setSeFused(True)
+    pipe.close()
+    det.close()
+    rec.close()
+
+
+def test_config0_one_jpeg_ir_se_two_face_gallery(frt, orc, synth, blobs):
+    """BASELINE configs[0]: a single 640x640 jpg -> RetinaFace-mnet0.25 -> ArcFace IR-SE50 -> 2-face gallery, through the reference's own
+    call sequence (src/app.cpp:296-310: imdecode, findFace, forward, featureMatching, getOutputs) vs the oracle on the same bytes."""
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import match, nets
+    dpath, dsd = blobs("det")
+    rpath, rsd = blobs("ir_se")
+    K, H, W = 4, 640, 640
+    b = io.BytesIO()
+    Image.fromarray(synth.make_frame(4242, H, W)[..., ::-1]).save(b, "JPEG", quality=90, subsampling=2)
+    jpg = b.getvalue()
+    # oracle side: libjpeg(-turbo) decode (what cv::imdecode wraps), then the CPU restatement stage by stage
+    oframe = np.ascontiguousarray(np.array(Image.open(io.BytesIO(jpg)))[..., ::-1])
+    oboxes, oemb = oracle_frame(orc, dsd, rsd, oframe, H, W, K)
+    assert len(oboxes) >= 2
+    gallery = np.stack([oemb[1], oemb[0]])  # the "2-face gallery": two enrolled identities
+    names = ["bob", "alice"]
+    # product side
+    codec = frt.JpegCodec(max_images=1, max_width=W, max_height=H)
+    frame = codec.decode(jpg)
+    assert np.array_equal(frame, oframe)
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), 1, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=1, maxFacesPerScene=K)  # rec_maxBatchSize 1: the reference's default (config.json:18)
+    rec.initKnownEmbeds(2)
+    for n, e in zip(names, gallery):
+        rec.addEmbedding(n, e)
+    rec.initMatMul()
+    boxes = det.findFace(frame)
+    assert len(boxes) == len(oboxes)
+    for c in ("x1", "y1", "x2", "y2"):
+        assert np.array_equal(boxes[c], oboxes[c]), c
+    emb = rec.forward(frame, boxes)
+    cos = (emb * oemb).sum(1)
+    assert cos.min() > 1 - COS_TOL, cos
+    sims = rec.featureMatching()                    # the full [F, 2] matrix, as MatMul::calculate returns it
+    got_names, got_sims = rec.getOutputs(sims)
+    osim = match.similarity(emb, gallery)
+    assert sims.shape == (len(boxes), 2) and np.abs(sims - osim).max() < 1e-5
+    oi, _ = match.top1(oemb, gallery)
+    assert got_names == [names[i] for i in oi]
+    assert got_names[0] == "alice" and got_names[1] == "bob" and got_sims[0] > 0.9999 and got_sims[1] > 0.9999
+    assert rec.matchTop1()[0] == got_names
+    codec.close()
+    det.close()
+    rec.close()
