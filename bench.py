@@ -298,7 +298,10 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     pipe.set_stream(stream.cuda_stream)
-    side = torch.cuda.ExternalStream(cg.stream) if use_dist else None   # the communicator's own stream: H2D of the records, ncclAllGather, D2H
+    # the exchange stream: H2D of the records, ncclAllGather, D2H.  A torch-owned stream handed to frt_comm_all_gather (a C++ host would use
+    # the communicator's own, frt_comm_stream): torch's pinned-memory allocator records events on every stream a pinned block was used
+    # on when the block is freed, so the stream must outlive the tensors - which a stream owned by the communicator would not at exit
+    side = torch.cuda.Stream() if use_dist else None
     ev_side = [torch.cuda.Event() for _ in range(NRING)] if use_dist else None
     gather = use_dist and not args.no_gather
 

@@ -72,6 +72,9 @@ ABI = {
     "frt_matcher_top1_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "frt_matcher_calculate": (_i, [_vp, _vp, _i, _vp]),
     "frt_matcher_top1": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "frt_matcher_calculate_top1": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "frt_pinned_alloc": (_i, [_sz, _i, ctypes.POINTER(_vp)]),
+    "frt_pinned_free": (None, [_vp]),
     "frt_merge_top1": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frt_matcher_topk": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "frt_matcher_topk_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -218,6 +221,15 @@ class MatMul:
         out = np.empty((n, self.m), np.float32)
         _check(lib.frt_matcher_calculate(self._h, _ptr(e), int(n), _ptr(out)))
         return out
+
+    def calculate_top1(self, embeds, materialize=True):
+        """calculate + row-wise first maximum in one call -> (matrix [n, m] or None, idx [n], sim [n])."""
+        e = np.ascontiguousarray(embeds, np.float32).reshape(-1, self.k)
+        out = np.empty((e.shape[0], self.m), np.float32) if materialize else None
+        idx = np.empty(e.shape[0], np.int32)
+        sim = np.empty(e.shape[0], np.float32)
+        _check(lib.frt_matcher_calculate_top1(self._h, _ptr(e), e.shape[0], _ptr(out), _ptr(idx), _ptr(sim)))
+        return out, idx, sim
 
     def top1(self, embeds):
         e = np.ascontiguousarray(embeds, np.float32).reshape(-1, self.k)
@@ -444,7 +456,7 @@ class ArcFaceIR50:
         self._embeds = np.zeros((0, self.outputDim), np.float32)
 
     def setSeFused(self, enable):
-        """IR-SE only: SE tail inside conv2's epilogue (default) or as stand-alone launches; bit-identical results."""
+        """IR-SE only: SE tail inside conv2's epilogue (default) or as stand-alone launches (equal to float rounding)."""
         _check(lib.frt_embedder_set_se_fused(self._h, 1 if enable else 0))
 
     def preprocessFace(self, face):

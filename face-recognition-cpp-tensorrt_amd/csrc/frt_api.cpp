@@ -508,6 +508,7 @@ struct ArcUnit {
     half_t *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;
     half_t *w1f = nullptr, *w2f = nullptr;  // fragment-ordered copies for the strip kernel (stride-1 3x3 convs)
     half_t *w2f2 = nullptr;                 // ... for the stride-2 strip kernel (conv2 of the first unit of a stage)
+    half_t *wscf = nullptr;                 // 1x1 shortcut weights in fragment order (the stride-2 strip kernel computes the shortcut conv itself)
     float *prelu = nullptr, *s2 = nullptr, *b2 = nullptr, *ssc = nullptr, *bsc = nullptr;
     float *sn = nullptr, *bn = nullptr;  // BatchNorm that consumes this unit's output (next unit's leading BN / output_layer.0)
     float *se_w1 = nullptr, *se_w2 = nullptr;
@@ -537,6 +538,7 @@ struct frt_embedder {
     half_t *Y[2], *Z[2], *T, *SC, *RES = nullptr, *zeros = nullptr;
     float *fc_partial, *d_out, *se_pool = nullptr, *se_gate = nullptr;
     int se_epoch = 0;  // launch counter of the fused SE tails (their gate-ready flags carry the launch number)
+    bool sc_fusion = true;       // IR-50: 1x1 stride-2 shortcut convs inside the stride-2 strip kernel (tuning build: FRT_SC_FUSED=0 restores the launches)
     bool se_fused = true;        // IR-SE: run the SE tail inside conv2's epilogue where the strip kernels allow it (FRT_SE_FUSED=0 /
                                  // frt_embedder_set_se_fused(e, 0): always the stand-alone pool + gate + apply launches)
     int *h_se_error = nullptr;   // error word of the fused tail's cross-workgroup hand-over (pinned, mapped; 0 = fine)
@@ -615,6 +617,19 @@ std::vector<uint16_t> conv_w_f16_frag(const frt::Blob &b, const std::string &nam
             }
     return w;
 }
+// 1x1 shortcut weights [Cout][Cin] in the stride-2 strip kernel's fragment order [Cout/32][Cin/64][kk][lane = (k half, cout row)][8]
+std::vector<uint16_t> conv1x1_w_f16_frag(const frt::Blob &b, const std::string &name, int cout, int cin) {
+    if (cin % 64 || cout % 32) return {};
+    const float *src = b.get(name, (size_t)cout * cin).data;
+    std::vector<uint16_t> w((size_t)cout * cin);
+    const int nch = cin / 64;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci) {
+            const int blk = co >> 5, r = co & 31, ch = ci >> 6, kk = (ci & 63) >> 4, hi = (ci & 15) >> 3, e = ci & 7;
+            w[(((((size_t)blk * nch + ch) * 4 + kk) * 64) + hi * 32 + r) * 8 + e] = frt::f32_to_f16(src[(size_t)co * cin + ci]);
+        }
+    return w;
+}
 std::vector<float> vec_of(const frt::Blob &b, const std::string &name, size_t n) {
     const float *p = b.get(name, n).data;
     return std::vector<float>(p, p + n);
@@ -672,6 +687,8 @@ void frt_embedder::build(const frt::Blob &b) {
             a.b2 = arena.upload(bi);
             if (a.cin != a.depth) {
                 a.wsc = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".shortcut_layer.0.weight", a.depth, a.cin, 1)));
+                const std::vector<uint16_t> fs = conv1x1_w_f16_frag(b, p + ".shortcut_layer.0.weight", a.depth, a.cin);
+                if (!fs.empty()) a.wscf = reinterpret_cast<half_t *>(arena.upload(fs));
                 frt::bn_fold(b, p + ".shortcut_layer.1", a.depth, sc, bi);
                 a.ssc = arena.upload(sc);
                 a.bsc = arena.upload(bi);
@@ -709,6 +726,10 @@ void frt_embedder::build(const frt::Blob &b) {
         bn_s = arena.upload(sc);
         bn_b = arena.upload(bi);
         flops_per_face += 2.0 * 25088 * 512;
+    }
+    {
+        const char *sf = frt_tuning_env("FRT_SC_FUSED");
+        sc_fusion = !(sf && sf[0] == '0');
     }
     const size_t F = (size_t)max_batch;
     const size_t big = F * 112 * 112 * 64;
@@ -789,7 +810,18 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             sc_h = ho;
             sc_stride = 1;
         }
-        if (u.wsc) {  // conv1x1 stride s + BN on the raw input
+        // IR-50: the stride-2 strip kernel computes the 1x1 stride-2 shortcut conv itself (its input pixels are the (even, even) phase
+        // plane) - no launch, no shortcut tensor.  IR-SE keeps the tensor: the gate multiplies the residual branch only.
+        bool sc_fused = false;
+        if (u.wsc && u.wscf && !se && u.stride == 2 && sc_fusion) {
+            ConvMfmaArgs t{};
+            t.x = T; t.w = u.w2; t.wf2 = u.w2f2;
+            t.B = F; t.H = h; t.W = h; t.Cin = u.depth; t.Ho = ho; t.Wo = ho; t.Cout = u.depth; t.ks = 3; t.stride = 2; t.pad = 1;
+            t.mode = EPI_BN_ADD_BN; t.splits = 1;
+            t.scx = Y[cur]; t.wscf = u.wscf; t.psc0 = u.ssc; t.psc1 = u.bsc; t.Csc = u.cin;
+            sc_fused = conv_s2_applies(t);
+        }
+        if (u.wsc && !sc_fused) {  // conv1x1 stride s + BN on the raw input
             ConvMfmaArgs a{};
             a.x = Y[cur];
             a.w = u.wsc;
@@ -821,6 +853,10 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             a.p3 = u.bn;
             a.sc = sc_t;
             a.sc_h = sc_h; a.sc_w = sc_h; a.sc_stride = sc_stride;
+            if (sc_fused) {
+                a.sc = nullptr;
+                a.scx = Y[cur]; a.wscf = u.wscf; a.psc0 = u.ssc; a.psc1 = u.bsc; a.Csc = u.cin;
+            }
             a.out0 = Y[cur ^ 1];
             a.out1 = Z[cur ^ 1];
             bool se_tail = false;  // IR-SE: the SE tail as separate launches behind conv2
@@ -849,7 +885,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
                 }
             }
             {
-                ProfScope pk(1, conv_kernel_label(a), 2.0 * 9 * u.depth * u.depth * (double)F * ho * ho, s);
+                ProfScope pk(1, conv_kernel_label(a), (2.0 * 9 * u.depth * u.depth + (sc_fused ? 2.0 * u.cin * u.depth : 0.0)) * (double)F * ho * ho, s);
                 launch_conv_mfma(a, s);
             }
             if (se_tail) {
@@ -1994,6 +2030,54 @@ int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, 
         HIPCHK(hipMemcpyAsync(outputs, m->d_full, need * sizeof(float), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     });
+}
+
+int frt_matcher_calculate_top1(frt_matcher *m, const float *embeds, int embed_count, float *outputs, int32_t *idx_out, float *sim_out) {
+    return guarded([&] {
+        if (!m || !embeds || !idx_out || !sim_out) raise(FRT_ERR_INVALID, "calculate_top1: null argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (m->N <= 0 || embed_count <= 0) raise(FRT_ERR_EMPTY, "Feature matching: No faces in database or no faces found");
+        use_device(m->device);
+        hipStream_t s = m->stream;
+        m->wait_idle(s);
+        m->ensure_queries(embed_count);
+        HIPCHK(hipMemcpyAsync(m->d_q, embeds, sizeof(float) * (size_t)embed_count * m->D, hipMemcpyHostToDevice, s));
+        if (outputs) {
+            const size_t need = (size_t)embed_count * m->N;
+            if (need > m->full_cap) {
+                if (m->d_full) (void)hipFree(m->d_full);
+                m->d_full = nullptr;
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_full), need * sizeof(float)));
+                m->full_cap = need;
+            }
+            for (int f0 = 0; f0 < embed_count; f0 += 128) {
+                const int nf = std::min(128, embed_count - f0);
+                if (m->store16)
+                    launch_match_full_h(m->d_g16, m->N, m->D, m->d_q + (size_t)f0 * m->D, nf, m->d_full + (size_t)f0 * m->N, s);
+                else
+                    launch_match_full(m->d_gallery, m->N, m->D, m->d_q + (size_t)f0 * m->D, nf, m->d_full + (size_t)f0 * m->N, s);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(outputs, m->d_full, need * sizeof(float), hipMemcpyDeviceToHost, s));  // (the top-1 search below runs under this copy's tail)
+        }
+        m->top1_dev(m->d_q, embed_count, m->d_idx, m->d_sim, s);
+        HIPCHK(hipMemcpyAsync(idx_out, m->d_idx, sizeof(int32_t) * embed_count, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(sim_out, m->d_sim, sizeof(float) * embed_count, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    });
+}
+
+int frt_pinned_alloc(size_t bytes, int device, void **out) {
+    return guarded([&] {
+        if (!out) raise(FRT_ERR_INVALID, "null argument");
+        *out = nullptr;
+        if (device >= 0) use_device(device);
+        HIPCHK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    });
+}
+
+void frt_pinned_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int frt_matcher_top1(frt_matcher *m, const float *embeds, int embed_count, int32_t *idx_out, float *sim_out) {

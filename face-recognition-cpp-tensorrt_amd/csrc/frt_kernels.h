@@ -176,6 +176,11 @@ struct ConvMfmaArgs {
     const float *p0, *p1, *p2, *p3;
     const half_t *sc;  // shortcut tensor [B][sc_h][sc_w][Cout], sampled at (oh*sc_stride, ow*sc_stride)
     int sc_h, sc_w, sc_stride;
+    // fused 1x1 stride-2 shortcut CONVOLUTION (stride-2 strip kernel, mode EPI_BN_ADD_BN, instead of `sc`): out = BN(conv3x3(x)) + BNsc(conv1x1_s2(scx))
+    const half_t *scx;   // the unit's raw input [B][H][W][Csc]; null: shortcut tensor `sc`
+    const half_t *wscf;  // 1x1 weights in fragment order [Cout/32][Csc/64][4 kk][64 lanes][8]
+    const float *psc0, *psc1;  // the shortcut's folded BatchNorm
+    int Csc;
     half_t *out0, *out1;
     float *outf;       // EPI_PARTIAL: [splits][M][Cout]
     int splits;

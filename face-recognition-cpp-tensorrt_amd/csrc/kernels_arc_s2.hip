@@ -36,7 +36,12 @@ __device__ constexpr int kLen[4] = {4, 1, 2, 2};   // steps per plane
 __device__ constexpr int kRowPar[4] = {1, 0, 1, 0};  // plane -> input row parity (1: odd rows 2*i - 1, 0: even rows 2*i)
 __device__ constexpr int kColPar[4] = {1, 0, 0, 1};
 
-template <int NT, int PP, bool SEP = false>  // NT pixel tiles per strip; PP = LDS-DMA pieces (1 KB per wave) per thread per plane; SEP: IR-SE tail in the epilogue
+// SCF: the unit's 1x1 stride-2 shortcut convolution (model_irse.py:52-54: Conv2d(in, depth, (1, 1), stride) + BatchNorm2d on the unit's RAW
+// input) computed HERE instead of by a launch of its own: its input pixels x[2 oy][2 ox] are exactly the (even, even) phase plane, so
+// when the last chunk of the 3x3 loop releases the four plane buffers they are refilled with the (even, even) planes of the shortcut's
+// (up to four) 64-channel chunks - the DMAs that used to fetch zeros at the tail - and 4 MFMAs per chunk and pixel tile into a second
+// accumulator set follow the main loop.  The shortcut tensor's HBM round trip (write + read, fp16-rounded) and a launch disappear.
+template <int NT, int PP, bool SEP = false, bool SCF = false>  // NT pixel tiles per strip; PP = LDS-DMA pieces (1 KB per wave) per thread per plane; SEP: IR-SE tail in the epilogue
 __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
     constexpr int PLANE_B = PP * 4096;
     constexpr int LA = 2, WR = 3, BFD = 2;
@@ -75,6 +80,24 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
                 if (b < p.B && y >= 0 && y < H && x >= 0 && x < W) poff[s][q] = ((b * H + y) * W + x) * p.Cin + pos * 8;
             }
         }
+    // shortcut planes: the (even, even) geometry on the shortcut conv's input tensor [B][H][W][Csc]
+    const int n_sc = SCF ? (p.Csc >> 6) : 0;  // 64-channel chunks: 1, 2 or 4 (<= the four plane buffers)
+    int poff_sc[SCF ? PP : 1];
+    if constexpr (SCF) {
+#pragma unroll
+        for (int q = 0; q < PP; ++q) {
+            const int g = (q * 4 + wave) * 64 + lane;
+            const int px = g / 9, pos = g - px * 9;
+            poff_sc[q] = -1;
+            if (pos < 8 && px < NPp) {
+                const int il = px / ((R + 1) * Wq);
+                const int rem = px - il * ((R + 1) * Wq);
+                const int i = rem / Wq, j = rem - i * Wq;
+                const int y = 2 * (oy0 + i), x = 2 * j, b = img0 + il;
+                if (b < p.B && y < H && x < W) poff_sc[q] = ((b * H + y) * W + x) * p.Csc + pos * 8;
+            }
+        }
+    }
     const half_t *wfrag = p.wf + ((long)((co_base + cow) >> 5) * n_chunks) * (9 * 4 * 512) + lane * 8;
     int pbase[NT];
 #pragma unroll
@@ -106,6 +129,9 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
 #pragma unroll
         for (int q = 0; q < PP; ++q) {
             const half_t *src = (real && poff[S][q] >= 0) ? p.x + (unsigned)(poff[S][q] + (c << 6)) : p.zeros;
+            if constexpr (SCF) {  // behind the last chunk: buffer S takes the (even, even) plane of shortcut chunk S
+                if (!real && S < n_sc && poff_sc[q] >= 0) src = p.scx + (unsigned)(poff_sc[q] + (S << 6));
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(pl + q * 4096), 16, 0, 0);
         }
@@ -180,7 +206,35 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
         step(c, std::integral_constant<int, 7>{});
         step(c, std::integral_constant<int, 8>{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's dummy DMAs still target LDS
+    floatx16 acc_sc[SCF ? NT : 1];
+    if constexpr (SCF) {  // this wave's shortcut weight fragments: [32-cout block][chunk][kk][lane][8 halfs], requested under the tail DMAs
+        half8 wsc[4][4];
+        const half_t *wsf = p.wscf + ((long)((co_base + cow) >> 5) * n_sc) * (4 * 512) + lane * 8;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wsc[c][kk] = *reinterpret_cast<const half8 *>(wsf + ((c < n_sc ? c : 0) * 4 + kk) * 512);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_sc[j][e] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the shortcut planes (the tail's DMAs) and the fragments have landed
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < n_sc) {  // (wave-uniform)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const half8 b = *reinterpret_cast<const half8 *>(smem + pbase[j] + c * PLANE_B + kk * 32);
+                        acc_sc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsc[c][kk], b, acc_sc[j], 0, 0, 0);
+                    }
+            }
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's dummy DMAs still target LDS
+    }
     __syncthreads();
 
     // ------------------------------------------------------------------ epilogue (per wave: 32 couts x NT pixel tiles) through LDS
@@ -222,8 +276,14 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
                                                });
         return;
     }
-    half8 sc8[NT][2];
-    if (p.mode == EPI_BN_ADD_BN) {  // the shortcut has the output's geometry; all loads in flight before the transposes
+    half8 sc8[SCF ? 1 : NT][2];
+    floatx4 qs0[2], qs1[2];
+    if constexpr (SCF) {  // the shortcut's folded BatchNorm
+        qs0[0] = *reinterpret_cast<const floatx4 *>(p.psc0 + cch);
+        qs0[1] = *reinterpret_cast<const floatx4 *>(p.psc0 + cch + 4);
+        qs1[0] = *reinterpret_cast<const floatx4 *>(p.psc1 + cch);
+        qs1[1] = *reinterpret_cast<const floatx4 *>(p.psc1 + cch + 4);
+    } else if (p.mode == EPI_BN_ADD_BN) {  // the shortcut has the output's geometry; all loads in flight before the transposes
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -236,34 +296,55 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+        float v[2][8];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const floatx4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-            *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = v;
+            const floatx4 t = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+            *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = t;
         }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int px = (lane >> 2) + 16 * it;
             const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
             const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
-            const int sl = j * 32 + px;
+            const float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[it][e] = t[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3];
+        }
+        if constexpr (SCF) {  // the shortcut conv's accumulators through the same tile (a wave's LDS operations execute in order)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 t = {acc_sc[j][4 * g], acc_sc[j][4 * g + 1], acc_sc[j][4 * g + 2], acc_sc[j][4 * g + 3]};
+                *reinterpret_cast<floatx4 *>(ep + r * EROW + 8 * g + 4 * hi) = t;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int px = (lane >> 2) + 16 * it;
+                const floatx4 v0 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8);
+                const floatx4 v1 = *reinterpret_cast<const floatx4 *>(ep + px * EROW + chunk * 8 + 4);
+                const float t[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[it][e] += t[e] * qs0[e >> 2][e & 3] + qs1[e >> 2][e & 3];
+            }
+        } else if (p.mode == EPI_BN_ADD_BN) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[it][e] += (float)sc8[j][it][e];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int sl = j * 32 + (lane >> 2) + 16 * it;
             long m;
             if (!slot_pixel(sl, m)) continue;
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * q0[e >> 2][e & 3] + q1[e >> 2][e & 3];
-            if (p.mode == EPI_BN_ADD_BN) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)sc8[j][it][e];
-            }
             half8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[it][e];
             *reinterpret_cast<half8 *>(p.out0 + m * p.Cout + cch) = o;
             if (two) {
                 half8 z;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = (half_t)(v[e] * q2[e >> 2][e & 3] + q3[e >> 2][e & 3]);
+                for (int e = 0; e < 8; ++e) z[e] = (half_t)(v[it][e] * q2[e >> 2][e & 3] + q3[e >> 2][e & 3]);
                 *reinterpret_cast<half8 *>(p.out1 + m * p.Cout + cch) = z;
             }
         }
@@ -461,16 +542,16 @@ bool s2c64_applies(const ConvMfmaArgs &a) {
     return !off;
 }
 
-template <int NT, int PP, bool SEP = false>
+template <int NT, int PP, bool SEP = false, bool SCF = false>
 void launch_s2_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
     constexpr size_t lds = (size_t)4 * PP * 4096;
     static_assert(lds <= 160 * 1024 && lds >= 4 * 32 * 36 * 4, "LDS budget / epilogue scratch");
     static bool attr_done[FRT_MAX_DEVICES] = {};
     if (frt_first_use_on_device(attr_done))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s2_kernel<NT, PP, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s2_kernel<NT, PP, SEP, SCF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int strips = ((a.B + n_img - 1) / n_img) * (a.Ho / R);
     const int linear = (n_img == 1 && R * (a.Wo + 1) <= NT * 32) ? 1 : 0;
-    hipLaunchKernelGGL((conv_s2_kernel<NT, PP, SEP>), dim3(strips * (a.Cout / 128)), dim3(256), lds, s, a, R, n_img, linear);
+    hipLaunchKernelGGL((conv_s2_kernel<NT, PP, SEP, SCF>), dim3(strips * (a.Cout / 128)), dim3(256), lds, s, a, R, n_img, linear);
 }
 
 // strip geometry; false: not eligible (the im2col kernel takes the layer)
@@ -478,7 +559,9 @@ bool s2_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &nt, int &pp) {
     if (!a.wf2 || a.ks != 3 || a.stride != 2 || a.pad != 1 || a.Cout % 128 || a.Cin % 64 || a.splits != 1 || a.H != a.W || (a.H & 1)) return false;
     if (a.Ho * 2 != a.H || a.Wo * 2 != a.W) return false;
     if (a.mode != EPI_BN && a.mode != EPI_BN_ADD_BN && a.mode != EPI_BN_SE) return false;
-    if ((a.mode == EPI_BN_ADD_BN || a.mode == EPI_BN_SE) && !(a.sc && a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
+    const bool scf = a.mode == EPI_BN_ADD_BN && a.scx;  // fused 1x1 stride-2 shortcut conv instead of a shortcut tensor
+    if (scf && !(a.wscf && a.psc0 && a.psc1 && (a.Csc == 64 || a.Csc == 128 || a.Csc == 256))) return false;
+    if (!scf && (a.mode == EPI_BN_ADD_BN || a.mode == EPI_BN_SE) && !(a.sc && a.sc_stride == 1 && a.sc_h == a.Ho && a.sc_w == a.Wo)) return false;
     static const bool off = frt_tuning_env("FRT_CONV_S2") && frt_tuning_env("FRT_CONV_S2")[0] == '0';
     if (off) return false;
     const int Wq = a.Wo + 1;
@@ -522,9 +605,12 @@ const char *conv_s2_label(const ConvMfmaArgs &a) {
     int R, n_img, nt, pp;
     if (s2c64_applies(a)) return "conv_s2c64_kernel";
     if (!s2_geometry(a, R, n_img, nt, pp)) return nullptr;
-    if (nt == 7) return "conv_s2_kernel<7, 9>";
-    if (nt == 4) return pp <= 5 ? "conv_s2_kernel<4, 5>" : "conv_s2_kernel<4, 9>";
-    return "conv_s2_kernel<2, 5>";
+    const bool scf = a.mode == EPI_BN_ADD_BN && a.scx;
+    if (a.mode == EPI_BN_SE) return nt == 7 ? "conv_s2_kernel<7, 9, true, false>" : "conv_s2_kernel<4, 5, true, false>";
+    if (nt == 7) return scf ? "conv_s2_kernel<7, 9, false, true>" : "conv_s2_kernel<7, 9, false, false>";
+    if (nt == 4) return pp <= 5 ? (scf ? "conv_s2_kernel<4, 5, false, true>" : "conv_s2_kernel<4, 5, false, false>")
+                                : (scf ? "conv_s2_kernel<4, 9, false, true>" : "conv_s2_kernel<4, 9, false, false>");
+    return scf ? "conv_s2_kernel<2, 5, false, true>" : "conv_s2_kernel<2, 5, false, false>";
 }
 
 bool launch_conv_s2(const ConvMfmaArgs &a0, hipStream_t s) {
@@ -542,11 +628,16 @@ bool launch_conv_s2(const ConvMfmaArgs &a0, hipStream_t s) {
     if (!s2_geometry(a0, R, n_img, nt, pp)) return false;
     ConvMfmaArgs a = a0;
     a.wf = a0.wf2;  // the kernel streams the stride-2 step order
+    const bool scf = a.mode == EPI_BN_ADD_BN && a.scx;
     if (nt == 7 && a.mode == EPI_BN_SE) launch_s2_t<7, 9, true>(a, R, n_img, s);  // (the caller checked conv_s2_se_fused)
+    else if (nt == 7 && scf) launch_s2_t<7, 9, false, true>(a, R, n_img, s);
     else if (nt == 7) launch_s2_t<7, 9>(a, R, n_img, s);
     else if (nt == 4 && pp <= 5 && a.mode == EPI_BN_SE) launch_s2_t<4, 5, true>(a, R, n_img, s);
+    else if (nt == 4 && pp <= 5 && scf) launch_s2_t<4, 5, false, true>(a, R, n_img, s);
     else if (nt == 4 && pp <= 5) launch_s2_t<4, 5>(a, R, n_img, s);
+    else if (nt == 4 && scf) launch_s2_t<4, 9, false, true>(a, R, n_img, s);
     else if (nt == 4) launch_s2_t<4, 9>(a, R, n_img, s);
+    else if (pp <= 5 && scf) launch_s2_t<2, 5, false, true>(a, R, n_img, s);
     else if (pp <= 5) launch_s2_t<2, 5>(a, R, n_img, s);
     else return false;
     return true;

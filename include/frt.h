@@ -103,7 +103,8 @@ void frt_embedder_destroy(frt_embedder *e);
 /* IR-SE-50 only (no reference counterpart; the reference's engine is a black box): 1 (default, env FRT_SE_FUSED=0 turns it off) runs the
  * squeeze-and-excitation tail of a unit inside conv2's epilogue, where the workgroups of one face hand their partial channel sums
  * over through device-scope stores and a flag; 0 always uses the stand-alone pool + gate + apply launches (no cross-workgroup wait
- * anywhere).  Results are bit-identical.  A timed-out hand-over never kills the HIP context: the next synchronising call on the
+ * anywhere).  Same arithmetic; the pooled sums are added in a different fixed order, so results agree to float rounding (cosine 1 - 1e-6),
+ * each mode bit-reproducible in itself.  A timed-out hand-over never kills the HIP context: the next synchronising call on the
  * embedder / pipeline returns FRT_ERR_DEVICE and this switch is the way back.  Takes effect for passes enqueued after the call; a
  * pipeline with hipGraph replay on must be told to re-capture (frt_pipeline_set_graph). */
 int frt_embedder_set_se_fused(frt_embedder *e, int enable);
@@ -149,6 +150,15 @@ int frt_matcher_gallery_commit(frt_matcher *m);
 int frt_matcher_num_rows(const frt_matcher *m);
 /* MatMul::calculate (src/matmul.cpp:36-77): outputs[i*num_row + j] = sum_k embeds[i][k] * gallery[j][k], fp32. */
 int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, float *outputs);
+/* calculate and the first-maximum argmax of every row in ONE call: outputs (may be NULL: no matrix is materialised) as
+ * frt_matcher_calculate, idx_out / sim_out as frt_matcher_top1 - the same accumulators, so idx_out[i] / sim_out[i] ARE std::max_element
+ * over outputs row i, bit for bit.  The drop-in ArcFaceIR50 shell uses it so that featureMatching() + getOutputs() (src/arcface.cpp:189-217)
+ * keep their signatures while the host-side O(F*N) scan disappears; with a pinned `outputs` (frt_pinned_alloc) the [F x N] copy is one DMA. */
+int frt_matcher_calculate_top1(frt_matcher *m, const float *embeds, int embed_count, float *outputs, int32_t *idx_out, float *sim_out);
+/* Page-locked host memory for buffers that cross PCIe on every call (the [F x N] matrix MatMul::calculate hands back is 4 MB per face at
+ * N = 1M: pageable memory makes that copy a staged, synchronous one).  device: the device whose context registers it. */
+int frt_pinned_alloc(size_t bytes, int device, void **out);
+void frt_pinned_free(void *p);
 /* Fused calculate + getOutputs argmax: idx_out[i] = FIRST j maximising the similarity (std::max_element semantics),
  * sim_out[i] = that similarity.  Never materialises the [n x num_row] matrix. */
 int frt_matcher_top1(frt_matcher *m, const float *embeds, int embed_count, int32_t *idx_out, float *sim_out);

@@ -71,7 +71,10 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
         std::cout << "[INFO] Loading ArcFace Engine...\n";
         croppedFaces.reserve((size_t)maxFacesPerScene);
     }
-    ~ArcFaceIR50() { frt_embedder_destroy(h_); }
+    ~ArcFaceIR50() {
+        frt_embedder_destroy(h_);
+        frt_pinned_free(m_out);
+    }
     ArcFaceIR50(const ArcFaceIR50 &) = delete;
     ArcFaceIR50 &operator=(const ArcFaceIR50 &) = delete;
 
@@ -116,6 +119,7 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     void forward(cv::Mat image, std::vector<struct Bbox> outputBbox) {
         const int n = (int)outputBbox.size();
         croppedFaces.clear();
+        m_top_valid = false;
         m_embeds.assign((size_t)std::max(n, 1) * m_OUTPUT_D, 0.f);
         if (!n) return;
         std::vector<unsigned char> crops((size_t)n * m_INPUT_H * m_INPUT_W * 3);
@@ -136,6 +140,7 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     void forwardAligned(cv::Mat image, std::vector<struct Bbox> outputBbox, const std::vector<std::array<float, 10>> &landmarks) {
         const int n = (int)landmarks.size();
         croppedFaces.clear();
+        m_top_valid = false;
         m_embeds.assign((size_t)std::max(n, 1) * m_OUTPUT_D, 0.f);
         if (!n) return;
         std::vector<unsigned char> crops((size_t)n * m_INPUT_H * m_INPUT_W * 3);
@@ -156,19 +161,46 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
         }
     }
     // src/arcface.cpp:189-201.  Throws a const char* exactly like the reference (handlers catch const char*, app.cpp:276,341).
+    // The [F x N] matrix lands in a page-locked buffer (one DMA instead of a staged pageable copy: 4 MB per face at N = 1M), and the
+    // row-wise first maximum is computed on the device in the same call - the same accumulators, bit for bit - so that getOutputs()
+    // on THIS buffer is O(F) instead of the reference's O(F*N) host scan.  setMaterializeSimilarities(false) skips the matrix
+    // altogether for callers that, like src/app.cpp:309-310, only ever hand the pointer on to getOutputs (the buffer then holds
+    // stale values; default: on, the reference's contract).
     float *featureMatching() {
         if (classNames.size() > 0 && croppedFaces.size() > 0) {
-            m_outputs.resize(croppedFaces.size() * (size_t)classCount);
-            matmul.calculate(m_embeds.data(), (int)croppedFaces.size(), m_outputs.data());
+            const size_t n = croppedFaces.size();
+            const size_t need = n * (size_t)classCount * sizeof(float);
+            if (need > m_out_cap) {
+                frt_pinned_free(m_out);
+                m_out = nullptr;
+                m_out_cap = 0;
+                void *p = nullptr;
+                checkFrtStatus(frt_pinned_alloc(need, matmul.device(), &p));
+                m_out = static_cast<float *>(p);
+                m_out_cap = need;
+            }
+            m_top_idx.resize(n);
+            m_top_sim.resize(n);
+            m_top_valid = false;
+            matmul.calculateTop1(m_embeds.data(), (int)n, m_materialize ? m_out : nullptr, m_top_idx.data(), m_top_sim.data());
+            m_top_valid = true;
         } else {
             throw "Feature matching: No faces in database or no faces found";
         }
-        return m_outputs.data();
+        return m_out;
     }
+    void setMaterializeSimilarities(bool on) { m_materialize = on; }
     // src/arcface.cpp:203-217: first maximum per row (std::max_element), no threshold here
     std::tuple<std::vector<std::string>, std::vector<float>> getOutputs(float *output_sims) {
         std::vector<std::string> names;
         std::vector<float> sims;
+        if (output_sims == m_out && m_top_valid && m_top_idx.size() == croppedFaces.size()) {  // the matrix featureMatching() just produced
+            for (size_t i = 0; i < croppedFaces.size(); ++i) {
+                names.push_back(classNames[(size_t)m_top_idx[i]]);
+                sims.push_back(m_top_sim[i]);
+            }
+            return std::make_tuple(names, sims);
+        }
         for (size_t i = 0; i < croppedFaces.size(); ++i) {
             const float *row = output_sims + i * (size_t)classCount;
             const int argmax = (int)std::distance(row, std::max_element(row, row + classCount));
@@ -215,7 +247,12 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     frt_embedder *h_;
     int m_frameWidth, m_frameHeight, m_INPUT_C, m_INPUT_H, m_INPUT_W, m_OUTPUT_D, m_maxBatchSize, m_maxFacesPerScene;
     float m_knownPersonThresh;
-    std::vector<float> m_embeds, m_outputs;
+    std::vector<float> m_embeds;
+    float *m_out = nullptr;  // page-locked [F x N] similarity matrix (object-owned, reused; the reference leaks new float[F*N] per call)
+    size_t m_out_cap = 0;
+    bool m_materialize = true, m_top_valid = false;
+    std::vector<int> m_top_idx;
+    std::vector<float> m_top_sim;
     std::vector<std::string> classNames;
     MatMul matmul;
 };

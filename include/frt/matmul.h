@@ -22,6 +22,12 @@ class MatMul {
         ensure();
         checkFrtStatus(frt_matcher_calculate(h_, embeds, embedCount, outputs));
     }
+    // Extension: calculate + the row-wise first maximum (what getOutputs computes from the matrix) in one call; outputs may be null
+    void calculateTop1(float *embeds, int embedCount, float *outputs, int *idx, float *sim) {
+        ensure();
+        checkFrtStatus(frt_matcher_calculate_top1(h_, embeds, embedCount, outputs, idx, sim));
+    }
+    int device() const { return device_; }
     // Extension: streaming load (== initKnownEmbeds / addEmbedding x n / initMatMul without a host copy of the gallery): rows go
     // through pinned staging chunks to the device while the caller fetches the next ones (src/db.cpp:316-346)
     void galleryBegin(int rowCapacity, int numCol) {

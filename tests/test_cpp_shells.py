@@ -73,3 +73,37 @@ def test_inference_call_sequence_matches_python_binding(demo, frt, synth, blobs,
             assert int(l[5]) == 100 + i and float(l[6]) > 0.9999
     det.close()
     rec.close()
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_from_plain_cpp(tmp_path):
+    """frt_comm_* (ncclAllGather bound from librccl at run time) driven by a C++ program with no Python / torch in the process: the
+    one-process-per-GPU form (unique id + create) and the one-process / all-devices form (create_all + all_gather_multi)."""
+    exe = str(tmp_path / "comm_test")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "comm_test.cpp"), "-o", exe, os.path.join(PKG, "libfrt.so"), "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "comm ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_dropin_call_sequence_threads_and_fast_getoutputs(frt, tmp_path):
+    """tests/cpp/dropin_bench.cpp at a small size: src/app.cpp:304-310 verbatim through the shells from 3 threads with their own objects
+    (two pipelines' worth of objects on one device: the one-process / several-devices shape), featureMatching() into the pinned matrix +
+    getOutputs() on the device-computed maxima == std::max_element over the materialised rows (exit code 3 otherwise)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dropin_bench as db
+    s = frt.synth
+    dpath = frt.write_weights(str(tmp_path / "det.frtw"), s.retinaface_state(1), 1)
+    rpath = frt.write_weights(str(tmp_path / "rec.frtw"), s.arcface_state(2, "ir", calib=s.load_calibration("ir")), 2)
+    frames = s.make_frames(3, 640, 640)
+    frames.tofile(str(tmp_path / "frames.bin"))
+    exe = db.build(str(tmp_path))
+    r = db.run(exe, dpath, rpath, str(tmp_path / "frames.bin"), 3, 640, 640, 60000, 3, 6, "0,0")
+    assert r["fastpath_mismatches"] == 0 and r["threads"] == 3
+    for k in ("featureMatching_getOutputs", "featureMatching_getOutputs_no_matrix", "matchTop1"):
+        assert r[k]["frames"] == 18 and r[k]["faces"] >= 18, r
+    json.dumps(r)

@@ -127,7 +127,7 @@ def test_1080p_frames_end_to_end_against_the_oracle(frt, orc, synth, blobs):
 def test_ir_se_through_the_pipeline_against_the_oracle(frt, orc, synth, blobs):
     """IR-SE-50 (the network north_star names) through frt_pipeline_submit / wait with three batches in flight - every slot, both
     activation sets, the fused SE epilogue with its cross-workgroup hand-over under co-running passes - against the fp32 oracle run
-    stage by stage, planted gallery rows; then the same batches with the stand-alone SE tail (frt_embedder_set_se_fused(e, 0)): byte-identical."""
+    stage by stage, planted gallery rows; then the same batches with the stand-alone SE tail (frt_embedder_set_se_fused(e, 0)): same boxes / ids, embeddings equal to 1e-6 in cosine."""
     import torch
     dpath, dsd = blobs("det")
     rpath, rsd = blobs("ir_se")
@@ -175,10 +175,14 @@ def test_ir_se_through_the_pipeline_against_the_oracle(frt, orc, synth, blobs):
         j = order.index(tag)
         assert np.array_equal(res[i], res[j]) and np.array_equal(emb[i], emb[j]), i  # same bytes wherever the batch sat in the pipeline
     assert exact >= total - 2, (exact, total)
-    rec.setSeFused(False)  # stand-alone pool + gate + apply launches: the same arithmetic
+    rec.setSeFused(False)  # stand-alone pool + gate + apply launches: the same arithmetic up to the order in which the pooled sums are added
     res2, emb2 = run_all()
     for i in range(len(order)):
-        assert np.array_equal(res2[i], res[i]) and np.array_equal(emb2[i], emb[i]), i
+        for c in ("x1", "y1", "x2", "y2", "score", "frame", "match_idx", "valid"):
+            assert np.array_equal(res2[i][c], res[i][c]), (i, c)
+        assert np.abs(res2[i]["match_sim"] - res[i]["match_sim"]).max() < 1e-5
+        assert ((emb2[i] * emb[i]).sum(1) > 1 - 1e-6).all(), i
+        assert np.array_equal(res2[i], res2[order.index(order[i])]) and np.array_equal(emb2[i], emb2[order.index(order[i])]), i
     rec.setSeFused(True)
     pipe.close()
     det.close()
