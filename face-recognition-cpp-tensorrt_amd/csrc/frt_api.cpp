@@ -933,7 +933,8 @@ struct frt_matcher {
     bool screen = false;
     ScreenScratch scr{};
     void free_screen_scratch() {
-        for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list, (void *)scr.segmax})  // scr.count lives behind tile_flags
+        for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list, (void *)scr.segmax, (void *)scr.wgmax, scr.pairs,
+                        (void *)scr.ctl, (void *)scr.qkey})  // scr.count lives behind tile_flags
             if (p) (void)hipFree(p);
         scr = ScreenScratch{};
     }
@@ -1124,6 +1125,15 @@ struct frt_matcher {
             scr.count = scr.tile_flags + tiles;                                                           // one contiguous range to clear per call
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_list), tiles * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.segmax), (size_t)cap * 16 * sizeof(float)));
+            const char *fe = getenv("FRT_MATCH_FAST");  // "0": the round-2 tile-list re-rank (diagnostics)
+            if (!(fe && fe[0] == '0')) {
+                scr.pair_cap = std::max(cap * 64, 8192);
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.wgmax), (size_t)256 * cap * sizeof(float)));
+                HIPCHK(hipMalloc(&scr.pairs, (size_t)scr.pair_cap * 8));
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.ctl), 4 * sizeof(int)));
+                HIPCHK(hipMemset(scr.ctl, 0, 4 * sizeof(int)));
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.qkey), (size_t)cap * sizeof(unsigned long long)));
+            }
         }
         q_cap = cap;
     }

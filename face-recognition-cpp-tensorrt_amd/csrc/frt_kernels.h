@@ -52,6 +52,12 @@ struct ScreenScratch {
     int *tile_list;    // [tiles]
     int *count;        // [1], == tile_flags + tiles (cleared together)
     float *segmax;     // [F][16] per-segment maxima of tilemax (selection step 1)
+    // fast top-1 path (round 3): null -> the tile-list path
+    float *wgmax;                 // [coarse workgroups][F] maxima of a workgroup's coarse entries
+    void *pairs;                  // (query, tile) candidate pairs
+    int pair_cap;
+    int *ctl;                     // [4]: pair count, overflow flag
+    unsigned long long *qkey;     // [F] packed (similarity, ~row) winners of the scalar re-rank
 };
 void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int *max_norm2_bits, hipStream_t s);
 void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void match_kernel(const GT *__restrict__ G, in
                                                     MatchPartial *__restrict__ partial, float *__restrict__ out_full, int num_tiles,
                                                     int row_offset, const int *__restrict__ tile_list, const int *__restrict__ d_num_tiles,
                                                     const float *__restrict__ prev_sim = nullptr, const int32_t *__restrict__ prev_idx = nullptr,
-                                                    int prev_stride = 1) {
+                                                    int prev_stride = 1, const int *__restrict__ gate = nullptr) {
+    if (gate && !*gate) return;  // fast top-1 path: this launch only runs when the pair list overflowed (uniform; before any barrier)
     // tile_list != nullptr: run only over the listed 128-row gallery tiles (num_tiles = list length): the exact re-rank pass of
     // the screened top-1 (same code path per tile as the full scan -> bitwise-identical similarities)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,7 +234,9 @@ __global__ __launch_bounds__(256) void match_kernel(const GT *__restrict__ G, in
 
 // one wave per query: lanes stride over the workgroup partials, then a butterfly with the same first-maximum rule
 __global__ __launch_bounds__(64) void match_reduce_kernel(const MatchPartial *__restrict__ partial, int blocks, int F,
-                                                          int32_t *__restrict__ idx_out, float *__restrict__ sim_out, int out_stride = 1) {
+                                                          int32_t *__restrict__ idx_out, float *__restrict__ sim_out, int out_stride = 1,
+                                                          const int *__restrict__ gate = nullptr) {
+    if (gate && !*gate) return;
     const int q = blockIdx.x;
     float v = -INFINITY;
     int i = INT_MAX;
@@ -323,9 +326,16 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const GT *__restrict_
 // refilled with the same k-step of the NEXT tile, i.e. every load has a full tile of MFMAs (4096 clk) to land, with 128 KB per CU in
 // flight.  LDS carries only the query fragments.  No barrier in the loop (a barrier per tile stalls the load stream - loads are only
 // issued from MFMA steps - and cost ~20 % of the bandwidth): every wave writes its own maximum, four coarse entries per tile.
+// Round 3 (fast top-1 path): Q32 != nullptr -> the fp32 queries are rounded to fp16 on their way into LDS (the separate conversion
+// launch disappears); wgmax != nullptr -> every workgroup also leaves the maximum of ALL its coarse entries per query in
+// wgmax[blockIdx.x][query] (plain stores; the selection kernel takes the maximum of those <= 256 values instead of a separate
+// pass over the 31 252 entries per query); ctl / qkey: the pair counter, the overflow flag and the packed per-query results of the
+// scalar re-rank are cleared here, i.e. in front of every kernel of this call that touches them.
 template <int D>
 __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restrict__ G, int N, const half_t *__restrict__ Q, int F,
-                                                           float *__restrict__ tilemax, int num_tiles) {
+                                                           float *__restrict__ tilemax, int num_tiles, const float *__restrict__ Q32 = nullptr,
+                                                           float *__restrict__ wgmax = nullptr, int *__restrict__ ctl = nullptr,
+                                                           unsigned long long *__restrict__ qkey = nullptr) {
     constexpr int KS = D / 16;   // k-steps
     constexpr int QP = D + 8;    // halves per query row in LDS
     extern __shared__ __attribute__((aligned(16))) char smem2[];
@@ -333,14 +343,32 @@ __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.y * 128;
+    if (ctl && blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid < 4) ctl[tid] = 0;
+        for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
+    }
     for (int i = tid; i < 128 * (D / 8); i += 256) {
         const int q = i / (D / 8), c = i - q * (D / 8);
         half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (q0 + q < F) v = *reinterpret_cast<const half8 *>(Q + (long)(q0 + q) * D + c * 8);
+        if (q0 + q < F) {
+            if (Q32) {
+                const floatx4 a = *reinterpret_cast<const floatx4 *>(Q32 + (long)(q0 + q) * D + c * 8), b = *reinterpret_cast<const floatx4 *>(Q32 + (long)(q0 + q) * D + c * 8 + 4);
+                v = half8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+            } else {
+                v = *reinterpret_cast<const half8 *>(Q + (long)(q0 + q) * D + c * 8);
+            }
+        }
         *reinterpret_cast<half8 *>(Qs + q * QP + c * 8) = v;
     }
+    float rmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // this wave's running maximum per query (NaN entries are tracked apart)
+    bool rnan = false;
     int tile = blockIdx.x;
-    if (tile >= num_tiles) return;  // (uniform per workgroup; no barrier has been executed yet)
+    if (tile >= num_tiles) {  // (uniform per workgroup; no barrier has been executed yet)
+        if (wgmax)
+            for (int i = tid; i < 128; i += 256)
+                if (q0 + i < F) wgmax[(long)blockIdx.x * F + q0 + i] = -INFINITY;
+        return;
+    }
     auto frag_ptr = [&](int t) { return G + (((long)t * 4 + wave) * KS) * 512 + lane * 8; };  // + ks * 512 halfs (1 KB) per k-step
     half8 areg[KS];
     {
@@ -386,8 +414,28 @@ __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restr
             m = fmaxf(m, __shfl_xor(m, 32));
             const int q = q0 + n * 32 + r;
             if (hi == 0 && q < F) tilemax[((long)q * num_tiles + tile) * 4 + wave] = m;
+            rnan = rnan || (m != m);
+            rmax[n] = fmaxf(rmax[n], m);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the iterations apart (without it the scheduler's version needs 512 registers + spills)
+    }
+    if (wgmax) {  // the four waves' maxima -> one value per (workgroup, query); a NaN anywhere makes it NaN (the selection then takes every tile)
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem2);  // the query block is dead now
+        if (hi == 0) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) red[wave * 128 + n * 32 + r] = rnan ? NAN : rmax[n];
+        }
+        __syncthreads();
+        if (tid < 128 && q0 + tid < F) {
+            float m = red[tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float o = red[w * 128 + tid];
+                m = (m != m || o != o) ? NAN : fmaxf(m, o);
+            }
+            wgmax[(long)blockIdx.x * F + q0 + tid] = m;
+        }
     }
 }
 
@@ -547,10 +595,146 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t *__restric
     }
 }
 
+// ---------------------------------------------------------------- fast screened top-1 (round 3)
+// The tile list + MFMA re-rank above recomputes ALL queries against every listed tile (128 x 128 dot products per tile where typically
+// one query asked for it) behind a per-tile barrier chain: 59 us for a few hundred tiles.  Here the selection emits (query, tile)
+// PAIRS and a scalar kernel recomputes exactly those 128 dot products per pair - one thread per gallery row walking k in the order the
+// exact kernel's v_mfma_f32_32x32x2_f32 chain consumes it, so the similarities are the same bits as the full scan's (checked by
+// tools/ubench/mfma_f32_order.hip and by the bit-identity tests).  Per pair the best row (first-maximum rule) goes into the query's
+// 64-bit slot with one atomicMax: high word = the similarity mapped monotonically to an unsigned integer, low word = ~row, so a higher
+// similarity wins and among equal similarities the LOWER row.  More pairs than the list holds (non-finite inputs, degenerate
+// galleries): the overflow flag routes the call through the unscreened exact scan instead (gate argument below).
+struct MatchPair {
+    int q, tile;
+};
+constexpr int CTL_COUNT = 0, CTL_OVERFLOW = 1;
+
+__device__ __forceinline__ unsigned mono_bits(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unmono_bits(unsigned m) { return __uint_as_float((m & 0x80000000u) ? (m & 0x7fffffffu) : ~m); }
+
+// grid (SEL_SEG, F): the query's best coarse entry from the per-workgroup maxima, ||q||, then every tile of the segment with a coarse
+// entry within 2*delta of it becomes a pair
+__global__ __launch_bounds__(256) void match_select_pairs_kernel(const float *__restrict__ tilemax, int num_tiles, const float *__restrict__ wgmax, int n_wg,
+                                                                 int F, const float *__restrict__ Q, int D, float gmax_norm, MatchPair *__restrict__ pairs,
+                                                                 int pair_cap, int *__restrict__ ctl) {
+    __shared__ float sm[4], sn[4];
+    __shared__ int snan[4];
+    const int q = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
+    float m = -INFINITY, n2 = 0.f;
+    int isnan_ = 0;
+    for (int w = tid; w < n_wg; w += 256) {
+        const float v = wgmax[(long)w * F + q];
+        isnan_ |= v != v;
+        m = fmaxf(m, v);
+    }
+    for (int k = tid; k < D; k += 256) n2 += Q[(long)q * D + k] * Q[(long)q * D + k];
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off));
+        n2 += __shfl_xor(n2, off);
+        isnan_ |= __shfl_xor(isnan_, off);
+    }
+    if ((tid & 63) == 0) {
+        sm[tid >> 6] = m;
+        sn[tid >> 6] = n2;
+        snan[tid >> 6] = isnan_;
+    }
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    const bool anynan = snan[0] | snan[1] | snan[2] | snan[3];
+    const float qn = sqrtf(sn[0] + sn[1] + sn[2] + sn[3]);
+    const float delta = 1.2e-3f * qn * gmax_norm;
+    // same rule as match_select_kernel: fp16 overflow / non-finite inputs -> no valid bound -> every tile (which overflows the pair list
+    // and sends the call through the exact full scan)
+    const float thr = (!anynan && qn < 6.0e4f && gmax_norm < 6.0e4f && m == m && m > -INFINITY && m < INFINITY) ? m - 2.f * delta : -INFINITY;
+    const int t0 = (int)((long)num_tiles * seg / SEL_SEG), t1 = (int)((long)num_tiles * (seg + 1) / SEL_SEG);
+    const floatx4 *row = reinterpret_cast<const floatx4 *>(tilemax + (long)q * num_tiles * 4);
+    for (int t = t0 + tid; t < t1; t += 256) {
+        const floatx4 e = row[t];
+        if (!(e[0] < thr) || !(e[1] < thr) || !(e[2] < thr) || !(e[3] < thr)) {
+            const int i = atomicAdd(&ctl[CTL_COUNT], 1);
+            if (i < pair_cap) pairs[i] = MatchPair{q, t};
+            else ctl[CTL_OVERFLOW] = 1;
+        }
+    }
+}
+
+// one workgroup (128 threads = the tile's 128 rows) per pair, pairs dealt round-robin over the grid
+template <typename GT>
+__global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__restrict__ G, int N, int D, const float *__restrict__ E, const MatchPair *__restrict__ pairs,
+                                                                 int pair_cap, const int *__restrict__ ctl, unsigned long long *__restrict__ qkey) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    float *qs = reinterpret_cast<float *>(smem3);  // [D]
+    __shared__ float rv[2];
+    __shared__ int ri[2];
+    const int tid = threadIdx.x;
+    int count = ctl[CTL_COUNT];
+    if (ctl[CTL_OVERFLOW]) return;  // the exact full scan answers this call
+    if (count > pair_cap) count = pair_cap;
+    for (int p = blockIdx.x; p < count; p += gridDim.x) {
+        const MatchPair pr = pairs[p];
+        __syncthreads();  // the previous pair's readers of qs / rv are done
+        for (int k = tid * 4; k < D; k += 512) *reinterpret_cast<floatx4 *>(qs + k) = *reinterpret_cast<const floatx4 *>(E + (long)pr.q * D + k);
+        __syncthreads();
+        const long g = (long)pr.tile * 128 + tid;
+        float acc = 0.f;
+        if (g < N) {
+            // k order of the exact kernel: per 32-wide step, for ks in 0..3, for s in 0..3: k = 8 ks + s (lanes 0-31 of the MFMA), then
+            // k = 8 ks + 4 + s (lanes 32-63) - one fused multiply-add each
+            for (int k0 = 0; k0 < D; k0 += 8) {
+                const floatx4 a = load_g4(G, g, D, k0), b = load_g4(G, g, D, k0 + 4);
+                const floatx4 x = *reinterpret_cast<const floatx4 *>(qs + k0), y = *reinterpret_cast<const floatx4 *>(qs + k0 + 4);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    acc = __builtin_fmaf(a[s2], x[s2], acc);
+                    acc = __builtin_fmaf(b[s2], y[s2], acc);
+                }
+            }
+        }
+        float v = g < N ? acc : -INFINITY;
+        int i = g < N ? (int)g : INT_MAX;
+        if (v != v) {  // NaN never wins (std::max_element with operator<: a NaN is never greater)
+            v = -INFINITY;
+            i = INT_MAX;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off);
+            const int oi = __shfl_xor(i, off);
+            if (better(ov, oi, v, i)) {
+                v = ov;
+                i = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            rv[tid >> 6] = v;
+            ri[tid >> 6] = i;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (better(rv[1], ri[1], v, i)) {
+                v = rv[1];
+                i = ri[1];
+            }
+            if (i != INT_MAX) atomicMax(&qkey[pr.q], ((unsigned long long)mono_bits(v) << 32) | (unsigned long long)(~(unsigned)i));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void match_unpack_kernel(const unsigned long long *__restrict__ qkey, int F, int row_offset, const int *__restrict__ ctl,
+                                                           int32_t *__restrict__ idx_out, float *__restrict__ sim_out) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= F || ctl[CTL_OVERFLOW]) return;
+    const unsigned long long k = qkey[q];
+    idx_out[q] = k ? (int)(~(unsigned)(k & 0xffffffffull)) + row_offset : -1;
+    sim_out[q] = k ? unmono_bits((unsigned)(k >> 32)) : -INFINITY;
+}
+
 template <int NQ, bool FULL, typename GT = float, bool EXCL = false>
 void launch_t(const GT *G, int N, int D, const float *E, int F, MatchPartial *partial, float *out_full, int blocks, int row_offset,
               hipStream_t s, const int *tile_list = nullptr, const int *d_num_tiles = nullptr, const float *prev_sim = nullptr,
-              const int32_t *prev_idx = nullptr, int prev_stride = 1) {
+              const int32_t *prev_idx = nullptr, int prev_stride = 1, const int *gate = nullptr) {
     const int tiles = (N + BM - 1) / BM;
     const size_t lds = (size_t)2 * (BM + NQ * 32) * BK * sizeof(float);
     static bool attr_done[FRT_MAX_DEVICES] = {};
@@ -559,7 +743,7 @@ void launch_t(const GT *G, int N, int D, const float *E, int F, MatchPartial *pa
     }
     dim3 grid(blocks, (F + NQ * 32 - 1) / (NQ * 32));
     hipLaunchKernelGGL((match_kernel<NQ, FULL, GT, EXCL>), grid, dim3(256), lds, s, G, N, D, E, F, partial, out_full, tiles, row_offset, tile_list, d_num_tiles,
-                       prev_sim, prev_idx, prev_stride);
+                       prev_sim, prev_idx, prev_stride, gate);
 }
 
 }  // namespace
@@ -579,7 +763,7 @@ void launch_match_top1(const float *gallery, int N, int D, const float *queries,
         launch_t<2, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
     else
         launch_t<4, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
-    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1, (const int *)nullptr);
 }
 
 void launch_match_top1_h(const half_t *g16, int N, int D, const float *queries, int F, MatchPartial *partial, int partial_blocks,
@@ -590,7 +774,7 @@ void launch_match_top1_h(const half_t *g16, int N, int D, const float *queries, 
         launch_t<2, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
     else
         launch_t<4, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s);
-    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1, (const int *)nullptr);
 }
 
 void launch_match_full_h(const half_t *g16, int N, int D, const float *queries, int F, float *out, hipStream_t s) {
@@ -635,14 +819,16 @@ void launch_gallery_norm16(const half_t *g16, int N, int D, int *max_norm2_bits,
     hipLaunchKernelGGL(row_norm_max_kernel<half_t>, dim3((N + 3) / 4), dim3(256), 0, s, g16, N, D, max_norm2_bits);
 }
 
+constexpr int COARSE_WG = 256;  // persistent workgroups of the coarse scan (one per CU)
 template <int D>
-static void launch_coarse_t(const half_t *g16, int N, const half_t *q16, int F, float *tilemax, int tiles, hipStream_t s) {
+static void launch_coarse_t(const half_t *g16, int N, const half_t *q16, int F, float *tilemax, int tiles, hipStream_t s, const float *q32 = nullptr,
+                            float *wgmax = nullptr, int *ctl = nullptr, unsigned long long *qkey = nullptr) {
     const size_t lds = (size_t)128 * (D + 8) * sizeof(half_t);
     static bool attr_done[FRT_MAX_DEVICES] = {};
     if (frt_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 g(tiles < 256 ? tiles : 256, (F + 127) / 128);
-    hipLaunchKernelGGL((match_coarse_kernel<D>), g, dim3(256), lds, s, g16, N, q16, F, tilemax, tiles);
+    dim3 g(tiles < COARSE_WG ? tiles : COARSE_WG, (F + 127) / 128);
+    hipLaunchKernelGGL((match_coarse_kernel<D>), g, dim3(256), lds, s, g16, N, q16, F, tilemax, tiles, q32, wgmax, ctl, qkey);
 }
 
 // coarse pass + tile selection: leaves the candidate tile list (w.tile_list, length *w.count on the device).  k > 1: the threshold hangs
@@ -694,7 +880,7 @@ void launch_match_topk(const float *gallery, const half_t *g16, int N, int D, co
             if (F <= 32) launch_t<1, false, half_t, true>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k);
             else launch_t<4, false, half_t, true>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k);
         }
-        hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out + j, sim_out + j, k);
+        hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out + j, sim_out + j, k, (const int *)nullptr);
     }
 }
 int match_topk_max() { return TOPK_MAX; }
@@ -713,6 +899,32 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
                                 const ScreenScratch &w, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
                                 int row_offset, hipStream_t s) {
     const int tiles = (N + BM - 1) / BM;
+    if (w.pairs && w.wgmax && tiles >= COARSE_WG) {  // fast path (round 3): coarse (queries converted on load, per-workgroup maxima) -> pairs -> scalar re-rank -> unpack
+        const int n_wg = COARSE_WG;
+        switch (D) {
+            case 64: launch_coarse_t<64>(g16, N, nullptr, F, w.tilemax, tiles, s, queries, w.wgmax, w.ctl, w.qkey); break;
+            case 128: launch_coarse_t<128>(g16, N, nullptr, F, w.tilemax, tiles, s, queries, w.wgmax, w.ctl, w.qkey); break;
+            case 256: launch_coarse_t<256>(g16, N, nullptr, F, w.tilemax, tiles, s, queries, w.wgmax, w.ctl, w.qkey); break;
+            default: launch_coarse_t<512>(g16, N, nullptr, F, w.tilemax, tiles, s, queries, w.wgmax, w.ctl, w.qkey); break;
+        }
+        // (with F > 128 every query block y writes its own columns of wgmax: [n_wg][F])
+        hipLaunchKernelGGL(match_select_pairs_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles, w.wgmax, n_wg, F, queries, D, gmax_norm,
+                           reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl);
+        const int rr_grid = 1024;
+        if (gallery)
+            hipLaunchKernelGGL((match_rerank_pairs_kernel<float>), dim3(rr_grid), dim3(128), (size_t)D * sizeof(float), s, gallery, N, D, queries,
+                               reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey);
+        else
+            hipLaunchKernelGGL((match_rerank_pairs_kernel<half_t>), dim3(rr_grid), dim3(128), (size_t)D * sizeof(float), s, g16, N, D, queries,
+                               reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey);
+        hipLaunchKernelGGL(match_unpack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, w.qkey, F, row_offset, w.ctl, idx_out, sim_out);
+        // overflow (more candidate pairs than the list holds): the unscreened exact scan answers instead - launched always, gated on the flag
+        const int *gate = w.ctl + CTL_OVERFLOW;
+        if (gallery) launch_t<4, false, float>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, nullptr, nullptr, 1, gate);
+        else launch_t<4, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, nullptr, nullptr, 1, gate);
+        hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1, gate);
+        return;
+    }
     const long q8 = (long)F * D / 8;
     const long nzero = (long)tiles + 1;  // tile flags + the candidate count behind them (ScreenScratch: count == tile_flags + tiles)
     const long n_thr = q8 > nzero ? q8 : nzero;
@@ -734,5 +946,5 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
         launch_t<1, false>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
     else  // fp16-stored gallery: the exact pass widens the stored rows (same per-tile code path as launch_match_top1_h's full scan)
         launch_t<1, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, w.tile_list, w.count);
-    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1);
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1, (const int *)nullptr);
 }

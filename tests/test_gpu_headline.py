@@ -180,7 +180,7 @@ def test_ir_se_through_the_pipeline_against_the_oracle(frt, orc, synth, blobs):
     for i in range(len(order)):
         for c in ("x1", "y1", "x2", "y2", "score", "frame", "match_idx", "valid"):
             assert np.array_equal(res2[i][c], res[i][c]), (i, c)
-        assert np.abs(res2[i]["match_sim"] - res[i]["match_sim"]).max() < 1e-5
+        assert np.abs(res2[i]["match_sim"] - res[i]["match_sim"]).max() < 2e-3  # |de| <= sqrt(2 * 1e-6) for embeddings within 1e-6 in cosine
         assert ((emb2[i] * emb[i]).sum(1) > 1 - 1e-6).all(), i
         assert np.array_equal(res2[i], res2[order.index(order[i])]) and np.array_equal(emb2[i], emb2[order.index(order[i])]), i
     rec.setSeFused(True)
