@@ -130,7 +130,12 @@ int parse(const uint8_t *d, size_t n, Parsed &out, std::string &err) {
             h.restart_interval = be16(s);
         } else if (m == 0xDA) {  // SOS
             if (!have_sof) return fail(err, "jpeg: SOS before SOF");
-            if (h.progressive) return fail(err, "jpeg: progressive streams are not supported (baseline / extended sequential only)");
+            if (h.progressive) {  // the scans are walked by decode_progressive; tables may still change between them
+                for (int i = 0; i < h.ncomp; ++i)
+                    if (!h.qset[h.c[i].tq]) return fail(err, "jpeg: component refers to a missing quantisation table");
+                h.first_sos = p;
+                break;
+            }
             if (sl < 1 || s[0] != h.ncomp || sl < 1 + 2 * h.ncomp + 3) return fail(err, "jpeg: multi-scan sequential streams are not supported");
             for (int i = 0; i < h.ncomp; ++i) {
                 const int cid = s[1 + 2 * i];
@@ -306,6 +311,241 @@ int decode_scan(const uint8_t *d, size_t n, const Parsed &P, int16_t *coef, std:
         }
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- progressive
+namespace {
+
+// one DHT segment body -> tables (shared with parse(): same validation)
+int read_dht(const uint8_t *s, int sl, Parsed &out, std::string &err) {
+    int q = 0;
+    while (q < sl) {
+        if (q + 17 > sl) return fail(err, "jpeg: short DHT");
+        const int tc = s[q] >> 4, th = s[q] & 15;
+        if (tc > 1 || th > 3) return fail(err, "jpeg: bad DHT");
+        HuffTable &t = tc ? out.ac[th] : out.dc[th];
+        int total = 0;
+        t.bits[0] = 0;
+        for (int i = 1; i <= 16; ++i) {
+            t.bits[i] = s[q + i];
+            total += t.bits[i];
+        }
+        if (total > 256 || q + 17 + total > sl) return fail(err, "jpeg: bad DHT counts");
+        for (int l = 1, code = 0; l <= 16; ++l) {
+            code += t.bits[l];
+            if (code > (1 << l)) return fail(err, "jpeg: bad Huffman table (over-subscribed code lengths)");
+            code <<= 1;
+        }
+        std::memcpy(t.vals, s + q + 17, (size_t)total);
+        t.build();
+        t.set = true;
+        q += 17 + total;
+    }
+    return 0;
+}
+
+struct ScanComp {
+    int ci, td, ta;
+};
+
+}  // namespace
+
+int decode_progressive(const uint8_t *d, size_t n, Parsed &P, int16_t *coef, std::string &err) {
+    Header &h = P.h;
+    size_t p = h.first_sos;  // at the length field of the first SOS
+    int m = 0xDA;
+    int n_scans = 0;
+    for (;;) {
+        // ---- marker segment `m` with its length field at p
+        if (m == 0xD9) break;  // EOI
+        if (p + 2 > n) break;  // truncated file: what has been decoded so far stands (libjpeg: "premature end of data")
+        const int len = be16(d + p);
+        if (len < 2 || p + len > n) return fail(err, "jpeg: bad segment length");
+        const uint8_t *s = d + p + 2;
+        const int sl = len - 2;
+        if (m == 0xC4) {
+            if (read_dht(s, sl, P, err)) return 3;
+        } else if (m == 0xDD) {
+            if (sl < 2) return fail(err, "jpeg: short DRI");
+            h.restart_interval = be16(s);
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+            return fail(err, "jpeg: two SOF markers");
+        } else if (m == 0xDA) {
+            if (++n_scans > 1000) return fail(err, "jpeg: too many scans");
+            if (sl < 1) return fail(err, "jpeg: short SOS");
+            const int ns = s[0];
+            if (ns < 1 || ns > h.ncomp || sl < 1 + 2 * ns + 3) return fail(err, "jpeg: bad SOS");
+            ScanComp sc[3];
+            for (int i = 0; i < ns; ++i) {
+                const int cid = s[1 + 2 * i];
+                sc[i].ci = -1;
+                for (int j = 0; j < h.ncomp; ++j)
+                    if (h.c[j].id == cid) sc[i].ci = j;
+                if (sc[i].ci < 0 || (i > 0 && sc[i].ci <= sc[i - 1].ci)) return fail(err, "jpeg: bad scan component");
+                sc[i].td = s[2 + 2 * i] >> 4;
+                sc[i].ta = s[2 + 2 * i] & 15;
+                if (sc[i].td > 3 || sc[i].ta > 3) return fail(err, "jpeg: bad scan table index");
+            }
+            const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+            if (Ss > Se || Se > 63 || Al > 13 || (Ah != 0 && Ah != Al + 1)) return fail(err, "jpeg: bad progressive scan parameters");
+            if (Ss == 0 && Se != 0) return fail(err, "jpeg: a progressive scan mixes DC and AC coefficients");
+            if (Ss > 0 && ns != 1) return fail(err, "jpeg: an AC scan must hold one component");
+            if (ns > 1 && ns != h.ncomp) return fail(err, "jpeg: interleaved scans over a subset of the components are not supported");
+            for (int i = 0; i < ns; ++i) {
+                if (Ss == 0 && Ah == 0 && !P.dc[sc[i].td].set) return fail(err, "jpeg: scan refers to a missing Huffman table");
+                if (Ss > 0 && !P.ac[sc[i].ta].set) return fail(err, "jpeg: scan refers to a missing Huffman table");
+            }
+            // ---- the entropy-coded segment
+            BitReader br{d, n, p + len};
+            int pred[3] = {0, 0, 0};
+            int eobrun = 0, rst = 0;
+            const int p1 = 1 << Al, m1 = -(1 << Al);
+            if (ns > 1 || (h.ncomp == 1 && Ss == 0)) {
+                // interleaved DC scan (or the only component's DC scan): MCU order, component planes padded to whole MCUs
+                const int total_mcu = h.mcux * h.mcuy;
+                int until = h.restart_interval ? h.restart_interval : total_mcu + 1;
+                for (int mcu = 0; mcu < total_mcu; ++mcu) {
+                    if (until == 0) {
+                        if (!br.restart(rst)) return fail(err, "jpeg: missing restart marker");
+                        rst = (rst + 1) & 7;
+                        pred[0] = pred[1] = pred[2] = 0;
+                        until = h.restart_interval;
+                    }
+                    --until;
+                    const int my = mcu / h.mcux, mx = mcu - my * h.mcux;
+                    for (int i = 0; i < ns; ++i) {
+                        const Component &c = h.c[sc[i].ci];
+                        for (int v = 0; v < c.v; ++v)
+                            for (int hh = 0; hh < c.h; ++hh) {
+                                int16_t *blk = coef + (c.block0 + (size_t)(my * c.v + v) * c.bw + (mx * c.h + hh)) * 64;
+                                if (Ah == 0) {
+                                    const int sz = decode_sym(br, P.dc[sc[i].td]);
+                                    if (sz < 0 || sz > 11) return fail(err, "jpeg: corrupt DC code");
+                                    if (sz) pred[i] += extend(br.get(sz), sz);
+                                    blk[0] = (int16_t)(pred[i] * (1 << Al));
+                                } else if (br.get(1)) {
+                                    blk[0] = (int16_t)(blk[0] | p1);
+                                }
+                            }
+                    }
+                }
+            } else {
+                // non-interleaved scan of one component: its own block raster, ceil(samples / 8) blocks per row / column
+                const Component &c = h.c[sc[0].ci];
+                const int bwn = (c.dw + 7) / 8, bhn = (c.dh + 7) / 8;
+                const int total = bwn * bhn;
+                int until = h.restart_interval ? h.restart_interval : total + 1;
+                const HuffTable &act = P.ac[sc[0].ta];
+                for (int b = 0; b < total; ++b) {
+                    if (until == 0) {
+                        if (!br.restart(rst)) return fail(err, "jpeg: missing restart marker");
+                        rst = (rst + 1) & 7;
+                        pred[0] = 0;
+                        eobrun = 0;
+                        until = h.restart_interval;
+                    }
+                    --until;
+                    const int by = b / bwn, bx = b - by * bwn;
+                    int16_t *blk = coef + (c.block0 + (size_t)by * c.bw + bx) * 64;
+                    if (Ss == 0) {  // DC scan of one component of a multi-component image
+                        if (Ah == 0) {
+                            const int sz = decode_sym(br, P.dc[sc[0].td]);
+                            if (sz < 0 || sz > 11) return fail(err, "jpeg: corrupt DC code");
+                            if (sz) pred[0] += extend(br.get(sz), sz);
+                            blk[0] = (int16_t)(pred[0] * (1 << Al));
+                        } else if (br.get(1)) {
+                            blk[0] = (int16_t)(blk[0] | p1);
+                        }
+                    } else if (Ah == 0) {  // AC first pass (G.2: decode_mcu_AC_first)
+                        if (eobrun > 0) {
+                            --eobrun;
+                            continue;
+                        }
+                        for (int k = Ss; k <= Se;) {
+                            const int rs = decode_sym(br, act);
+                            if (rs < 0) return fail(err, "jpeg: corrupt AC code");
+                            const int r = rs >> 4, sz = rs & 15;
+                            if (sz) {
+                                k += r;
+                                if (k > Se) return fail(err, "jpeg: AC run past the end of the band");
+                                blk[kNaturalOrder[k]] = (int16_t)(extend(br.get(sz), sz) * (1 << Al));
+                                ++k;
+                            } else if (r == 15) {
+                                k += 16;
+                            } else {  // EOBr: this block and (1 << r) + extra - 1 following ones have nothing more in the band
+                                eobrun = 1 << r;
+                                if (r) eobrun += br.get(r);
+                                --eobrun;
+                                break;
+                            }
+                        }
+                    } else {  // AC refinement (G.1.2.3: decode_mcu_AC_refine)
+                        int k = Ss;
+                        if (eobrun == 0) {
+                            for (; k <= Se; ++k) {
+                                const int rs = decode_sym(br, act);
+                                if (rs < 0) return fail(err, "jpeg: corrupt AC code");
+                                int r = rs >> 4;
+                                const int sz = rs & 15;
+                                int val = 0;
+                                if (sz) {
+                                    if (sz != 1) return fail(err, "jpeg: corrupt AC refinement code");
+                                    val = br.get(1) ? p1 : m1;
+                                } else if (r != 15) {
+                                    eobrun = 1 << r;
+                                    if (r) eobrun += br.get(r);
+                                    break;  // the rest of the block is handled as end-of-band below
+                                }
+                                // skip r still-zero coefficients, refining the already non-zero ones that are passed
+                                for (; k <= Se; ++k) {
+                                    int16_t &cf = blk[kNaturalOrder[k]];
+                                    if (cf != 0) {
+                                        if (br.get(1) && (cf & p1) == 0) cf = (int16_t)(cf >= 0 ? cf + p1 : cf + m1);
+                                    } else if (--r < 0) {
+                                        break;
+                                    }
+                                }
+                                if (val && k <= Se) blk[kNaturalOrder[k]] = (int16_t)val;
+                            }
+                        }
+                        if (eobrun > 0) {  // refine the remaining non-zero coefficients of the band
+                            for (; k <= Se; ++k) {
+                                int16_t &cf = blk[kNaturalOrder[k]];
+                                if (cf != 0 && br.get(1) && (cf & p1) == 0) cf = (int16_t)(cf >= 0 ? cf + p1 : cf + m1);
+                            }
+                            --eobrun;
+                        }
+                    }
+                }
+            }
+            // ---- the next marker: where the bit reader met it, or further on if the buffer had not got there yet
+            p = br.p;
+            while (p + 1 < n && !(d[p] == 0xFF && d[p + 1] != 0 && d[p + 1] != 0xFF && !(d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7))) ++p;
+            if (p + 1 >= n) break;  // no EOI: accept what was decoded
+            m = d[p + 1];
+            p += 2;
+            continue;
+        }
+        // ---- next marker behind a non-scan segment
+        p += len;
+        if (p + 2 > n) break;
+        if (d[p] != 0xFF) return fail(err, "jpeg: marker expected");
+        while (p < n && d[p] == 0xFF) ++p;
+        if (p >= n) break;
+        m = d[p++];
+        while (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) {  // parameterless
+            if (p + 2 > n || d[p] != 0xFF) return 0;
+            while (p < n && d[p] == 0xFF) ++p;
+            if (p >= n) return 0;
+            m = d[p++];
+        }
+    }
+    if (n_scans == 0) return fail(err, "jpeg: no scan");
+    return 0;
+}
+
+int decode_coefficients(const uint8_t *d, size_t n, Parsed &P, int16_t *coef, std::string &err) {
+    return P.h.progressive ? decode_progressive(d, n, P, coef, err) : decode_scan(d, n, P, coef, err);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- encoder

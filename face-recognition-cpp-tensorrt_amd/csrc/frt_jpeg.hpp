@@ -31,7 +31,8 @@ struct Header {
     uint16_t q[4][64];        // quantisation tables, NATURAL (row-major) order
     bool qset[4] = {false, false, false, false};
     size_t total_blocks = 0;
-    size_t scan_begin = 0;    // byte offset of the entropy-coded segment
+    size_t scan_begin = 0;    // byte offset of the entropy-coded segment (sequential streams)
+    size_t first_sos = 0;     // byte offset of the first SOS segment's length field (progressive streams: the scan loop starts here)
 };
 
 // 0 on success; error text in `err`.  Parses every marker segment up to the first SOS, including the Huffman tables.
@@ -54,6 +55,13 @@ int parse(const uint8_t *data, size_t size, Parsed &out, std::string &err);
 // Entropy-decodes the (single, interleaved or one-component) baseline scan into coef[total_blocks][64] (int16, natural order,
 // NOT dequantised).  coef must be zero-filled by the caller.
 int decode_scan(const uint8_t *data, size_t size, const Parsed &p, int16_t *coef, std::string &err);
+// Progressive streams (SOF2; cv::imdecode accepts them, src/app.cpp:296): every scan of the file - DC first / refinement, AC first /
+// refinement with end-of-band runs, spectral selection and successive approximation (ITU T.81 Annex G), Huffman tables redefined between
+// scans, restart intervals - accumulated into the same coef[total_blocks][64] layout decode_scan produces; everything behind the entropy
+// decoder (dequantisation, IDCT, upsampling, colour) is shared with the sequential path.  `p` is updated with the tables the scans define.
+int decode_progressive(const uint8_t *data, size_t size, Parsed &p, int16_t *coef, std::string &err);
+// either of the two, by p.h.progressive
+int decode_coefficients(const uint8_t *data, size_t size, Parsed &p, int16_t *coef, std::string &err);
 
 // ------------------------------------------------------------------------------------------------------------ encoder
 struct EncTables {

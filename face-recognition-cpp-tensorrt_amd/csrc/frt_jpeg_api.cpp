@@ -199,7 +199,7 @@ int frt_jpeg_read_coefficients(const uint8_t *data, size_t size, int16_t *coef_o
         if (!coef_out) return;
         if (coef_capacity_blocks < h.total_blocks) raise(FRT_ERR_CAPACITY, "jpeg: coefficient buffer too small");
         std::memset(coef_out, 0, h.total_blocks * 128);
-        if (frtjpeg::decode_scan(data, size, p, coef_out, err)) raise(FRT_ERR_FORMAT, err);
+        if (frtjpeg::decode_coefficients(data, size, p, coef_out, err)) raise(FRT_ERR_FORMAT, err);
     });
 }
 
@@ -305,7 +305,7 @@ int frt_jpeg_decode_batch_dev(frt_jpeg_decoder *d, const uint8_t *const *data, c
             const frtjpeg::Header &h = parsed[(size_t)i].h;
             int16_t *c = s.h_coef + s.h_desc[i].coef_block0 * 64;
             std::memset(c, 0, h.total_blocks * 128);
-            if (frtjpeg::decode_scan(data[i], sizes[i], parsed[(size_t)i], c, errs[(size_t)i])) bad.fetch_add(1);
+            if (frtjpeg::decode_coefficients(data[i], sizes[i], parsed[(size_t)i], c, errs[(size_t)i])) bad.fetch_add(1);
         });
         if (bad.load())
             for (const std::string &e : errs)

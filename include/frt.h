@@ -103,7 +103,7 @@ void frt_embedder_destroy(frt_embedder *e);
 /* IR-SE-50 only (no reference counterpart; the reference's engine is a black box): 1 (default, env FRT_SE_FUSED=0 turns it off) runs the
  * squeeze-and-excitation tail of a unit inside conv2's epilogue, where the workgroups of one face hand their partial channel sums
  * over through device-scope stores and a flag; 0 always uses the stand-alone pool + gate + apply launches (no cross-workgroup wait
- * anywhere).  Same arithmetic; the pooled sums are added in a different fixed order, so results agree to float rounding (cosine 1 - 1e-6),
+ * anywhere).  Same arithmetic; the pooled sums are added in a different fixed order, so results agree to fp16 rounding of the gated activations (cosine >= 1 - 1e-5),
  * each mode bit-reproducible in itself.  A timed-out hand-over never kills the HIP context: the next synchronising call on the
  * embedder / pipeline returns FRT_ERR_DEVICE and this switch is the way back.  Takes effect for passes enqueued after the call; a
  * pipeline with hipGraph replay on must be told to re-capture (frt_pipeline_set_graph). */
@@ -297,8 +297,9 @@ int frt_resize_frames_dev(const void *src_dev, int n, int rows, int cols, size_t
  * "islow" DCT, triangle-filter chroma upsampling, quality 95, 4:2:0, Annex-K Huffman tables) - all-integer algorithms, reproduced
  * here bit for bit: Huffman coding on a pool of host threads (it is serial per scan), dequantisation + IDCT + upsampling + colour
  * conversion (+ the resize) and colour conversion + downsampling + FDCT + quantisation on the device.  Supported streams: baseline /
- * extended-sequential Huffman, 8 bit, grey or YCbCr with 4:4:4 / 4:2:2 / 4:2:0 sampling, restart intervals; progressive and
- * arithmetic-coded streams return FRT_ERR_FORMAT.  Grey images come out with the value replicated to B, G and R. */
+ * extended-sequential / progressive (spectral selection + successive approximation, any scan script) Huffman, 8 bit, grey or YCbCr
+ * with 4:4:4 / 4:2:2 / 4:2:0 sampling, restart intervals; arithmetic-coded, lossless, RGB-coded and CMYK streams return
+ * FRT_ERR_FORMAT.  Grey images come out with the value replicated to B, G and R. */
 typedef struct frt_jpeg_decoder frt_jpeg_decoder;
 /* header only; any of the out pointers may be NULL */
 int frt_jpeg_info(const uint8_t *data, size_t size, int *width, int *height, int *components);

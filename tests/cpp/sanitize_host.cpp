@@ -22,7 +22,7 @@ static int try_jpeg(const std::vector<uint8_t> &b) {
     if (frtjpeg::parse(b.data(), b.size(), p, err)) return 1;
     if (p.h.total_blocks > (1u << 20)) return 2;
     std::vector<int16_t> coef(p.h.total_blocks * 64, 0);
-    return frtjpeg::decode_scan(b.data(), b.size(), p, coef.data(), err) ? 3 : 0;
+    return frtjpeg::decode_coefficients(b.data(), b.size(), p, coef.data(), err) ? 3 : 0;  // sequential or progressive
 }
 
 int main(int argc, char **argv) {

@@ -51,9 +51,21 @@ b = io.BytesIO()
 Image.fromarray(noisy(30, 50, 34)[..., 0]).save(b, "JPEG", quality=85)
 out["dec_gray_q85_jpg"] = np.frombuffer(b.getvalue(), np.uint8)
 out["dec_gray_q85_bgr"] = dec(b.getvalue())
+# progressive streams (cv::imdecode accepts them, src/app.cpp:296): libjpeg's default scan script - DC first, spectral bands,
+# successive-approximation refinement passes - for colour (4:4:4, 4:2:0, odd size, restart intervals) and grey
+for name, h, w, kw in [("prog_444_q85", 40, 40, dict(quality=85, subsampling=0)), ("prog_420_odd_q60", 33, 71, dict(quality=60, subsampling=2)),
+                       ("prog_422_q80", 37, 53, dict(quality=80, subsampling=1)), ("prog_420_rst", 48, 80, dict(quality=90, subsampling=2, restart_marker_blocks=2))]:
+    data = enc(noisy(60 + h, h, w), progressive=True, **kw)
+    out["dec_%s_jpg" % name] = np.frombuffer(data, np.uint8)
+    out["dec_%s_bgr" % name] = dec(data)
 b = io.BytesIO()
-Image.fromarray(noisy(31, 40, 40)[..., ::-1]).save(b, "JPEG", quality=85, progressive=True)
-out["unsupported_progressive_jpg"] = np.frombuffer(b.getvalue(), np.uint8)
+Image.fromarray(noisy(31, 40, 40)[..., 0]).save(b, "JPEG", quality=85, progressive=True)
+out["dec_prog_gray_q85_jpg"] = np.frombuffer(b.getvalue(), np.uint8)
+out["dec_prog_gray_q85_bgr"] = dec(b.getvalue())
+# an arithmetic-coded frame header (SOF9 in place of SOF0): must be refused, not mis-decoded
+arith = bytearray(out["dec_420_q95_jpg"].tobytes())
+arith[arith.index(b"\xff\xc0") + 1] = 0xC9
+out["unsupported_arithmetic_jpg"] = np.frombuffer(bytes(arith), np.uint8)
 for i, (h, w, q) in enumerate([(112, 112, 95), (112, 112, 75), (37, 53, 95), (16, 31, 95)]):
     img = noisy(40 + i, h, w)
     out["enc_%d_bgr" % i] = img

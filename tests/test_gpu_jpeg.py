@@ -23,7 +23,8 @@ def codec(frt):
     c.close()
 
 
-@pytest.mark.parametrize("name", ["444_q95", "422_q80", "420_q95", "420_odd_q60", "420_rst", "420_tiny", "420_q100", "gray_q85"])
+@pytest.mark.parametrize("name", ["444_q95", "422_q80", "420_q95", "420_odd_q60", "420_rst", "420_tiny", "420_q100", "gray_q85",
+                                  "prog_444_q85", "prog_420_odd_q60", "prog_422_q80", "prog_420_rst", "prog_gray_q85"])
 def test_device_decode_equals_libjpeg(codec, vec, name):
     got = codec.decode(vec["dec_%s_jpg" % name].tobytes())
     want = vec["dec_%s_bgr" % name]
@@ -38,7 +39,7 @@ def test_device_encode_equals_libjpeg(codec, vec, i):
 
 def test_unsupported_stream_is_reported(frt, codec, vec):
     with pytest.raises(frt.FrtError) as e:
-        codec.decode(vec["unsupported_progressive_jpg"].tobytes())
+        codec.decode(vec["unsupported_arithmetic_jpg"].tobytes())
     assert e.value.code == frt.FRT_ERR_FORMAT
 
 

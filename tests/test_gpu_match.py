@@ -236,3 +236,33 @@ def test_streaming_gallery_load_equals_init(frt, synth):
     with pytest.raises(frt.FrtError):
         mm.galleryAppend(g[0])                   # no load in progress
     mm.close()
+
+
+def test_screened_top1_pair_list_overflow_falls_back_to_the_exact_scan(frt, synth):
+    """Round 3: the screened search re-ranks (query, tile) pairs with a scalar kernel; when more pairs qualify than its list holds - a
+    gallery of identical rows puts EVERY tile within the rounding band of the maximum, a NaN query has no bound at all - the call is
+    answered by the unscreened exact scan instead.  Same answers as the materialised matrix, first index on ties."""
+    N = 50000
+    g = np.tile(synth.make_gallery(1), (N, 1))                      # all rows equal: every row attains the maximum, index 0 must win
+    q = np.concatenate([g[:1], synth.make_gallery(47, seed=5)])
+    m = frt.MatMul(0)
+    m.init(g)
+    i, s = m.top1(q)                                                # 48 queries x 391 tiles = 18 768 candidate pairs > the list's capacity
+    full = m.calculate(q)
+    assert np.array_equal(i, np.zeros(48, np.int32)) and np.array_equal(s, full.max(1)) and np.array_equal(full.argmax(1), i)
+    # the next call on the same object is an ordinary one again (the overflow flag is cleared per call)
+    g2 = synth.make_gallery(N)
+    g2[40000] = g2[9]
+    m.init(g2)
+    q2 = synth.make_queries(g2, [9, 40000, 777, 49999])
+    i2, s2 = m.top1(q2)
+    assert i2.tolist() == [9, 9, 777, 49999]
+    # a NaN / inf query: no rounding bound -> every tile -> fallback; the finite queries of the same call still get their exact answers
+    q3 = q2.copy()
+    q3[1, 5] = np.nan
+    q3[2, 7] = np.inf
+    i3, s3 = m.top1(q3)
+    full3 = m.calculate(q3)
+    assert i3[0] == 9 and i3[3] == 49999 and np.array_equal(s3[[0, 3]], full3.max(1)[[0, 3]])
+    assert i3[1] == -1                                              # every similarity of a NaN query is NaN: nothing is ever "greater"
+    m.close()

@@ -16,7 +16,8 @@ def vec():
     return np.load(os.path.join(GOLDEN, "jpeg_vectors.npz"))
 
 
-DEC = ["444_q95", "422_q80", "420_q95", "420_odd_q60", "420_rst", "420_tiny", "420_q100", "gray_q85"]
+DEC = ["444_q95", "422_q80", "420_q95", "420_odd_q60", "420_rst", "420_tiny", "420_q100", "gray_q85",
+       "prog_444_q85", "prog_420_odd_q60", "prog_422_q80", "prog_420_rst", "prog_gray_q85"]  # prog_*: progressive scan scripts (SOF2)
 
 
 @pytest.mark.parametrize("name", DEC)
@@ -25,7 +26,7 @@ def test_entropy_decode_plus_numpy_transforms_equal_libjpeg(frt, vec, name):
     data = vec["dec_%s_jpg" % name].tobytes()
     want = vec["dec_%s_bgr" % name]
     w, h, c = frt.jpeg_info(data)
-    assert (h, w) == want.shape[:2] and c == (1 if name.startswith("gray") else 3)
+    assert (h, w) == want.shape[:2] and c == (1 if "gray" in name else 3)
     geo, coef = frt.jpeg_read_coefficients(data)
     got = jpegops.decode_from_coefficients(geo, coef)
     assert np.array_equal(got, want), np.abs(got.astype(int) - want).max()
@@ -59,8 +60,8 @@ def test_live_against_pil_when_available(frt, synth):
 def test_bad_streams_are_errors_not_crashes(frt, vec):
     good = vec["dec_420_q95_jpg"].tobytes()
     with pytest.raises(frt.FrtError) as e:
-        frt.jpeg_info(vec["unsupported_progressive_jpg"].tobytes())
-    assert e.value.code == frt.FRT_ERR_FORMAT and "progressive" in str(e.value)
+        frt.jpeg_info(vec["unsupported_arithmetic_jpg"].tobytes())
+    assert e.value.code == frt.FRT_ERR_FORMAT and "arithmetic" in str(e.value)
     for bad in (b"", b"\xff\xd8", good[:40], good[:200], b"\x00" * 64, good[:2] + b"\xff\xc0\x00\x02" + good[2:]):
         with pytest.raises(frt.FrtError):
             frt.jpeg_read_coefficients(bad)
@@ -83,3 +84,38 @@ def test_base64_matches_the_standard_alphabet(frt):
     for n in (0, 1, 2, 3, 4, 57, 1000, 10368):
         data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         assert frt.base64_encode(data) == base64.b64encode(data).decode()
+
+
+def test_progressive_coefficients_equal_the_sequential_coding_of_the_same_image(frt):
+    """A progressive stream carries the SAME quantised coefficients as the baseline coding of the image, spread over DC / AC first and
+    refinement scans; the progressive entropy decoder (csrc/frt_jpeg.cpp: decode_progressive, ITU T.81 Annex G) must reassemble them
+    exactly.  Needs PIL to write the two codings (skipped without it; the committed prog_* vectors above cover the decoder regardless)."""
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    r = np.random.default_rng(3)
+    for (h, w), kw in [((40, 40), dict(quality=85)), ((33, 71), dict(quality=60, subsampling=2)), ((120, 200), dict(quality=95, subsampling=0)),
+                       ((5, 3), dict(quality=90)), ((48, 80), dict(quality=90, subsampling=2, restart_marker_blocks=3))]:
+        img = r.integers(0, 256, (h, w, 3)).astype(np.uint8)
+
+        def enc(**k):
+            b = io.BytesIO()
+            Image.fromarray(img).save(b, "JPEG", **k)
+            return b.getvalue()
+        g0, c0 = frt.jpeg_read_coefficients(enc(**kw))
+        g1, c1 = frt.jpeg_read_coefficients(enc(progressive=True, **kw))
+        assert np.array_equal(c0, c1) and g0["width"] == g1["width"] and [c["bw"] for c in g0["comps"]] == [c["bw"] for c in g1["comps"]]
+    # truncated / damaged progressive streams: an error or partial data, never a crash
+    good = enc(progressive=True, quality=90)
+    for cut in range(0, len(good), max(1, len(good) // 60)):
+        try:
+            frt.jpeg_read_coefficients(good[:cut])
+        except frt.FrtError:
+            pass
+    for _ in range(200):
+        b = bytearray(good)
+        for k in r.integers(2, len(good) - 2, 3):
+            b[k] = int(r.integers(0, 256))
+        try:
+            frt.jpeg_read_coefficients(bytes(b))
+        except frt.FrtError:
+            pass
