@@ -1043,12 +1043,6 @@ static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
     return wide ? CV_G3_22 : CV_G3_14;
 }
 
-// weight-ring depth of the short-strip variants: 9 (tuning build: FRT_CONV_SMALL_WR=3 restores the 3-deep ring)
-static bool small_wr9() {
-    static const bool v = !(frt_tuning_env("FRT_CONV_SMALL_WR") && frt_tuning_env("FRT_CONV_SMALL_WR")[0] == '3');
-    return v;
-}
-
 const char *conv_kernel_label(const ConvMfmaArgs &a) {
     static const char *names[] = {"conv_mfma_kernel<2, 2>", "conv_mfma_kernel<1, 4>", "conv_glds_kernel<2, 2, 2, 0>", "conv_glds_kernel<1, 4, 2, 0>",
                                   "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true, 7, 2, 3>",
@@ -1059,10 +1053,7 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
-    const int variant = conv_variant(a, R, n_img);
-    const char *base = names[variant];
-    if ((variant == CV_P_NT1 || variant == CV_P_NT2) && small_wr9())
-        base = variant == CV_P_NT2 ? "conv_patch_kernel<5, 1, 5, false, 0, false, 2, 1, 9>" : "conv_patch_kernel<5, 1, 5, false, 0, false, 1, 1, 9>";
+    const char *base = names[conv_variant(a, R, n_img)];
     if (!strncmp(base, "conv_patch_kernel", 17)) {  // the strip kernel's symbol carries a tenth argument: SE tail in the epilogue or not
         static thread_local char buf[96];
         snprintf(buf, sizeof(buf), "%.*s, %s>", (int)strlen(base) - 1, base, a.mode == EPI_BN_SE ? "true" : "false");
@@ -1130,14 +1121,12 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
 #endif
             if (a.mode == EPI_BN_SE) return launch_patch_t<10, 1, 5, false, 0, false, 4, 1, 3, true>(a, R, n_img, s);  // (conv_se_fused)
             return launch_patch_t<10, 1, 5, false, 0, false, 4, 1>(a, R, n_img, s);
-        // short strips (small batches): 1 - 2 accumulator tiles leave ~200 registers free, so the weight ring may run 8 steps ahead
-        // instead of 2 (a workgroup of a 4-face batch streams its 590 KB of weights at whatever is in flight / latency)
-        case CV_P_NT2:
-            if (small_wr9()) return launch_patch_t<5, 1, 5, false, 0, false, 2, 1, 9>(a, R, n_img, s);
-            return launch_patch_t<5, 1, 5, false, 0, false, 2, 1>(a, R, n_img, s);
-        case CV_P_NT1:
-            if (small_wr9()) return launch_patch_t<5, 1, 5, false, 0, false, 1, 1, 9>(a, R, n_img, s);
-            return launch_patch_t<5, 1, 5, false, 0, false, 1, 1>(a, R, n_img, s);
+        // (Round 3, measured and not kept: a 9-deep weight ring for these short-strip variants - 1 or 2 accumulator tiles leave the
+        //  registers for it.  4 / 16 / 32 faces: 12.4 -> 12.0, 14.0 -> 13.5, 18.7 -> 18.9 us per launch, batch-1 call 1.286 -> 1.280 ms
+        //  (profiles/r03f_small_batch_wr.txt): a small-batch launch is prologue + four chunk hand-overs + epilogue + dispatch, not
+        //  weight latency.)
+        case CV_P_NT2: return launch_patch_t<5, 1, 5, false, 0, false, 2, 1>(a, R, n_img, s);
+        case CV_P_NT1: return launch_patch_t<5, 1, 5, false, 0, false, 1, 1>(a, R, n_img, s);
         case CV_V1_22: return launch_conv_t<2, 2>(a, s);
         case CV_V1_14: return launch_conv_t<1, 4>(a, s);
         case CV_G2_22:
