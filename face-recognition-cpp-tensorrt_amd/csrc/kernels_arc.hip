@@ -1053,7 +1053,8 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
     int R, n_img;
-    const char *base = names[conv_variant(a, R, n_img)];
+    const int variant = conv_variant(a, R, n_img);
+    const char *base = names[variant];
     if (!strncmp(base, "conv_patch_kernel", 17)) {  // the strip kernel's symbol carries a tenth argument: SE tail in the epilogue or not
         static thread_local char buf[96];
         snprintf(buf, sizeof(buf), "%.*s, %s>", (int)strlen(base) - 1, base, a.mode == EPI_BN_SE ? "true" : "false");
@@ -1112,6 +1113,11 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
 #endif
             if (a.mode == EPI_BN_SE)  // IR-SE conv2 with the whole SE tail in the epilogue (the caller checked conv_se_fused)
                 return launch_patch_t<10, 1, 5, false, 0, false, 7, 1, 3, true>(a, R, n_img, s);
+            // (Round 3, built, measured and parked in tools/experiments/conv_patch2_two_cout_blocks_per_wave.hip: a wave owning TWO cout
+            //  blocks x half the pixel tiles, so that a B fragment read from LDS feeds two MFMAs - half the LDS bytes per MFMA at 256
+            //  registers, parity tests green.  40.9 -> 43.2 us per launch, pipelined step 3.274 -> 3.348 ms (profiles/r03g_patch2_*):
+            //  the 4 + 3 split of 7 tiles puts 8 MFMA slots per kk step on the critical SIMDs, and the K loop was never LDS-bound - it
+            //  runs at 78 % of the rate the part sustains on back-to-back MFMAs with real operands.)
             return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
         case CV_P_255_NT4:
