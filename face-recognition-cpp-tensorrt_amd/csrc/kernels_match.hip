@@ -619,7 +619,8 @@ __device__ __forceinline__ float unmono_bits(unsigned m) { return __uint_as_floa
 // entry within 2*delta of it becomes a pair
 __global__ __launch_bounds__(256) void match_select_pairs_kernel(const float *__restrict__ tilemax, int num_tiles, const float *__restrict__ wgmax, int n_wg,
                                                                  int F, const float *__restrict__ Q, int D, float gmax_norm, MatchPair *__restrict__ pairs,
-                                                                 int pair_cap, int *__restrict__ ctl) {
+                                                                 int pair_cap, int *__restrict__ ctl, const float *__restrict__ kth = nullptr) {
+    // kth != nullptr (top-k): the threshold hangs on the query's k-th largest coarse entry (match_kth_kernel; see match_select_kernel)
     __shared__ float sm[4], sn[4];
     __shared__ int snan[4];
     const int q = blockIdx.y, seg = blockIdx.x, tid = threadIdx.x;
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(256) void match_select_pairs_kernel(const float *__
     }
     __syncthreads();
     m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (kth) m = kth[q];
     const bool anynan = snan[0] | snan[1] | snan[2] | snan[3];
     const float qn = sqrtf(sn[0] + sn[1] + sn[2] + sn[3]);
     const float delta = 1.2e-3f * qn * gmax_norm;
@@ -664,7 +666,11 @@ __global__ __launch_bounds__(256) void match_select_pairs_kernel(const float *__
 // one workgroup (128 threads = the tile's 128 rows) per pair, pairs dealt round-robin over the grid
 template <typename GT>
 __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__restrict__ G, int N, int D, const float *__restrict__ E, const MatchPair *__restrict__ pairs,
-                                                                 int pair_cap, const int *__restrict__ ctl, unsigned long long *__restrict__ qkey) {
+                                                                 int pair_cap, const int *__restrict__ ctl, unsigned long long *__restrict__ qkey,
+                                                                 const float *__restrict__ prev_sim = nullptr, const int32_t *__restrict__ prev_idx = nullptr,
+                                                                 int prev_stride = 1, int row_offset = 0) {
+    // prev_sim != nullptr (top-k pass j > 0): only rows strictly AFTER the query's previous winner (its similarity, its GLOBAL index) in the
+    // result order take part - the EXCL rule of match_kernel
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     float *qs = reinterpret_cast<float *>(smem3);  // [D]
     __shared__ float rv[2];
@@ -695,6 +701,14 @@ __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__res
         }
         float v = g < N ? acc : -INFINITY;
         int i = g < N ? (int)g : INT_MAX;
+        if (prev_sim && i != INT_MAX) {
+            const float ps = prev_sim[(long)pr.q * prev_stride];
+            const int pi = prev_idx[(long)pr.q * prev_stride];
+            if (!((v < ps) || (v == ps && i + row_offset > pi))) {
+                v = -INFINITY;
+                i = INT_MAX;
+            }
+        }
         if (v != v) {  // NaN never wins (std::max_element with operator<: a NaN is never greater)
             v = -INFINITY;
             i = INT_MAX;
@@ -722,13 +736,14 @@ __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__res
     }
 }
 
-__global__ __launch_bounds__(256) void match_unpack_kernel(const unsigned long long *__restrict__ qkey, int F, int row_offset, const int *__restrict__ ctl,
-                                                           int32_t *__restrict__ idx_out, float *__restrict__ sim_out) {
+__global__ __launch_bounds__(256) void match_unpack_kernel(unsigned long long *__restrict__ qkey, int F, int row_offset, const int *__restrict__ ctl,
+                                                           int32_t *__restrict__ idx_out, float *__restrict__ sim_out, int out_stride = 1) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= F || ctl[CTL_OVERFLOW]) return;
     const unsigned long long k = qkey[q];
-    idx_out[q] = k ? (int)(~(unsigned)(k & 0xffffffffull)) + row_offset : -1;
-    sim_out[q] = k ? unmono_bits((unsigned)(k >> 32)) : -INFINITY;
+    qkey[q] = 0ull;  // ready for the next top-k pass of this call
+    idx_out[(long)q * out_stride] = k ? (int)(~(unsigned)(k & 0xffffffffull)) + row_offset : -1;
+    sim_out[(long)q * out_stride] = k ? unmono_bits((unsigned)(k >> 32)) : -INFINITY;
 }
 
 template <int NQ, bool FULL, typename GT = float, bool EXCL = false>
@@ -864,6 +879,39 @@ static void screen_tiles(const half_t *g16, int N, int D, const float *queries, 
 void launch_match_topk(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, int k, bool screen, float gmax_norm,
                        const ScreenScratch &w, float *kth_scratch, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,
                        int row_offset, hipStream_t s) {
+    const int tiles_ = (N + BM - 1) / BM;
+    if (screen && w.pairs && w.wgmax && tiles_ >= COARSE_WG) {
+        // fast path (round 3): ONE coarse scan, (query, tile) pairs within the rounding band of the k-th largest coarse entry, then k
+        // passes of the scalar pair re-rank (a few microseconds each), pass j restricted to the rows behind winner j - 1.  With the
+        // all-gathered queries of a node (configs[4]: 2 048 of them per rank) the tile-list path would re-rank every query against every
+        // listed tile, k times.
+        switch (D) {
+            case 64: launch_coarse_t<64>(g16, N, nullptr, F, w.tilemax, tiles_, s, queries, w.wgmax, w.ctl, w.qkey); break;
+            case 128: launch_coarse_t<128>(g16, N, nullptr, F, w.tilemax, tiles_, s, queries, w.wgmax, w.ctl, w.qkey); break;
+            case 256: launch_coarse_t<256>(g16, N, nullptr, F, w.tilemax, tiles_, s, queries, w.wgmax, w.ctl, w.qkey); break;
+            default: launch_coarse_t<512>(g16, N, nullptr, F, w.tilemax, tiles_, s, queries, w.wgmax, w.ctl, w.qkey); break;
+        }
+        hipLaunchKernelGGL(match_kth_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles_ * 4, k, kth_scratch);
+        hipLaunchKernelGGL(match_select_pairs_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles_, w.wgmax, COARSE_WG, F, queries, D, gmax_norm,
+                           reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl, (const float *)kth_scratch);
+        const int *gate = w.ctl + CTL_OVERFLOW;
+        for (int j = 0; j < k; ++j) {
+            const float *ps = j ? sim_out + (j - 1) : nullptr;
+            const int32_t *pi = j ? idx_out + (j - 1) : nullptr;
+            if (gallery)
+                hipLaunchKernelGGL((match_rerank_pairs_kernel<float>), dim3(1024), dim3(128), (size_t)D * sizeof(float), s, gallery, N, D, queries,
+                                   reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, ps, pi, k, row_offset);
+            else
+                hipLaunchKernelGGL((match_rerank_pairs_kernel<half_t>), dim3(1024), dim3(128), (size_t)D * sizeof(float), s, g16, N, D, queries,
+                                   reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, ps, pi, k, row_offset);
+            hipLaunchKernelGGL(match_unpack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, w.qkey, F, row_offset, w.ctl, idx_out + j, sim_out + j, k);
+            // pair-list overflow: the unscreened exact scan answers this pass instead (gated on the flag)
+            if (gallery) launch_t<4, false, float, true>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k, gate);
+            else launch_t<4, false, half_t, true>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k, gate);
+            hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out + j, sim_out + j, k, gate);
+        }
+        return;
+    }
     if (screen) screen_tiles(g16, N, D, queries, F, gmax_norm, w, k, kth_scratch, s);
     for (int j = 0; j < k; ++j) {
         const float *ps = j ? sim_out + (j - 1) : nullptr;
@@ -909,15 +957,15 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
         }
         // (with F > 128 every query block y writes its own columns of wgmax: [n_wg][F])
         hipLaunchKernelGGL(match_select_pairs_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles, w.wgmax, n_wg, F, queries, D, gmax_norm,
-                           reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl);
+                           reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl, (const float *)nullptr);
         const int rr_grid = 1024;
         if (gallery)
             hipLaunchKernelGGL((match_rerank_pairs_kernel<float>), dim3(rr_grid), dim3(128), (size_t)D * sizeof(float), s, gallery, N, D, queries,
-                               reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey);
+                               reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, (const float *)nullptr, (const int32_t *)nullptr, 1, 0);
         else
             hipLaunchKernelGGL((match_rerank_pairs_kernel<half_t>), dim3(rr_grid), dim3(128), (size_t)D * sizeof(float), s, g16, N, D, queries,
-                               reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey);
-        hipLaunchKernelGGL(match_unpack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, w.qkey, F, row_offset, w.ctl, idx_out, sim_out);
+                               reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, (const float *)nullptr, (const int32_t *)nullptr, 1, 0);
+        hipLaunchKernelGGL(match_unpack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, w.qkey, F, row_offset, w.ctl, idx_out, sim_out, 1);
         // overflow (more candidate pairs than the list holds): the unscreened exact scan answers instead - launched always, gated on the flag
         const int *gate = w.ctl + CTL_OVERFLOW;
         if (gallery) launch_t<4, false, float>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, nullptr, nullptr, 1, gate);

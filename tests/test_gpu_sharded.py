@@ -144,3 +144,33 @@ def test_two_shards_merged_on_the_device_equal_the_whole_gallery(frt, synth):
     assert np.array_equal(hi, oi.cpu().numpy()) and np.array_equal(hs, os_.cpu().numpy())
     for mm in mms:
         mm.close()
+
+
+def test_topk_pair_list_overflow_falls_back_to_the_exact_scan(frt, synth):
+    """top-k on a gallery of identical rows: every tile qualifies for every query, the pair list overflows and each of the k passes is answered
+    by the unscreened exact scan with the exclusion rule - the list is rows 0, 1, 2 with identical similarities."""
+    N, k = 45000, 3
+    g = np.tile(synth.make_gallery(1), (N, 1))
+    q = np.concatenate([g[:1], synth.make_gallery(39, seed=8)])
+    m = frt.MatMul(0)
+    m.init(g)
+    i, s = m.topk(q, k)
+    assert np.array_equal(i, np.tile(np.arange(k, dtype=np.int32), (40, 1)))
+    assert np.array_equal(s[:, 0], s[:, 1]) and np.array_equal(s[:, 1], s[:, 2]) and np.array_equal(s[:, 0], m.top1(q)[1])
+    m.close()
+
+
+def test_topk_with_two_thousand_queries_on_the_shard(frt, synth, shard):
+    """configs[4] at N = 8: every rank searches the 8 x 256 all-gathered queries of the node against its shard."""
+    from oracle import match
+    g, mm = shard
+    F, k = 2048, 5
+    q, idx = queries(synth, g, F, 11)
+    gi, gs = mm.topk(q, k)
+    pick = np.concatenate([np.arange(12), np.arange(1000, 1040), np.arange(F - 8, F)])  # the oracle on a sample (it is O(F N) on the host)
+    wi, ws = match.topk(q[pick], g, k, row_offset=OFFSET)
+    assert np.array_equal(gi[pick], wi) and np.abs(gs[pick] - ws).max() < SIM_TOL
+    i1, s1 = mm.top1(q)
+    assert np.array_equal(gi[:, 0], i1) and np.array_equal(gs[:, 0], s1)      # entry 0 is the top-1 answer, bit for bit
+    assert np.array_equal(gi[10:, 0], idx[10:] + OFFSET)                       # planted rows win (the first ten are the duplicated ones)
+    assert (np.diff(gs, axis=1) <= 0).all()                                    # lists are sorted
