@@ -808,7 +808,15 @@ __global__ __launch_bounds__(512) void fc_finalize_kernel(const float *__restric
                                                           const int *__restrict__ valid, float *__restrict__ out) {
     const int f = blockIdx.x, o = threadIdx.x;
     float v = 0.f;
-    for (int k = 0; k < splits; ++k) v += partial[((long)k * F + f) * 512 + o];
+    if (splits == 49) {  // the recogniser's 7x7 slices: all 49 loads in flight, then added in slice order (128 blocks cannot hide a dependent load chain)
+        float t[49];
+#pragma unroll
+        for (int k = 0; k < 49; ++k) t[k] = partial[((long)k * F + f) * 512 + o];
+#pragma unroll
+        for (int k = 0; k < 49; ++k) v += t[k];
+    } else {
+        for (int k = 0; k < splits; ++k) v += partial[((long)k * F + f) * 512 + o];
+    }
     v = (v + bias[o]) * s[o] + b[o];
     float sq = v * v;
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
@@ -1117,7 +1125,7 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             //  blocks x half the pixel tiles, so that a B fragment read from LDS feeds two MFMAs - half the LDS bytes per MFMA at 256
             //  registers, parity tests green.  40.9 -> 43.2 us per launch, pipelined step 3.274 -> 3.348 ms (profiles/r03g_patch2_*):
             //  the 4 + 3 split of 7 tiles puts 8 MFMA slots per kk step on the critical SIMDs, and the K loop was never LDS-bound - it
-            //  runs at 78 % of the rate the part sustains on back-to-back MFMAs with real operands.)
+            //  runs at 0.94 of the rate the part sustains for its instruction mix.)
             return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
         case CV_P_255_NT4:

@@ -608,6 +608,7 @@ struct MatchPair {
     int q, tile;
 };
 constexpr int CTL_COUNT = 0, CTL_OVERFLOW = 1;
+constexpr int FB_BLOCKS = 128;  // workgroups of the gated fallback scan (it returns at once in the normal case: keep the empty launch small)
 
 __device__ __forceinline__ unsigned mono_bits(float f) {
     const unsigned u = __float_as_uint(f);
@@ -689,7 +690,8 @@ __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__res
         if (g < N) {
             // k order of the exact kernel: per 32-wide step, for ks in 0..3, for s in 0..3: k = 8 ks + s (lanes 0-31 of the MFMA), then
             // k = 8 ks + 4 + s (lanes 32-63) - one fused multiply-add each
-            for (int k0 = 0; k0 < D; k0 += 8) {
+#pragma unroll 8
+            for (int k0 = 0; k0 < D; k0 += 8) {  // (unrolled: 16 row loads in flight per thread; the fma chain itself stays sequential)
                 const floatx4 a = load_g4(G, g, D, k0), b = load_g4(G, g, D, k0 + 4);
                 const floatx4 x = *reinterpret_cast<const floatx4 *>(qs + k0), y = *reinterpret_cast<const floatx4 *>(qs + k0 + 4);
 #pragma unroll
@@ -736,10 +738,28 @@ __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__res
     }
 }
 
+// Last kernel of a pass.  Normal case: the packed winners of the pair re-rank.  Overflow case: the gated exact scan ran in front of this
+// kernel (fb_blocks workgroups); its per-workgroup partials are reduced here, one thread per query, with the same first-maximum rule.
 __global__ __launch_bounds__(256) void match_unpack_kernel(unsigned long long *__restrict__ qkey, int F, int row_offset, const int *__restrict__ ctl,
-                                                           int32_t *__restrict__ idx_out, float *__restrict__ sim_out, int out_stride = 1) {
+                                                           int32_t *__restrict__ idx_out, float *__restrict__ sim_out, int out_stride,
+                                                           const MatchPartial *__restrict__ fb_partial, int fb_blocks) {
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= F || ctl[CTL_OVERFLOW]) return;
+    if (q >= F) return;
+    if (ctl[CTL_OVERFLOW]) {
+        float v = -INFINITY;
+        int i = INT_MAX;
+        for (int b = 0; b < fb_blocks; ++b) {
+            const MatchPartial p = fb_partial[(long)b * F + q];
+            if (p.idx >= 0 && better(p.sim, p.idx, v, i)) {
+                v = p.sim;
+                i = p.idx;
+            }
+        }
+        qkey[q] = 0ull;
+        idx_out[(long)q * out_stride] = i == INT_MAX ? -1 : i;  // (the scan's partial indices already carry the row offset)
+        sim_out[(long)q * out_stride] = v;
+        return;
+    }
     const unsigned long long k = qkey[q];
     qkey[q] = 0ull;  // ready for the next top-k pass of this call
     idx_out[(long)q * out_stride] = k ? (int)(~(unsigned)(k & 0xffffffffull)) + row_offset : -1;
@@ -904,11 +924,11 @@ void launch_match_topk(const float *gallery, const half_t *g16, int N, int D, co
             else
                 hipLaunchKernelGGL((match_rerank_pairs_kernel<half_t>), dim3(1024), dim3(128), (size_t)D * sizeof(float), s, g16, N, D, queries,
                                    reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, ps, pi, k, row_offset);
-            hipLaunchKernelGGL(match_unpack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, w.qkey, F, row_offset, w.ctl, idx_out + j, sim_out + j, k);
-            // pair-list overflow: the unscreened exact scan answers this pass instead (gated on the flag)
-            if (gallery) launch_t<4, false, float, true>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k, gate);
-            else launch_t<4, false, half_t, true>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, ps, pi, k, gate);
-            hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out + j, sim_out + j, k, gate);
+            // pair-list overflow: the unscreened exact scan answers this pass instead (gated on the flag; see the top-1 path)
+            const int fb = partial_blocks < FB_BLOCKS ? partial_blocks : FB_BLOCKS;
+            if (gallery) launch_t<4, false, float, true>(gallery, N, D, queries, F, partial, nullptr, fb, row_offset, s, nullptr, nullptr, ps, pi, k, gate);
+            else launch_t<4, false, half_t, true>(g16, N, D, queries, F, partial, nullptr, fb, row_offset, s, nullptr, nullptr, ps, pi, k, gate);
+            hipLaunchKernelGGL(match_unpack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, w.qkey, F, row_offset, w.ctl, idx_out + j, sim_out + j, k, partial, fb);
         }
         return;
     }
@@ -965,12 +985,13 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
         else
             hipLaunchKernelGGL((match_rerank_pairs_kernel<half_t>), dim3(rr_grid), dim3(128), (size_t)D * sizeof(float), s, g16, N, D, queries,
                                reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, (const float *)nullptr, (const int32_t *)nullptr, 1, 0);
-        hipLaunchKernelGGL(match_unpack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, w.qkey, F, row_offset, w.ctl, idx_out, sim_out, 1);
-        // overflow (more candidate pairs than the list holds): the unscreened exact scan answers instead - launched always, gated on the flag
+        // overflow (more candidate pairs than the list holds): the unscreened exact scan answers instead - launched always, gated on the
+        // flag (FB_BLOCKS workgroups that return at once in the normal case); the unpack kernel behind it finishes either path
         const int *gate = w.ctl + CTL_OVERFLOW;
-        if (gallery) launch_t<4, false, float>(gallery, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, nullptr, nullptr, 1, gate);
-        else launch_t<4, false, half_t>(g16, N, D, queries, F, partial, nullptr, partial_blocks, row_offset, s, nullptr, nullptr, nullptr, nullptr, 1, gate);
-        hipLaunchKernelGGL(match_reduce_kernel, dim3(F), dim3(64), 0, s, partial, partial_blocks, F, idx_out, sim_out, 1, gate);
+        const int fb = partial_blocks < FB_BLOCKS ? partial_blocks : FB_BLOCKS;
+        if (gallery) launch_t<4, false, float>(gallery, N, D, queries, F, partial, nullptr, fb, row_offset, s, nullptr, nullptr, nullptr, nullptr, 1, gate);
+        else launch_t<4, false, half_t>(g16, N, D, queries, F, partial, nullptr, fb, row_offset, s, nullptr, nullptr, nullptr, nullptr, 1, gate);
+        hipLaunchKernelGGL(match_unpack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, w.qkey, F, row_offset, w.ctl, idx_out, sim_out, 1, partial, fb);
         return;
     }
     const long q8 = (long)F * D / 8;

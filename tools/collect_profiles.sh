@@ -66,8 +66,10 @@ python bench.py --batch 1 --gallery 10000 --no-cpu-baseline > "$OUT/${TAG}_bench
 python bench.py --faces 1 --no-cpu-baseline > "$OUT/${TAG}_bench_k1.json" 2>/dev/null
 FRT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_rccl_1rank.json"
 FRT_BENCH_FORCE_DIST=1 python bench.py --sharded-gallery --batch 64 --gallery 1250000 --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_sharded_1rank.json"
+# 3b. the drop-in shells measured (src/app.cpp:304-310 through include/frt/*.h, 1 and 8 threads, N = 1M)
+python tools/dropin_bench.py --gallery 1000000 --threads 1 8 --iters 150 --out "$OUT/${TAG}_dropin_bench.json" > /dev/null 2>&1
 # 4. the microbenchmarks DESIGN.md quotes (sources in tools/ubench/*.hip)
-for P in clock_probe occ_probe; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/$P "$ROOT/tools/ubench/$P.hip" 2>/dev/null && timeout 120 /tmp/$P > "$OUT/${TAG}_$P.txt" 2>&1
+for P in clock_probe occ_probe mfma_f32_order; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -w -o /tmp/$P "$ROOT/tools/ubench/$P.hip" 2>/dev/null && timeout 120 /tmp/$P > "$OUT/${TAG}_$P.txt" 2>&1
 done
 ls -la "$OUT"
