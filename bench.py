@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resident", action="store_true", help="primary timed region with frames/results resident in HBM (frt_pipeline_run_dev)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: ONE batch of --batch frames split over the ranks (BASELINE configs[3])")
+    ap.add_argument("--in-flight", type=int, default=DEPTH, help="batches in flight at the host boundary (1..4; default 3).  With --strong every rank "
+                                                                 "keeps this many of its small batches in the stage pipeline at once")
     ap.add_argument("--sharded-gallery", action="store_true",
                     help="BASELINE configs[4]: gallery row-sharded over the ranks and stored as fp16; RCCL all-gather of embeddings and of the top-1 winners")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step RCCL all-gather of the result records")
@@ -214,6 +216,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (no side measurements)")
     ap.add_argument("--smi-trace", default=None, help="write the rocm-smi power/clock samples taken during the timed region to this file")
     args = ap.parse_args()
+    depth = max(1, min(4, args.in_flight))
 
     import torch
     import torch.distributed as dist
@@ -324,7 +327,7 @@ def main():
         """pinned host frames -> host records, DEPTH batches in flight (frt_pipeline_submit / frt_pipeline_wait)."""
         tickets = []
         for i in range(n_steps):
-            if len(tickets) >= DEPTH:
+            if len(tickets) >= depth:
                 pipe.wait(tickets.pop(0))
             if i == profile_step:
                 frt.profile_enable(1)
@@ -352,7 +355,7 @@ def main():
                 ev_side[slot].record(side)
 
         for i in range(n_steps):
-            if len(tickets) >= DEPTH:
+            if len(tickets) >= depth:
                 t, slot = tickets.pop(0)
                 pipe.wait(t)
                 gather_async(slot)
@@ -620,7 +623,7 @@ def main():
                    "then lower global index)" % (world, world, (args.gallery + world - 1) // world, args.topk))
         else:
             boundary = ("HBM-resident frames -> HBM-resident records (frt_pipeline_run_dev)" if args.resident else
-                        "pinned host frames -> host records, %d batches in flight (frt_pipeline_submit/wait)" % DEPTH)
+                        "pinned host frames -> host records, %d batches in flight (frt_pipeline_submit/wait)" % depth)
             par = "frames sharded dp%d (%s), gallery replicated, no data-path collective%s" % (
                 world, "strong: one batch split over the ranks" if args.strong else "weak: every rank its own batch",
                 "; RCCL all-gather of every step's result records on a side stream inside the timed region" if gather else "")
