@@ -217,6 +217,13 @@ def main():
     ap.add_argument("--smi-trace", default=None, help="write the rocm-smi power/clock samples taken during the timed region to this file")
     args = ap.parse_args()
     depth = max(1, min(4, args.in_flight))
+    # Hardware queues (read by the HIP runtime when it initialises, i.e. before torch / libfrt are imported).  ROCm multiplexes a process's
+    # streams onto GPU_MAX_HW_QUEUES (default 4) in-order hardware queues per priority class.  Alone, the pipeline is 1.2 % faster on the
+    # default (39.05 k against 38.5 - 38.7 k faces/s with 6 / 8 / 12 queues, one box); with RCCL in the process and the per-step record
+    # gather running on its own stream (N > 1) four queues put that stream's copies and collective in front of pipeline work: 35.25 k
+    # against 38.4 - 38.6 k with 6 / 8 / 12 (same box, alternating runs, profiles/r03l_hw_queues.txt).  So: 8 whenever a communicator exists.
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("FRT_BENCH_FORCE_DIST") == "1":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     import torch.distributed as dist
@@ -268,6 +275,19 @@ def main():
         rec.initMatMul()
     gallery_load_s = time.perf_counter() - t_load
     pipe = frt.Pipeline(det, rec, B, match=not args.sharded_gallery)  # sharded gallery: the pipeline produces embeddings, match + merge follow below
+    # The caller's stream (NOT torch's default stream: that is the legacy NULL stream, and every operation on it - an event record, a
+    # collective's stream hand-over - is a barrier against all blocking streams, including the pipeline's stage streams: measured 7.9
+    # instead of 3.6 ms per step) is created, handed to the pipeline and USED once - so that the pipeline's lazily created upload stream
+    # exists too - before any other stream user of the process (RCCL's process group, libfrt's communicator) comes into being.  Measured
+    # with tools/queue_probe.py: in this order every later stream creation leaves the step alone (0.78 ms per 4-frame step); a caller's
+    # stream that first meets the pipeline after RCCL's streams exist can cost 2x at small batches (1.65 ms) and 4.5 % at 32 frames.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    pipe.set_stream(stream.cuda_stream)
+    _prime = s.make_frames(B, FH, FW, start=frame_start + 9000)
+    pipe.run(_prime, want_embeds=False)
+    pipe.run(_prime, want_embeds=False)
+    del _prime
     if use_dist:
         # AFTER the pipeline exists: RCCL creates streams of its own, and a stream created before the pipeline's stage streams can change
         # how ROCm maps those onto hardware queues (the stages then share a queue with somebody's pending waits and stop overlapping)
@@ -295,12 +315,6 @@ def main():
     d_res = [torch.zeros(F * RD.itemsize, dtype=torch.uint8, device="cuda") for _ in range(NRING)]
     d_all = [torch.zeros(world * F * RD.itemsize, dtype=torch.uint8, device="cuda") for _ in range(NRING)] if use_dist else None
     h_all = [torch.zeros(world * F * RD.itemsize, dtype=torch.uint8).pin_memory() for _ in range(NRING)] if use_dist else None
-    # NOT torch's default stream: that is the legacy NULL stream, and every operation on it (an event record, a collective's stream
-    # hand-over) is a barrier against all blocking streams - including the pipeline's stage streams - which serialises the stages
-    # (measured: 7.9 instead of 3.6 ms per step).  Everything below runs on an ordinary stream.
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    pipe.set_stream(stream.cuda_stream)
     # the exchange stream: H2D of the records, ncclAllGather, D2H.  A torch-owned stream handed to frt_comm_all_gather (a C++ host would use
     # the communicator's own, frt_comm_stream): torch's pinned-memory allocator records events on every stream a pinned block was used
     # on when the block is freed, so the stream must outlive the tensors - which a stream owned by the communicator would not at exit
@@ -347,6 +361,8 @@ def main():
         tickets = []
 
         def gather_async(slot):
+            if not gather:
+                return
             with torch.cuda.stream(side):
                 d_res[slot].copy_(h_res[slot], non_blocking=True)
                 if gather:
@@ -360,7 +376,7 @@ def main():
                 pipe.wait(t)
                 gather_async(slot)
             slot = i % 4
-            if i >= 4:
+            if i >= 4 and gather:
                 ev_side[slot].synchronize()       # the slot's previous records have left the host buffer (long done)
             if i == profile_step:
                 frt.profile_enable(1)

@@ -1205,12 +1205,17 @@ struct frt_pipeline {
     };
     AsyncBuf abuf[NBUF];
     hipStream_t copy_stream = nullptr;
+    int copy_prio = 0;
     hipEvent_t ev_frames = nullptr;  // set by submit for the next run(): the detector stream waits for it
     long next_ticket = 0;
     std::mutex async_mu;
     void ensure_async() {
         if (copy_stream) return;
-        HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        // The upload stream sits in the stage streams' priority class (its own hardware-queue pool): as a normal-priority stream it is
+        // dealt round-robin onto the four queues the CALLER's streams live on, and whenever it lands on the queue of the caller's joining
+        // stream the next batch's upload sits behind the pending joins of the batches in flight (measured with RCCL's streams in the
+        // process: 4-frame step 0.96 -> 1.69 ms, 32-frame step 3.28 -> 3.45 ms).  copy_prio: see frt_pipeline_create.
+        HIPCHK(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, copy_prio));
         const size_t F = (size_t)F_cap;
         for (AsyncBuf &b : abuf) {
             b.d_frames = arena.alloc<uint8_t>((size_t)max_frames * det->g.frame_h * det->g.frame_w * 3);
@@ -1325,18 +1330,94 @@ struct frt_pipeline {
         }
         return worst;
     }
+    // Does a wait that is PENDING on stream `j` hold up work on stream `x`?  That is what sharing a hardware queue means for this
+    // pipeline: kernels of two streams multiplexed onto one queue may still run side by side, but a queue is in-order, so the caller's
+    // stream - on which every call leaves "wait for the end of my match stage" - blocks whatever stream shares its queue until that
+    // call has finished, and consecutive calls serialise.  Test: a 400 us probe kernel on `g`, an event behind it that `j` waits for,
+    // then a 20 us probe on `x`: finished long before the gate opens (ratio << 1) or only behind it (>= 1).
+    float blocked_by_wait(hipStream_t j, hipStream_t x, hipStream_t g) {
+        hipEvent_t e0, gate, xb;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&gate));
+        HIPCHK(hipEventCreate(&xb));
+        for (hipStream_t st : {j, x, g}) HIPCHK(hipStreamSynchronize(st));
+        float worst = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {
+            HIPCHK(hipEventRecord(e0, g));
+            launch_spin(400.0, g);
+            HIPCHK(hipEventRecord(gate, g));
+            HIPCHK(hipStreamWaitEvent(j, gate, 0));
+            launch_spin(20.0, x);
+            HIPCHK(hipEventRecord(xb, x));
+            HIPCHK(hipEventSynchronize(xb));
+            HIPCHK(hipStreamSynchronize(j));
+            HIPCHK(hipStreamSynchronize(g));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, xb));
+            const float r = ms / 0.4f;
+            worst = rep == 0 ? r : std::min(worst, r);
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(gate);
+        (void)hipEventDestroy(xb);
+        return worst;
+    }
+
     void self_check(bool with_caller) {
         std::vector<hipStream_t> sts = {det_stream, emb_stream, emb_stream2};
-        if (with_caller && stream) sts.push_back(stream);
-        overlap_ratio = check_streams(sts);
+        std::vector<const char *> names = {"detector", "recogniser", "recogniser-2"};
+        if (with_caller) {
+            if (stream) {
+                sts.push_back(stream);
+                names.push_back("caller");
+            }
+            if (copy_stream) {
+                sts.push_back(copy_stream);
+                names.push_back("upload");
+            }
+        }
+        overlap_ratio = check_streams({det_stream, emb_stream, emb_stream2});
         warning.clear();
+        if (with_caller && stream) {  // the hazard proper: a pending join on the caller's stream must not hold up a pipeline stream
+            std::string held;
+            struct X {
+                hipStream_t st;
+                const char *name;
+                hipStream_t gate_on;
+            } xs[] = {{copy_stream, "upload", emb_stream2}, {det_stream, "detector", emb_stream2}, {emb_stream, "recogniser", emb_stream2},
+                      {emb_stream2, "recogniser-2", emb_stream}};
+            for (const X &x : xs) {
+                if (!x.st) continue;
+                const float r = blocked_by_wait(stream, x.st, x.gate_on);
+                if (r > 0.8f) held += std::string(held.empty() ? "" : ", ") + x.name;
+            }
+            if (!held.empty()) {
+                char buf[768];
+                snprintf(buf, sizeof(buf),
+                         "frt_pipeline: a wait pending on the caller's stream holds up the pipeline's %s stream(s) - they share a hardware queue, so "
+                         "every call's final join blocks the next call and consecutive batches serialise (measured: 4-frame step 0.78 -> 1.65 ms).  "
+                         "Hand the pipeline another stream (a newly created one lands on another queue) and check again; see INTEGRATION.md "
+                         "'Streams and hardware queues'.",
+                         held.c_str());
+                warning = buf;
+                overlap_ratio = std::max(overlap_ratio, 2.0f);
+                if (!getenv("FRT_QUIET")) fprintf(stderr, "[libfrt] warning: %s\n", buf);
+                return;
+            }
+        }
         if (overlap_ratio > 1.5f) {
-            char buf[512];
+            // which two?  pairwise probes (only on the failing path: 3 x 150 us per pair)
+            std::string pairs;
+            for (size_t i = 0; i < sts.size(); ++i)
+                for (size_t j = i + 1; j < sts.size(); ++j)
+                    if (check_streams({sts[i], sts[j]}) > 1.5f) pairs += std::string(pairs.empty() ? "" : ", ") + names[i] + " + " + names[j];
+            char buf[768];
             snprintf(buf, sizeof(buf),
-                     "frt_pipeline: the %zu stage streams do not run side by side (150 us probe kernels took %.2fx as long together as alone): "
-                     "they share a hardware queue, consecutive batches will not overlap.  Create the pipeline before other HIP streams "
-                     "(RCCL, copy streams), keep GPU_MAX_HW_QUEUES at its default 4, see INTEGRATION.md 'Streams and hardware queues'.",
-                     sts.size(), overlap_ratio);
+                     "frt_pipeline: %zu streams of the stage pipeline do not run side by side (150 us probe kernels took %.2fx as long together as "
+                     "alone; sharing a hardware queue: %s): consecutive batches will not overlap.  Create the pipeline - and hand it the "
+                     "caller's stream - before the process's other HIP streams (RCCL, codec, copy streams) are created or first used, keep "
+                     "GPU_MAX_HW_QUEUES at its default 4, see INTEGRATION.md 'Streams and hardware queues'.",
+                     sts.size(), overlap_ratio, pairs.empty() ? "?" : pairs.c_str());
             warning = buf;
             if (!getenv("FRT_QUIET")) fprintf(stderr, "[libfrt] warning: %s\n", buf);
         }
@@ -2264,6 +2345,7 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         // hipMemcpy on the legacy default stream) is then ordered against the stages still in flight without the caller
         // synchronising anything (tests/test_gpu_pipeline.py::test_gallery_reload_between_pipelined_calls); non-blocking
         // streams also measured 1 % slower
+        p->copy_prio = prio_hi;
         auto mk = [&](hipStream_t *st) { HIPCHK(hipStreamCreateWithPriority(st, hipStreamDefault, prio_hi)); };
         mk(&p->det_stream);
         mk(&p->emb_stream);
@@ -2384,6 +2466,11 @@ int frt_pipeline_check_overlap(frt_pipeline *p, float *ratio_out) {
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
         if (p->stream) HIPCHK(hipStreamSynchronize(p->stream));
+        {
+            std::lock_guard<std::mutex> la(p->async_mu);
+            p->ensure_stream();
+            p->ensure_async();  // the upload stream of frt_pipeline_submit / run takes part
+        }
         p->self_check(true);
         if (ratio_out) *ratio_out = p->overlap_ratio;
     });

@@ -1074,10 +1074,34 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
 // IR-SE: can the launch of `a` (conv2 of a unit described as EPI_BN_ADD_BN, se_* scratch set) run the whole SE tail in its epilogue
 // (mode EPI_BN_SE)?  Only the strip kernel's main variant with row-range strips of single images can; everything else writes the BN
 // output and leaves the tail to launch_se.
+// The fused tail makes the (at most SE_SPLIT x 4) workgroups of one face wait for each other inside a launch, so they must be able to be
+// resident together whatever else runs: checked once per device from the runtime's own occupancy figures for the two strip-kernel
+// instantiations that carry the tail (a device on which fewer than 16 of their workgroups fit - a much smaller part, a broken LDS opt-in -
+// gets the stand-alone tail instead of a hand-over that could starve).
+static bool se_fused_fits_device() {
+    static int ok[FRT_MAX_DEVICES] = {};  // 0 unknown, 1 yes, -1 no
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= FRT_MAX_DEVICES - 1;
+    if (!ok[d]) {
+        hipDeviceProp_t prop;
+        int per_cu7 = 0, per_cu4 = 0;
+        const size_t lds7 = (size_t)2 * 10 * 4096, lds4 = (size_t)2 * 10 * 4096;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<10, 1, 5, false, 0, false, 7, 1, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        const bool q = hipGetDeviceProperties(&prop, d) == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu7, conv_patch_kernel<10, 1, 5, false, 0, false, 7, 1, 3, true>, 256, lds7) == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3, true>, 256, lds4) == hipSuccess;
+        ok[d] = (q && (long)per_cu7 * prop.multiProcessorCount >= 16 && (long)per_cu4 * prop.multiProcessorCount >= 16) ? 1 : -1;
+    }
+    return ok[d] > 0;
+}
+
 bool conv_se_fused(const ConvMfmaArgs &a0) {
     ConvMfmaArgs a = a0;
     a.mode = EPI_BN_ADD_BN;  // same eligibility as the plain unit tail (shortcut with the output's geometry)
     if (!a.se_pool || !a.sc || !a.out1 || conv64_applies(a)) return false;
+    if (!se_fused_fits_device()) return false;
     if (conv_s2_applies(a)) return conv_s2_se_fused(a);
     int R = 0, n_img = 0;
     const int v = conv_variant(a, R, n_img);
