@@ -712,8 +712,9 @@ class JpegCodec:
         sizes = (ctypes.c_size_t * n)(*[k.size for k in keep])
         _check(lib.frt_jpeg_decode_batch_dev(self._h, ptrs, sizes, n, _vp(frames_ptr), int(out_h), int(out_w), _vp(hip_stream) if hip_stream else None))
 
-    def encode(self, images, quality=95, device_ptr=None, shape=None):
-        """u8 BGR [n, rows, cols, 3] (host array, or raw device address + ``shape``) -> list of JFIF byte strings."""
+    def encode(self, images, quality=95, device_ptr=None, shape=None, ready_event=None):
+        """u8 BGR [n, rows, cols, 3] (host array, or raw device address + ``shape``) -> list of JFIF byte strings.  ``ready_event``: raw
+        hipEvent_t recorded behind the producer of a device input (the codec's stream waits for it on the device)."""
         if device_ptr is None:
             a = np.ascontiguousarray(images, np.uint8)
             if a.ndim == 3:
@@ -726,7 +727,8 @@ class JpegCodec:
         stride = rows * cols * 3 + 4096
         out = np.zeros((n, stride), np.uint8)
         sizes = (ctypes.c_size_t * n)()
-        _check(lib.frt_jpeg_encode_batch(self._h, src, dev, n, rows, cols, int(quality), _ptr(out), stride, sizes))
+        _check(lib.frt_jpeg_encode_batch_after(self._h, src, dev, n, rows, cols, int(quality), _ptr(out), stride, sizes,
+                                               _vp(ready_event) if ready_event else None))
         return [out[i, :sizes[i]].tobytes() for i in range(n)]
 
     def close(self):

@@ -266,3 +266,22 @@ def test_screened_top1_pair_list_overflow_falls_back_to_the_exact_scan(frt, synt
     assert i3[0] == 9 and i3[3] == 49999 and np.array_equal(s3[[0, 3]], full3.max(1)[[0, 3]])
     assert i3[1] == -1                                              # every similarity of a NaN query is NaN: nothing is ever "greater"
     m.close()
+
+
+def test_calculate_top1_is_the_matrix_and_its_row_maxima_in_one_call(frt, synth):
+    """frt_matcher_calculate_top1 (what the drop-in ArcFaceIR50::featureMatching + getOutputs use): the materialised [F, N] matrix equals
+    calculate(), the (idx, sim) pairs equal top1() AND std::max_element over the rows, bit for bit; without the matrix the pairs are the same."""
+    for N, fp16 in ((5000, False), (60000, False), (60000, True)):
+        g = synth.make_gallery(N)
+        g[N - 7] = g[3]
+        q = np.concatenate([g[[3]], synth.make_queries(g, [N - 1, 1234, 77], noise=0.05)])
+        m = frt.MatMul(0)
+        m.setStorage(fp16)
+        m.init(g)
+        full, i, s = m.calculate_top1(q)
+        assert np.array_equal(full, m.calculate(q))
+        assert np.array_equal(i, full.argmax(1).astype(np.int32)) and np.array_equal(s, full.max(1)) and i[0] == 3
+        _, i2, s2 = m.calculate_top1(q, materialize=False)
+        i3, s3 = m.top1(q)
+        assert np.array_equal(i2, i) and np.array_equal(s2, s) and np.array_equal(i3, i) and np.array_equal(s3, s)
+        m.close()

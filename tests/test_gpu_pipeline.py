@@ -443,3 +443,29 @@ def test_run_dev_orders_behind_the_callers_producer(frt, synth, blobs):
     pipe.close()
     det.close()
     rec.close()
+
+
+def test_stream_overlap_self_check_reports_a_clean_pipeline(frt, synth, blobs):
+    """frt_pipeline_check_overlap (round 3): on a freshly created pipeline the three stage streams run their probe kernels side by side
+    (ratio ~ 1) and a wait pending on the caller's stream holds up none of them - no warning; the call leaves the pipeline usable."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 2, 4, 160, 224
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=B * K, maxFacesPerScene=K)
+    rec.setGallery(synth.make_gallery(2000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, B)
+    frames = synth.make_frames(B, H, W)
+    want, _ = pipe.run(frames)
+    st = torch.cuda.Stream()
+    pipe.set_stream(st.cuda_stream)
+    ratio, warning = pipe.check_overlap()
+    assert 0.5 < ratio < 1.5 and warning == "", (ratio, warning)
+    got, _ = pipe.run(frames)
+    assert np.array_equal(got, want)
+    pipe.set_stream(None)
+    pipe.close()
+    det.close()
+    rec.close()
