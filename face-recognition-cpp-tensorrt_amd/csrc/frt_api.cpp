@@ -819,7 +819,7 @@ void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, fl
             t.B = F; t.H = h; t.W = h; t.Cin = u.depth; t.Ho = ho; t.Wo = ho; t.Cout = u.depth; t.ks = 3; t.stride = 2; t.pad = 1;
             t.mode = EPI_BN_ADD_BN; t.splits = 1;
             t.scx = Y[cur]; t.wscf = u.wscf; t.psc0 = u.ssc; t.psc1 = u.bsc; t.Csc = u.cin;
-            sc_fused = conv_s2_applies(t);
+            sc_fused = conv_small_applies(t) || conv_s2_applies(t);
         }
         if (u.wsc && !sc_fused) {  // conv1x1 stride s + BN on the raw input
             ConvMfmaArgs a{};

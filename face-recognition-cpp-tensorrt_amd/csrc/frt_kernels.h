@@ -206,6 +206,8 @@ bool conv_s2_applies(const ConvMfmaArgs &a);                // kernels_arc_s2.hi
 bool launch_conv_s2(const ConvMfmaArgs &a, hipStream_t s);
 bool conv_s2_se_fused(const ConvMfmaArgs &a);  // IR-SE tail in the stride-2 strip kernel's epilogue (see conv_se_fused)
 const char *conv_s2_label(const ConvMfmaArgs &a);
+bool conv_small_applies(const ConvMfmaArgs &a);              // kernels_arc_small.hip: 3x3 convs of a small batch (few pixel tiles)
+bool launch_conv_small(const ConvMfmaArgs &a, hipStream_t s);
 bool conv64_applies(const ConvMfmaArgs &a);                 // kernels_arc_c64.hip: Cin = Cout = 64, 3x3, stride 1
 bool launch_conv64(const ConvMfmaArgs &a, hipStream_t s);
 const char *conv_kernel_label(const ConvMfmaArgs &a);  // kernel symbol (as rocprofv3 prints it) a launch resolves to

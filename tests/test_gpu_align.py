@@ -125,7 +125,8 @@ def test_forward_aligned_and_pipeline_align_mode(frt, orc, synth, blobs):
     res, emb = pipe.run(frames)
     pipe.sync()
     assert res["valid"].all() and np.array_equal(res["x1"], res_crop["x1"])
-    assert np.abs(emb - oemb).max() < 1e-5
+    # 8 faces in one pass vs 4 + 4: other kernels for some layers (kernels_arc_small.hip), fp16 roundings of activations flip
+    assert np.abs(emb - oemb).max() < 1e-3 and (emb * oemb).sum(1).min() > 1 - 1e-5
     assert np.array_equal(res["match_idx"], slots) and (res["match_sim"] > 0.999).all()
     assert not np.array_equal(res_crop["match_idx"], slots)
     oi, _ = match.top1(emb, gal)

@@ -39,8 +39,13 @@ def test_batch_chunking_and_batch1_agree(frt, synth, blobs):
     rec1 = frt.ArcFaceIR50(path, maxBatchSize=1)   # the reference default (config.json:18): one face per launch
     rec4 = frt.ArcFaceIR50(path, maxBatchSize=4)   # 5 faces -> chunks of 4 + 1
     e1, e4 = rec1.doInference(x), rec4.doInference(x)
-    assert (e1 * e4).sum(1).min() > 1 - 1e-6
-    assert np.abs(e1 - e4).max() < 1e-4
+    # 1 face and 4 faces take different kernels for the large layers (kernels_arc_small.hip's K split over four waves sums in another
+    # order than the strip kernels): fp16 roundings of activations flip here and there - the two agree as closely as either agrees
+    # with the fp32 oracle (1 - cos ~ 3e-6, tools/small_batch_parity.py), not bit for bit
+    assert (e1 * e4).sum(1).min() > 1 - 1e-5
+    assert np.abs(e1 - e4).max() < 1e-3
+    # the same batch twice: bit-identical (the K split is summed in a fixed order)
+    assert np.array_equal(rec4.doInference(x), e4) and np.array_equal(rec1.doInference(x), e1)
     rec1.close()
     rec4.close()
 
@@ -77,17 +82,26 @@ def test_forward_crops_and_embeds_like_the_oracle(frt, orc, synth, blobs):
 
 
 def test_batch_of_128_equals_small_batches(frt, synth, blobs):
-    """Benchmark batch (128 faces) vs the same faces in batches of 8: identical embeddings (strip walks of the persistent conv
-    kernels, grid-dependent tile variants and the split-K linear must be batch-size independent per face)."""
+    """Benchmark batch (128 faces) vs the same faces in batches of 32: identical embeddings (strip walks of the persistent conv
+    kernels, grid-dependent tile variants and the split-K linear must be batch-size independent per face).  Batches of 8 take the
+    small-batch kernel (kernels_arc_small.hip) for most layers - another fp32 summation order, so fp16 roundings of activations flip:
+    as close to the 128-face result as either is to the fp32 oracle."""
     path, _ = blobs("ir")
     big = frt.ArcFaceIR50(path, maxBatchSize=128)
+    mid = frt.ArcFaceIR50(path, maxBatchSize=32)
     small = frt.ArcFaceIR50(path, maxBatchSize=8)
     x = np.random.default_rng(11).standard_normal((128, 3, 112, 112)).astype(np.float32) * 0.5
     e = big.doInference(x)
+    for f0 in (0, 32, 96):
+        em = mid.doInference(x[f0:f0 + 32])
+        assert np.abs(e[f0:f0 + 32] - em).max() < 2e-6, (f0, np.abs(e[f0:f0 + 32] - em).max())
     for f0 in (0, 40, 120):
         es = small.doInference(x[f0:f0 + 8])
-        assert np.abs(e[f0:f0 + 8] - es).max() < 2e-6, (f0, np.abs(e[f0:f0 + 8] - es).max())
+        assert (e[f0:f0 + 8] * es).sum(1).min() > 1 - 1e-5 and np.abs(e[f0:f0 + 8] - es).max() < 1e-3, f0
+        # position in the batch does not matter: the same faces alone, bit for bit
+        assert np.array_equal(small.doInference(x[f0 + 2:f0 + 8])[:3], es[2:5])
     big.close()
+    mid.close()
     small.close()
 
 

@@ -47,7 +47,8 @@ def test_pipeline_end_to_end(frt, orc, synth, blobs):
     # device results == the un-fused API sequence findFace -> forward -> matchTop1
     b0 = det.findFace(frames[0])
     e0 = rec.forward(frames[0], b0)
-    assert np.array_equal(b0["x1"], res["x1"][:K]) and np.abs(e0 - emb[:K]).max() < 1e-5
+    # (4 faces alone take the small-batch kernels for most layers, the pipeline's whole batch the strip kernels: fp16 roundings flip)
+    assert np.array_equal(b0["x1"], res["x1"][:K]) and np.abs(e0 - emb[:K]).max() < 1e-3 and (e0 * emb[:K]).sum(1).min() > 1 - 1e-5
     oi, osim = match.top1(emb, gal)
     assert np.array_equal(oi, res["match_idx"]) and np.abs(osim - res["match_sim"]).max() < 1e-5
     # fewer frames than capacity, and an empty gallery
