@@ -106,6 +106,23 @@ def test_batch_of_128_equals_small_batches(frt, synth, blobs):
 
 
 @pytest.mark.parametrize("mode", ["ir", "ir_se"])
+def test_small_batches_match_the_oracle(frt, synth, blobs, mode):
+    """1, 2 and 7 faces per pass: the small-batch convolution kernel (kernels_arc_small.hip: ragged last pixel tiles at every
+    resolution - 196 x F is never a multiple of 32 for these F -, tiles that span two faces, the fused 1x1 shortcut convs of IR-50, the
+    stand-alone SE tail of IR-SE-50 behind it) against the fp32 oracle (model_irse.py:48-66, 139-156)."""
+    from oracle import nets
+    path, sd = blobs(mode)
+    x = np.random.default_rng(23).standard_normal((7, 3, 112, 112)).astype(np.float32) * 0.5
+    want = nets.arcface_forward(sd, x)
+    for F in (1, 2, 7):
+        rec = frt.ArcFaceIR50(path, maxBatchSize=F)
+        e = rec.doInference(x[:F])
+        rec.close()
+        assert (e * want[:F]).sum(1).min() > 1 - COS_TOL, (mode, F)
+        assert np.abs(e - want[:F]).max() < 2e-3, (mode, F)
+
+
+@pytest.mark.parametrize("mode", ["ir", "ir_se"])
 def test_every_batch_size_class_embeds_alike(frt, synth, blobs, mode):
     """The strip heights, images per strip and (IR-SE) which units run the SE tail inside conv2's epilogue all follow the batch size;
     odd batch sizes leave a last strip with a single image.  The same faces must embed alike (fp16 rounding flips only) whatever

@@ -15,7 +15,7 @@ path = frt.write_weights(os.path.join(tmp, "det.frtw"), s.retinaface_state(1), 1
 det = frt.RetinaFace(path, 640, 640, (3, 640, 640), B, 4)
 frames = s.make_frames(4)
 import numpy as np  # noqa: E402
-frames = np.concatenate([frames] * (B // 4))
+frames = np.concatenate([frames] * ((B + 3) // 4))[:B]
 for _ in range(reps):
     out = det.findFaceBatch(frames)
 print("ok", sum(len(o) for o in out))
