@@ -956,7 +956,7 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     single = a.Cin == 64;
     const int co_tiles = pair ? 1 : a.Cout / 128;
     static const bool small_ok = !(frt_tuning_env("FRT_CONV_SMALL_BATCH") && frt_tuning_env("FRT_CONV_SMALL_BATCH")[0] == '0');
-    constexpr int kWant = 224;  // workgroups that count as "fills the 256 CUs"
+    constexpr int kWant = 224;  // workgroups that count as "fills the 256 CUs" (128 / 64 measured at 16 / 32 / 64 faces: 0.89 / 1.20 / 1.68 ms per pass become 0.89 / 1.28 / 1.87 and 1.10 / 1.56 / 1.88, profiles/r03r_kwant.txt)
     auto tiles_for = [](int px) { return px <= 32 ? 1 : (px <= 64 ? 2 : (px <= 128 ? 4 : (px <= 224 ? 7 : 0))); };
     auto slots_of = [&](int r, int ni) { return (ni * (r + 2) * (a.W + 2) * 9 + 255) / 256; };
     auto fits = [&](int r, int ni, int t) {  // LDS budget of the instantiation that serves t tiles (see launch_conv_mfma)

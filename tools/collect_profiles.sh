@@ -68,6 +68,9 @@ FRT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | head -1 >
 FRT_BENCH_FORCE_DIST=1 python bench.py --sharded-gallery --batch 64 --gallery 1250000 --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_sharded_1rank.json"
 # 3b. the drop-in shells measured (src/app.cpp:304-310 through include/frt/*.h, 1 and 8 threads, N = 1M)
 python tools/dropin_bench.py --gallery 1000000 --threads 1 8 --iters 150 --out "$OUT/${TAG}_dropin_bench.json" > /dev/null 2>&1
+# 3c. small batches: the small-batch recogniser path against the strip kernels and the oracle; per-launch table of a 1- and a 4-face pass
+python tools/small_batch_parity.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/${TAG}_small_batch_parity.txt"
+for nf in 1 4; do NF=$nf bash tools/layer_table.sh "A=1"; done > "$OUT/${TAG}_small_batch_layers.txt" 2>&1
 # 4. the microbenchmarks DESIGN.md quotes (sources in tools/ubench/*.hip)
 for P in clock_probe occ_probe mfma_f32_order; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -w -o /tmp/$P "$ROOT/tools/ubench/$P.hip" 2>/dev/null && timeout 120 /tmp/$P > "$OUT/${TAG}_$P.txt" 2>&1
