@@ -1185,6 +1185,7 @@ struct frt_pipeline {
     bool align = false;  // optional: 5-point similarity warp instead of the reference's bbox crop + bicubic resize
     unsigned seq = 0;
     bool overlap = true;
+    bool serial_call = false;  // this call only: every stage on the caller's stream (a synchronous call with nothing else in flight, see frt_pipeline_run)
     Arena arena;
     float *d_chw, *d_sim;
     int32_t *d_idx;
@@ -1258,7 +1259,7 @@ struct frt_pipeline {
     }
     template <typename Body>
     void run_part(const GraphKey &key, hipStream_t st, Body body) {
-        if (!use_graphs || g_prof_kind != 0) return body(st);
+        if (!use_graphs || g_prof_kind != 0 || serial_call) return body(st);
         GraphEntry *e = nullptr;
         for (GraphEntry &g : graphs)
             if (g.key == key) e = &g;
@@ -1444,7 +1445,7 @@ struct frt_pipeline {
         // results, exactly as if the call had run on that stream.  Boxes, embeddings and validity flags live in two slots.
         // Profiled calls (frt_profile_enable 1 or 2) run serially on `s`: HIP events around a launch only measure the kernel when
         // no other stream competes for the dispatch (with four streams in flight the bracketed time was 2.7x the kernel time).
-        const bool pipe3 = overlap && g_prof_kind == 0;
+        const bool pipe3 = overlap && g_prof_kind == 0 && !serial_call;
         if (pipe3 && serial_pending) {  // a serial call used the shared detector / recogniser buffers on `s`: order the stages behind it
             HIPCHK(hipStreamWaitEvent(det_stream, ev_serial, 0));
             HIPCHK(hipStreamWaitEvent(emb_stream, ev_serial, 0));
@@ -2555,7 +2556,7 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable) {
 }
 
 // queue one batch through a staging set; caller holds neither mutex
-static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out) {
+static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, bool synchronous = false) {
     if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
     use_device(p->det->device);
     std::lock_guard<std::mutex> lk(p->async_mu);   // staging sets + ticket order
@@ -2567,15 +2568,29 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     if (b.ticket >= 0) HIPCHK(hipEventSynchronize(b.ev_out));  // the staging set is free once its previous batch has left
     hipStream_t s = p->stream;
     const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
-    HIPCHK(hipMemcpyAsync(b.d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, p->copy_stream));
-    HIPCHK(hipEventRecord(b.ev_h2d, p->copy_stream));
-    p->ev_frames = b.ev_h2d;  // the stages that read the frames (detector, crop) wait for the copy; the caller's stream does not
+    // A synchronous call that finds nothing else in flight (the reference's request / reply shape: one frame, one caller) has nothing to
+    // overlap with: upload, detector, recogniser, match and download go down ONE stream - no stream-to-stream event hand-overs on its
+    // critical path (5 of them otherwise; one 4-face call 1.02 -> 0.94 ms, profiles/r03u_sync_overlap.txt).  Calls that arrive while
+    // another is in flight take the stage streams as before (and are ordered behind this one through ev_serial).
+    bool lone = synchronous && p->overlap;
+    for (int i = 0; lone && i < frt_pipeline::NBUF; ++i)
+        if (p->abuf[i].ticket >= 0 && i != (int)(ticket % frt_pipeline::NBUF) && hipEventQuery(p->abuf[i].ev_out) != hipSuccess) lone = false;
+    if (lone) {
+        HIPCHK(hipMemcpyAsync(b.d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, s));
+    } else {
+        HIPCHK(hipMemcpyAsync(b.d_frames, frames, fbytes * n_frames, hipMemcpyHostToDevice, p->copy_stream));
+        HIPCHK(hipEventRecord(b.ev_h2d, p->copy_stream));
+        p->ev_frames = b.ev_h2d;  // the stages that read the frames (detector, crop) wait for the copy; the caller's stream does not
+    }
+    p->serial_call = lone;
     try {
         pipeline_lock_run(p, b.d_frames, n_frames, b.d_results, embeds_out ? b.d_embeds : nullptr);
     } catch (...) {
         p->ev_frames = nullptr;
+        p->serial_call = false;
         throw;
     }
+    p->serial_call = false;
     const int F = n_frames * p->max_faces;
     HIPCHK(hipMemcpyAsync(results, b.d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
     if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, b.d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
@@ -2605,7 +2620,7 @@ static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
 int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out) {
     return guarded([&] {
         if (!p || !frames || !results) raise(FRT_ERR_INVALID, "null argument");
-        const long t = pipeline_submit_impl(p, frames, n_frames, results, embeds_out);
+        const long t = pipeline_submit_impl(p, frames, n_frames, results, embeds_out, true);
         pipeline_wait_impl(p, t);
     });
 }
