@@ -337,19 +337,27 @@ def main():
         final = [None]
 
     # ---------------------------------------------------------------------------------------------------- step bodies
+    step_times = [] if os.environ.get("FRT_BENCH_STEP_TIMES") else None  # diagnostic: host timestamps of every submit / wait (printed to stderr)
+
     def run_host(n_steps, profile_step=None):
         """pinned host frames -> host records, DEPTH batches in flight (frt_pipeline_submit / frt_pipeline_wait)."""
         tickets = []
         for i in range(n_steps):
             if len(tickets) >= depth:
                 pipe.wait(tickets.pop(0))
+                if step_times is not None:
+                    step_times.append(("wait", i, time.perf_counter()))
             if i == profile_step:
                 frt.profile_enable(1)
             tickets.append(pipe.submit(h_np[i & 1], h_views[i % 4]))
+            if step_times is not None:
+                step_times.append(("submit", i, time.perf_counter()))
             if i == profile_step:
                 frt.profile_enable(-1)  # pause: keep the records, stop recording (host-side flag, no sync)
         for t in tickets:
             pipe.wait(t)
+            if step_times is not None:
+                step_times.append(("drain", t, time.perf_counter()))
 
     def run_host_dist(n_steps, profile_step=None):
         """Same boundary with N > 1: the step itself is run_host's (frt_pipeline_submit / frt_pipeline_wait, DEPTH batches in flight); the
@@ -451,10 +459,19 @@ def main():
     torch.cuda.synchronize()
     if smi:
         smi.__enter__()
+    if step_times is not None:
+        del step_times[:]
     t0 = time.perf_counter()
     run(args.steps, sampled_step)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if step_times:
+        prev = t0
+        for what, i, t in step_times:
+            print("[step-times] %-6s %3d  +%.3f ms" % (what, i, 1e3 * (t - prev)), file=sys.stderr)
+            prev = t
+        print("[step-times] region %.3f ms" % (1e3 * dt), file=sys.stderr)
+        step_times = None
     if smi:
         smi.__exit__()
     if gather and run is run_host_dist and args.steps >= 1:

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -54,6 +55,44 @@ struct Arena {
     }
 };
 
+// Host waits poll first.  hipEventSynchronize / hipStreamSynchronize park the thread on an interrupt; in the 20-step benchmark region (one wait
+// every 3 ms) that wake-up was observed 20 - 30 ms late about once in four processes - the GPU finished all three batches in flight while the
+// host slept (profiles/r03v_step_times.txt; with polling 12 of 12 processes within 1 %, r03w_step_times.txt) - and an ordinary wake-up costs
+// tens of microseconds on every synchronous call.  Polling costs a core while waiting; FRT_WAIT_SPIN_US bounds it (default 50 000 us, then
+// the blocking wait takes over; 0: block at once).
+static long wait_spin_us() {
+    static const long v = [] {
+        const char *e = getenv("FRT_WAIT_SPIN_US");
+        return e ? atol(e) : 50000L;
+    }();
+    return v;
+}
+template <class Query>
+static bool spin_until_done(Query &&query) {
+    const long spin_us = wait_spin_us();
+    if (spin_us <= 0) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0;; ++it) {
+        const hipError_t q = query();
+        if (q == hipSuccess) {
+            if (it) (void)hipGetLastError();  // "not ready" is an answer, not an error: do not leave it behind as the thread's last error
+            return true;
+        }
+        if (q != hipErrorNotReady) HIPCHK(q);
+        if ((it & 63) == 63 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) {
+            (void)hipGetLastError();
+            return false;
+        }
+        __builtin_ia32_pause();
+    }
+}
+static void wait_event_spinning(hipEvent_t ev) {
+    if (!spin_until_done([&] { return hipEventQuery(ev); })) HIPCHK(hipEventSynchronize(ev));
+}
+static void sync_stream_spinning(hipStream_t st) {
+    if (!spin_until_done([&] { return hipStreamQuery(st); })) HIPCHK(hipStreamSynchronize(st));
+}
+
 // ------------------------------------------------------------------------------------------------ profiling (HIP events)
 struct ProfRec {
     std::string name;
@@ -63,6 +102,21 @@ struct ProfRec {
 std::mutex g_prof_mu;
 int g_prof_kind = 0;
 std::vector<ProfRec> g_prof;
+// Events are created when profiling is switched on, not between the two records of a bracket: the first hipEventCreate calls of a process
+// take ~ 100 us each (pool set-up), and a host stall between "record a" and the launch it brackets is GPU idle time INSIDE the bracket
+// (it showed up as conv_s2c64_kernel - the second bracket of a pass - at 224 us "live" against 97 us in rocprofv3's trace).
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
 
 struct ProfScope {
     bool on = false;
@@ -73,8 +127,8 @@ struct ProfScope {
         on = true;
         rec.name = name;
         rec.work = work;
-        (void)hipEventCreate(&rec.a);
-        (void)hipEventCreate(&rec.b);
+        rec.a = prof_event();
+        rec.b = prof_event();
         (void)hipEventRecord(rec.a, s);
     }
     ~ProfScope() {
@@ -1643,7 +1697,7 @@ int frt_detector_find_faces_batch(frt_detector *d, const uint8_t *bgr, int n_fra
         d->postprocess(n_frames, s);
         HIPCHK(hipMemcpyAsync(out, d->d_boxes, sizeof(frt_bbox) * n_frames * d->g.max_faces, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(n_out, d->d_nout, sizeof(int) * n_frames, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -1670,7 +1724,7 @@ int frt_detector_find_faces_landmarks(frt_detector *d, const uint8_t *bgr, int r
         HIPCHK(hipMemcpyAsync(out, d->d_boxes, sizeof(frt_bbox) * d->g.max_faces, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(landmarks_out, d->d_landmarks, sizeof(float) * 10 * d->g.max_faces, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(n_out, d->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -1686,7 +1740,7 @@ int frt_detector_preprocess(frt_detector *d, const uint8_t *bgr, int rows, int c
         HIPCHK(hipMemcpy2DAsync(d->d_frames, tight, bgr, row_stride, tight, rows, hipMemcpyHostToDevice, s));
         d->preprocess(d->d_frames, 1, tight, (size_t)rows * tight, s);
         HIPCHK(hipMemcpyAsync(chw_out, d->d_input, sizeof(float) * 3 * d->g.in_h * d->g.in_w, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -1703,7 +1757,7 @@ int frt_detector_infer(frt_detector *d, const float *chw, int batch, float *loc_
         d->forward(batch, s);
         HIPCHK(hipMemcpyAsync(loc_out, d->d_loc, sizeof(float) * (size_t)batch * d->g.A * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(conf_out, d->d_conf, sizeof(float) * (size_t)batch * d->g.A * 2, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -1722,7 +1776,7 @@ int frt_detector_infer_landmarks(frt_detector *d, const float *chw, int batch, f
         HIPCHK(hipMemcpyAsync(loc_out, d->d_loc, sizeof(float) * (size_t)batch * d->g.A * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(conf_out, d->d_conf, sizeof(float) * (size_t)batch * d->g.A * 2, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(ldm_out, d->d_ldm, sizeof(float) * (size_t)batch * d->g.A * 10, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -1738,7 +1792,7 @@ int frt_detector_postprocess(frt_detector *d, const float *loc, const float *con
         d->postprocess(1, s);
         HIPCHK(hipMemcpyAsync(out, d->d_boxes, sizeof(frt_bbox) * d->g.max_faces, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(n_out, d->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -1866,7 +1920,7 @@ int frt_embedder_preprocess_face(frt_embedder *e, const uint8_t *bgr_crop, float
         HIPCHK(hipMemcpyAsync(e->d_crops, bgr_crop, 112 * 112 * 3, hipMemcpyHostToDevice, s));
         launch_face_normalize(e->d_crops, 1, 112, 112, e->d_in, s);
         HIPCHK(hipMemcpyAsync(chw_out, e->d_in, sizeof(float) * 3 * 112 * 112, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -1883,7 +1937,7 @@ int frt_embedder_infer(frt_embedder *e, const float *chw, int batch, float *embe
             HIPCHK(hipMemcpyAsync(e->d_in, chw + (size_t)f0 * in_elems, sizeof(float) * in_elems * nf, hipMemcpyHostToDevice, s));
             e->forward(e->d_in, nf, nullptr, e->d_out, s);
             HIPCHK(hipMemcpyAsync(embeds_out + (size_t)f0 * 512, e->d_out, sizeof(float) * 512 * nf, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            sync_stream_spinning(s);
             e->check_se_error();
         }
     });
@@ -1916,7 +1970,7 @@ int frt_embedder_forward(frt_embedder *e, const uint8_t *bgr, int rows, int cols
             if (crops_out) HIPCHK(hipMemcpyAsync(crops_out + (size_t)f0 * 112 * 112 * 3, e->d_crops, (size_t)nf * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
             std::vector<int> valid(nf);
             HIPCHK(hipMemcpyAsync(valid.data(), e->d_valid, sizeof(int) * nf, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            sync_stream_spinning(s);
             e->check_se_error();
             for (int v : valid) bad = bad || !v;
         }
@@ -1978,7 +2032,7 @@ int frt_embedder_forward_aligned(frt_embedder *e, const uint8_t *bgr, int rows, 
             if (crops_out) HIPCHK(hipMemcpyAsync(crops_out + (size_t)f0 * 112 * 112 * 3, e->d_crops, (size_t)nf * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
             std::vector<int> valid(nf);
             HIPCHK(hipMemcpyAsync(valid.data(), e->d_valid, sizeof(int) * nf, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            sync_stream_spinning(s);
             e->check_se_error();
             for (int v : valid) bad = bad || !v;
         }
@@ -2120,7 +2174,7 @@ int frt_matcher_calculate(frt_matcher *m, const float *embeds, int embed_count, 
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(outputs, m->d_full, need * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -2155,7 +2209,7 @@ int frt_matcher_calculate_top1(frt_matcher *m, const float *embeds, int embed_co
         m->top1_dev(m->d_q, embed_count, m->d_idx, m->d_sim, s);
         HIPCHK(hipMemcpyAsync(idx_out, m->d_idx, sizeof(int32_t) * embed_count, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(sim_out, m->d_sim, sizeof(float) * embed_count, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -2185,7 +2239,7 @@ int frt_matcher_top1(frt_matcher *m, const float *embeds, int embed_count, int32
         m->top1_dev(m->d_q, embed_count, m->d_idx, m->d_sim, s);
         HIPCHK(hipMemcpyAsync(idx_out, m->d_idx, sizeof(int32_t) * embed_count, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(sim_out, m->d_sim, sizeof(float) * embed_count, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -2239,7 +2293,7 @@ int frt_matcher_topk(frt_matcher *m, const float *embeds, int embed_count, int k
         m->topk_dev(m->d_q, embed_count, k, m->d_idx, m->d_sim, s);
         HIPCHK(hipMemcpyAsync(idx_out, m->d_idx, sizeof(int32_t) * (size_t)embed_count * k, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(sim_out, m->d_sim, sizeof(float) * (size_t)embed_count * k, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        sync_stream_spinning(s);
     });
 }
 
@@ -2565,7 +2619,7 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     p->ensure_async();
     const long ticket = p->next_ticket;
     frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
-    if (b.ticket >= 0) HIPCHK(hipEventSynchronize(b.ev_out));  // the staging set is free once its previous batch has left
+    if (b.ticket >= 0) wait_event_spinning(b.ev_out);  // the staging set is free once its previous batch has left
     hipStream_t s = p->stream;
     const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
     // A synchronous call that finds nothing else in flight (the reference's request / reply shape: one frame, one caller) has nothing to
@@ -2610,7 +2664,7 @@ static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
         if (b.ticket > ticket) return;  // its staging set was reused, which submit only does after that batch completed
         ev = b.ev_out;
     }
-    HIPCHK(hipEventSynchronize(ev));
+    wait_event_spinning(ev);
     p->emb->check_se_error();
 }
 
@@ -2648,10 +2702,16 @@ int frt_profile_enable(int kind) {
     }
     g_prof_kind = kind;
     for (ProfRec &r : g_prof) {
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
     }
     g_prof.clear();
+    if (kind >= 0)  // (also on "off": a caller that is about to time a region switches profiling off first - the pool is filled outside it)
+        while (g_prof_pool.size() < 512) {  // a profiled pipeline call brackets ~ 120 launches
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            g_prof_pool.push_back(e);
+        }
     return FRT_OK;
 }
 
@@ -2670,8 +2730,8 @@ int frt_profile_collect(char *names_out, size_t names_cap, double *ms_out, doubl
             names += '\n';
             ++n;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
     }
     g_prof.clear();
     if (names_out && names_cap) {

@@ -363,7 +363,8 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable);
  * ------------------------------------------------------------------------------------------------------------------ */
 /* kinds: 0 = off (drops the records), 1 = time every launch of the dominant kernel family (conv3x3 MFMA), 2 = time every stage,
  * -1 = pause: stop recording but keep the records (bench.py samples ONE step of its timed region: the events around every conv
- * launch cost 11 % of a step when left on for all of them). */
+ * launch cost 11 % of a step when left on for all of them).  Every call with kind >= 0 also makes sure a pool of events exists, so that
+ * no event is created between the two records of a bracket (call it with 0 once before a timed region). */
 int frt_profile_enable(int kind);
 /* Drains recorded events.  names_out: '\n'-separated labels; returns the number of records written (<= cap). */
 int frt_profile_collect(char *names_out, size_t names_cap, double *ms_out, double *work_out, int cap);
