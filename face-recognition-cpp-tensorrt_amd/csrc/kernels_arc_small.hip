@@ -6,7 +6,8 @@
 // workgroups, each pulling 590 KB through ONE CU's vector memory path (~ 90 GB/s) for 1 us of MFMAs: 8.6 - 12.4 us per launch, ~ 150 such
 // launches in a call.  Here the unit of work is the smallest the matrix core allows - ONE 32-cout block x ONE 32-pixel tile per workgroup
 // (pixels flattened over faces and rows, so 4 faces of 14x14 are 24.5 tiles, not 28) - and the K loop (Cin x 9 taps) is split over the
-// four waves of the workgroup: a 256 -> 256 layer for 4 faces is 200 workgroups of 147 KB of weights each, every wave runs 36 MFMAs on
+// four waves of the workgroup (two cout blocks per workgroup once a layer has more units than the chip has CUs): a 256 -> 256 layer for 4
+// faces is 200 workgroups of 147 KB of weights each, every wave runs 36 MFMAs on
 // operands it loads straight from global memory / L2 into registers (no LDS staging: a tile's patch is read once, by one workgroup), and
 // the four partial accumulators meet in LDS in a fixed order (deterministic).  The 1x1 stride-2 shortcut convolution of a unit's first
 // block rides along as extra K steps into a second accumulator (its own BatchNorm), exactly as in the stride-2 strip kernel.
@@ -29,38 +30,32 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// NW waves split the K loop; NT pixel tiles per workgroup share every weight fragment; D = depth of the operand register ring in
-// (chunk, tap) pairs (one pair = the operands of 4 MFMAs per tile): D >= a wave's pair count puts every load of the launch in flight at once.
-template <bool SCF, int NW, int NT, int D>
+// NW waves split the K loop; the workgroup owns NC 32-cout blocks of one 32-pixel tile (a pixel fragment then feeds NC MFMAs); D = depth of
+// the operand register ring in (chunk, tap) pairs (one pair = the operands of 4 MFMAs per cout block).
+template <bool SCF, int NW, int NC, int D>
 __global__ __launch_bounds__(NW * 64) void conv_small_kernel(ConvMfmaArgs p, const half_t *wfrag, unsigned long long tap_pack, int M) {
     __shared__ __attribute__((aligned(16))) float red[SCF ? 2 : 1][NW][32][EROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
-    const int tile0 = blockIdx.x * NT, cb = blockIdx.y;
+    const int tile = blockIdx.x, cb0 = blockIdx.y * NC;
     const int H = p.H, W = p.W, Cin = p.Cin, HoWo = p.Ho * p.Wo;
     const int nch = Cin >> 6, np = nch * 9, nsc = SCF ? p.Csc >> 6 : 0;
     const int total = np + nsc;
     const int cnt = total > wave ? (total - wave + NW - 1) / NW : 0;  // this wave's pairs: wave, wave + NW, ...
 
-    // the pixels this lane feeds into the B fragments (one per tile)
-    bool valid[NT];
-    int iy0[NT], ix0[NT];
-    const half_t *xf[NT], *scxf[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int m = (tile0 + t) * 32 + r;
-        valid[t] = m < M;
-        const int f = valid[t] ? m / HoWo : 0, rem = valid[t] ? m - f * HoWo : 0;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        iy0[t] = oy * p.stride - 1;
-        ix0[t] = ox * p.stride - 1;
-        xf[t] = p.x + (long)f * H * W * Cin + hi * 8;
-        scxf[t] = SCF ? p.scx + ((long)(f * H + oy * 2) * W + ox * 2) * p.Csc + hi * 8 : nullptr;
-    }
-    const half_t *wb = wfrag + (long)cb * nch * 9 * 2048 + lane * 8;
-    const half_t *wscb = SCF ? p.wscf + (long)cb * nsc * 2048 + lane * 8 : nullptr;
+    // the pixel this lane feeds into the B fragments
+    const int m = tile * 32 + r;
+    const bool valid = m < M;
+    const int f = valid ? m / HoWo : 0, rem = valid ? m - f * HoWo : 0;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
+    const half_t *xf = p.x + (long)f * H * W * Cin + hi * 8;
+    const half_t *scxf = SCF ? p.scx + ((long)(f * H + oy * 2) * W + ox * 2) * p.Csc + hi * 8 : nullptr;
+    const long wstride = (long)nch * 9 * 2048, wsc_stride = (long)nsc * 2048;  // halfs per cout block
+    const half_t *wb = wfrag + (long)cb0 * wstride + lane * 8;
+    const half_t *wscb = SCF ? p.wscf + (long)cb0 * wsc_stride + lane * 8 : nullptr;
 
-    half8 A[D][4], B[D][NT][4];
+    half8 A[D][NC][4], B[D][4];
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef FRT_ABLATE
     const int abl = (int)(tap_pack >> 40) & 3;  // timing experiments (wrong results): 1 no B loads, 2 no A loads
@@ -71,76 +66,73 @@ __global__ __launch_bounds__(NW * 64) void conv_small_kernel(ConvMfmaArgs p, con
 #ifdef FRT_ABLATE
         if (abl) {
             const half_t *ap = wb + (long)((j / 9) * 9 + j % 9) * 2048;
-            const half_t *bp = xf[0] + (long)(j % 9) * Cin + (j / 9) * 64;
+            const half_t *bp = xf + (long)(j % 9) * Cin + (j / 9) * 64;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) A[d][kk] = abl == 2 ? zero8 + (half_t)lane : *reinterpret_cast<const half8 *>(ap + kk * 512);
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int kk = 0; kk < 4; ++kk) A[d][c][kk] = abl == 2 ? zero8 + (half_t)lane : *reinterpret_cast<const half8 *>(ap + c * wstride + kk * 512);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) B[d][t][kk] = abl == 1 ? zero8 + (half_t)lane : *reinterpret_cast<const half8 *>(bp + kk * 16);
+            for (int kk = 0; kk < 4; ++kk) B[d][kk] = abl == 1 ? zero8 + (half_t)lane : *reinterpret_cast<const half8 *>(bp + kk * 16);
             return;
         }
 #endif
         if (SCF && j >= np) {
-            const int c = j - np;
-            const half_t *ap = wscb + (long)c * 2048;
+            const int c64 = j - np;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) A[d][kk] = *reinterpret_cast<const half8 *>(ap + kk * 512);
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int kk = 0; kk < 4; ++kk) A[d][c][kk] = *reinterpret_cast<const half8 *>(wscb + c * wsc_stride + (long)c64 * 2048 + kk * 512);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) B[d][t][kk] = valid[t] ? *reinterpret_cast<const half8 *>(scxf[t] + c * 64 + kk * 16) : zero8;
+            for (int kk = 0; kk < 4; ++kk) B[d][kk] = valid ? *reinterpret_cast<const half8 *>(scxf + c64 * 64 + kk * 16) : zero8;
         } else {
-            const int c = j / 9, st = j - c * 9;
+            const int c64 = j / 9, st = j - c64 * 9;
             const int tap = (int)(tap_pack >> (4 * st)) & 15;
             const int dy = tap / 3, dx = tap - dy * 3;
-            const half_t *ap = wb + (long)(c * 9 + st) * 2048;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) A[d][kk] = *reinterpret_cast<const half8 *>(ap + kk * 512);
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int iy = iy0[t] + dy, ix = ix0[t] + dx;
-                const bool inb = valid[t] && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const half_t *bp = xf[t] + ((long)iy * W + ix) * Cin + c * 64;
+                for (int kk = 0; kk < 4; ++kk) A[d][c][kk] = *reinterpret_cast<const half8 *>(wb + c * wstride + (long)(c64 * 9 + st) * 2048 + kk * 512);
+            const int iy = iy0 + dy, ix = ix0 + dx;
+            const bool inb = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const half_t *bp = xf + ((long)iy * W + ix) * Cin + c64 * 64;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) B[d][t][kk] = inb ? *reinterpret_cast<const half8 *>(bp + kk * 16) : zero8;
-            }
+            for (int kk = 0; kk < 4; ++kk) B[d][kk] = inb ? *reinterpret_cast<const half8 *>(bp + kk * 16) : zero8;
         }
     };
 
-    // the epilogue's operands (thread = output pixel px, couts 4q..4q+3) are requested now: they land under the K loop
+    // the epilogue's operands (thread = output pixel px, couts 4q..4q+3 of every cout block) are requested now: they land under the K loop
     const int px = (tid & 255) >> 3, q = tid & 7;
-    const int cch = cb * 32 + 4 * q;
-    floatx4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
-    half4 sc4[NT];
+    const int mo = tile * 32 + px;
+    floatx4 q0[NC], q1[NC], q2[NC], q3[NC], q4[NC], q5[NC];
+    half4 sc4[NC];
     if (tid < 256) {
-        q0 = *reinterpret_cast<const floatx4 *>(p.p0 + cch);
-        if (p.mode != EPI_PRELU) q1 = *reinterpret_cast<const floatx4 *>(p.p1 + cch);
-        if (p.mode == EPI_BN_ADD_BN) {
-            if (p.out1) {
-                q2 = *reinterpret_cast<const floatx4 *>(p.p2 + cch);
-                q3 = *reinterpret_cast<const floatx4 *>(p.p3 + cch);
-            }
-            if constexpr (SCF) {
-                q4 = *reinterpret_cast<const floatx4 *>(p.psc0 + cch);
-                q5 = *reinterpret_cast<const floatx4 *>(p.psc1 + cch);
-            } else {
+        const int mc = mo < M ? mo : 0;
+        const int fo = mc / HoWo, ro = mc - fo * HoWo, yo = ro / p.Wo, xo = ro - yo * p.Wo;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int mo = (tile0 + t) * 32 + px;
-                    const int mc = mo < M ? mo : 0;
-                    const int fo = mc / HoWo, ro = mc - fo * HoWo, yo = ro / p.Wo, xo = ro - yo * p.Wo;
-                    sc4[t] = *reinterpret_cast<const half4 *>(p.sc + ((long)(fo * p.sc_h + yo * p.sc_stride) * p.sc_w + xo * p.sc_stride) * p.Cout + cch);
+        for (int c = 0; c < NC; ++c) {
+            const int cch = (cb0 + c) * 32 + 4 * q;
+            q0[c] = *reinterpret_cast<const floatx4 *>(p.p0 + cch);
+            if (p.mode != EPI_PRELU) q1[c] = *reinterpret_cast<const floatx4 *>(p.p1 + cch);
+            if (p.mode == EPI_BN_ADD_BN) {
+                if (p.out1) {
+                    q2[c] = *reinterpret_cast<const floatx4 *>(p.p2 + cch);
+                    q3[c] = *reinterpret_cast<const floatx4 *>(p.p3 + cch);
+                }
+                if constexpr (SCF) {
+                    q4[c] = *reinterpret_cast<const floatx4 *>(p.psc0 + cch);
+                    q5[c] = *reinterpret_cast<const floatx4 *>(p.psc1 + cch);
+                } else {
+                    sc4[c] = *reinterpret_cast<const half4 *>(p.sc + ((long)(fo * p.sc_h + yo * p.sc_stride) * p.sc_w + xo * p.sc_stride) * p.Cout + cch);
                 }
             }
         }
     }
 
-    floatx16 acc[NT], acc_sc[NT];
+    floatx16 acc[NC], acc_sc[NC];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f, acc_sc[t][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.f, acc_sc[c][e] = 0.f;
 
     static_for<D>([&](auto dc) {
         if (decltype(dc)::value < cnt) load(decltype(dc)::value, dc);
@@ -152,53 +144,53 @@ __global__ __launch_bounds__(NW * 64) void conv_small_kernel(ConvMfmaArgs p, con
             if (i >= cnt) return;
             if (SCF && wave + NW * i >= np) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc_sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[d][kk], B[d][t][kk], acc_sc[t], 0, 0, 0);
+                    for (int kk = 0; kk < 4; ++kk) acc_sc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[d][c][kk], B[d][kk], acc_sc[c], 0, 0, 0);
             } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[d][kk], B[d][t][kk], acc[t], 0, 0, 0);
+                    for (int kk = 0; kk < 4; ++kk) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[d][c][kk], B[d][kk], acc[c], 0, 0, 0);
             }
             if (i + D < cnt) load(i + D, dc);
         });
     }
 
-    // ---- the waves' partial sums meet in LDS (lane owns pixel r, couts 8g + 4hi + j), summed in wave order; tile by tile
+    // ---- the waves' partial sums meet in LDS (lane owns pixel r, couts 8g + 4hi + j), summed in wave order; cout block by cout block
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (t) __syncthreads();
+    for (int c = 0; c < NC; ++c) {
+        if (c) __syncthreads();
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<floatx4 *>(&red[0][wave][r][8 * g + 4 * hi]) = floatx4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            *reinterpret_cast<floatx4 *>(&red[0][wave][r][8 * g + 4 * hi]) = floatx4{acc[c][4 * g], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]};
             if constexpr (SCF)
                 *reinterpret_cast<floatx4 *>(&red[1][wave][r][8 * g + 4 * hi]) =
-                    floatx4{acc_sc[t][4 * g], acc_sc[t][4 * g + 1], acc_sc[t][4 * g + 2], acc_sc[t][4 * g + 3]};
+                    floatx4{acc_sc[c][4 * g], acc_sc[c][4 * g + 1], acc_sc[c][4 * g + 2], acc_sc[c][4 * g + 3]};
         }
         __syncthreads();
-        const int mo = (tile0 + t) * 32 + px;
         if (tid >= 256 || mo >= M) continue;
+        const int cch = (cb0 + c) * 32 + 4 * q;
         floatx4 v = *reinterpret_cast<const floatx4 *>(&red[0][0][px][4 * q]);
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const floatx4 *>(&red[0][w][px][4 * q]);
         if (p.mode == EPI_PRELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * q0[e];
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * q0[c][e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * q0[e] + q1[e];
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * q0[c][e] + q1[c][e];
         }
         if (p.mode == EPI_BN_ADD_BN) {
             if constexpr (SCF) {
-                floatx4 s = *reinterpret_cast<const floatx4 *>(&red[1][0][px][4 * q]);
+                floatx4 sacc = *reinterpret_cast<const floatx4 *>(&red[1][0][px][4 * q]);
 #pragma unroll
-                for (int w = 1; w < NW; ++w) s += *reinterpret_cast<const floatx4 *>(&red[1][w][px][4 * q]);
+                for (int w = 1; w < NW; ++w) sacc += *reinterpret_cast<const floatx4 *>(&red[1][w][px][4 * q]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += s[e] * q4[e] + q5[e];
+                for (int e = 0; e < 4; ++e) v[e] += sacc[e] * q4[c][e] + q5[c][e];
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)sc4[t][e];
+                for (int e = 0; e < 4; ++e) v[e] += (float)sc4[c][e];
             }
         }
         half4 o;
@@ -208,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void conv_small_kernel(ConvMfmaArgs p, con
         if (p.mode == EPI_BN_ADD_BN && p.out1) {
             half4 z;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] = (half_t)(v[e] * q2[e] + q3[e]);
+            for (int e = 0; e < 4; ++e) z[e] = (half_t)(v[e] * q2[c][e] + q3[c][e]);
             *reinterpret_cast<half4 *>(p.out1 + (long)mo * p.Cout + cch) = z;
         }
     }
@@ -248,10 +240,10 @@ bool conv_small_applies(const ConvMfmaArgs &a) {
     return (M + 31) / 32 * (a.Cout / 32) * pairs <= small_work_limit(a.stride);
 }
 
-template <bool SCF, int NW, int NT, int D>
+template <bool SCF, int NW, int NC, int D>
 void launch_small_t(const ConvMfmaArgs &a, const half_t *wfrag, unsigned long long taps, int M, hipStream_t s) {
-    const dim3 grid(((M + 31) / 32 + NT - 1) / NT, a.Cout / 32);
-    hipLaunchKernelGGL((conv_small_kernel<SCF, NW, NT, D>), grid, dim3(NW * 64), 0, s, a, wfrag, taps, M);
+    const dim3 grid((M + 31) / 32, a.Cout / (32 * NC));
+    hipLaunchKernelGGL((conv_small_kernel<SCF, NW, NC, D>), grid, dim3(NW * 64), 0, s, a, wfrag, taps, M);
 }
 
 bool launch_conv_small(const ConvMfmaArgs &a, hipStream_t s) {
@@ -272,7 +264,16 @@ bool launch_conv_small(const ConvMfmaArgs &a, hipStream_t s) {
     // kept: the pixel operand fetched as whole 128-byte chunks of 8 pixels per load (8 cache lines per instruction instead of the gather's
     // 32) and transposed into MFMA fragments through a wave-private LDS tile, with 1 / 2 / 4 tiles per workgroup: bit-identical results,
     // 430 / 659 us (1 face), 504 / 716 us (4 faces), 16 - 32 faces 1.3 - 3.1 ms per pass (profiles/r03x_small_lds.txt).)
-    if (scf) launch_small_t<true, 4, 1, 3>(a, wfrag, taps, M, s);
-    else launch_small_t<false, 4, 1, 3>(a, wfrag, taps, M, s);
+    static const int nc_env = frt_tuning_env("FRT_CONV_SMALL_NC") ? atoi(frt_tuning_env("FRT_CONV_SMALL_NC")) : 0;
+    const int wgs = (M + 31) / 32 * (a.Cout / 32);
+    int nc = wgs > 256 && a.Cout % 64 == 0 ? 2 : 1;  // more one-block units than CUs: two cout blocks per workgroup share the pixel fragments
+    if (nc_env == 1 || (nc_env == 2 && a.Cout % 64 == 0)) nc = nc_env;
+    if (nc == 2) {
+        if (scf) launch_small_t<true, 4, 2, 3>(a, wfrag, taps, M, s);
+        else launch_small_t<false, 4, 2, 3>(a, wfrag, taps, M, s);
+    } else {
+        if (scf) launch_small_t<true, 4, 1, 3>(a, wfrag, taps, M, s);
+        else launch_small_t<false, 4, 1, 3>(a, wfrag, taps, M, s);
+    }
     return true;
 }
