@@ -268,6 +268,8 @@ bool launch_conv_small(const ConvMfmaArgs &a, hipStream_t s) {
     const int wgs = (M + 31) / 32 * (a.Cout / 32);
     int nc = wgs > 256 && a.Cout % 64 == 0 ? 2 : 1;  // more one-block units than CUs: two cout blocks per workgroup share the pixel fragments
     if (nc_env == 1 || (nc_env == 2 && a.Cout % 64 == 0)) nc = nc_env;
+    // (four cout blocks per workgroup, ring of 2: 8 / 12 / 16 / 32 faces 0.86 / 1.00 / 1.04 / 1.61 ms per pass against 0.73 / 0.86 / 0.91 / 1.19 -
+    //  from ~ 10 faces on the strip kernels win, profiles/r03z_small_nc4.txt)
     if (nc == 2) {
         if (scf) launch_small_t<true, 4, 2, 3>(a, wfrag, taps, M, s);
         else launch_small_t<false, 4, 2, 3>(a, wfrag, taps, M, s);
