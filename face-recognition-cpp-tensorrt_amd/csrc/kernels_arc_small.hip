@@ -258,9 +258,10 @@ bool launch_conv_small(const ConvMfmaArgs &a, hipStream_t s) {
 #endif
     const half_t *wfrag = a.stride == 1 ? a.wf : a.wf2;
     const bool scf = a.mode == EPI_BN_ADD_BN && a.scx;
-    // Four waves, one tile, ring of 3.  (Measured and not kept: 8 waves with every load in flight at once <8, 1, 5>, and 2 / 4 pixel tiles
-    // per workgroup sharing the weight fragments <8, 2, 3>, <8, 4, 2> - 1 face 412 / 404 / - us per pass, 4 faces 500 / 547 / 640+: a
-    // workgroup's time is the ~ 300 KB of operands it pulls through its CU's vector memory path, not the number of round trips.  Also not
+    // Four waves, one pixel tile, ring of 3.  (Measured and not kept: 8 waves with every load of the launch in flight at once (ring of 5),
+    // and 2 / 4 PIXEL tiles per workgroup sharing the weight fragments (8 waves, rings of 3 / 2) - 1 face 412 / 404 / 720 us per pass,
+    // 4 faces 500 / 547 / 800: a workgroup's time is the ~ 300 KB of operands it pulls through its CU's vector memory path, not the number
+    // of round trips, and a second pixel tile doubles the gathers.  Also not
     // kept: the pixel operand fetched as whole 128-byte chunks of 8 pixels per load (8 cache lines per instruction instead of the gather's
     // 32) and transposed into MFMA fragments through a wave-private LDS tile, with 1 / 2 / 4 tiles per workgroup: bit-identical results,
     // 430 / 659 us (1 face), 504 / 716 us (4 faces), 16 - 32 faces 1.3 - 3.1 ms per pass (profiles/r03x_small_lds.txt).)
