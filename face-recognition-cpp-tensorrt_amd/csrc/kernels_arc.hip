@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     const int r = lane & 31, hi = lane >> 5;
     const int H = p.H, W = p.W, Wp = W + 2;
     const int NP = n_img * (R + 2) * Wp;
-    const int strips_per_img = H / R;
+    const int strips_per_img = (H + R - 1) / R;  // (the last strip of an image may be ragged - linear enumeration only, see patch_geometry)
     const int n_valid = n_img * R * W;
 
     const int n_co_tiles = PAIR ? 1 : p.Cout >> 7;
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
             const int rr = (int)(((float)sl + 0.5f) * inv_wp);  // exact for sl < 2^20
             const int cc = sl - rr * Wp;
             m = m0 + rr * W + cc;
-            return strip_ok && rr < R && cc < W && m < Mtot;
+            return strip_ok && rr < R && row0 + rr < H && cc < W && m < Mtot;
         }
         m = m0 + sl;
         return strip_ok && sl < n_valid && m < Mtot;
@@ -986,8 +986,19 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     } else {
         static const int lim14 = frt_tuning_env("FRT_CONV_NT4_14") ? 128 : 224;  // experiment: half-image strips (4 tiles) on the 14x14 layers
         const int lim = a.H == 14 ? lim14 : 224;
+        static const bool ragged_ok = !(frt_tuning_env("FRT_CONV_RAGGED") && frt_tuning_env("FRT_CONV_RAGGED")[0] == '0');
         for (int d = a.H; d >= 1; --d) {  // tallest strip first
-            if (a.H % d || d * a.W > lim) continue;
+            if (d * a.W > lim) continue;
+            const int n_str = (a.H + d - 1) / d;
+            if (a.H % d) {
+                // Ragged last strip (rows past the image are padding in the patch and dead in the epilogue): only the short two-tile strips
+                // of a medium batch, in the padded enumeration, with at most 1/7 of the rows wasted - 14x14 in strips of 4 rows puts 24 - 48
+                // faces at ONE round of two-tile workgroups where two-row strips take two rounds of one-tile workgroups, each of which
+                // streams the same 590 KB of weights (pass of 28 / 32 / 40 / 48 / 55 faces: 1.15 / 1.22 / 1.54 / 1.60 / 1.84 -> 1.08 / 1.12 / 1.42 / 1.49 /
+                // 1.57 ms, profiles/r03z_ragged.txt)
+                if (!ragged_ok || !small_ok || (n_str * d - a.H) * 7 > a.H || tiles_for(d * (a.W + 2)) != 2 || d * (a.W + 2) > 64) continue;
+                if (a.B * n_str * co_tiles < kWant) continue;  // (never the last resort: the divisor strips cover that)
+            }
             // slots are enumerated over the padded row width when that still fits the same number of tiles (conflict-free LDS reads)
             int t = tiles_for(d * (a.W + 2));
             if (!t || t != tiles_for(d * a.W)) t = tiles_for(d * a.W);
@@ -995,7 +1006,7 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
             if (d * a.W * 10 < t * 32 * 7) continue;  // more than 30 % dead pixel slots
             R = d;
             nt = t;
-            if (!small_ok || a.B * (a.H / d) * co_tiles >= kWant) break;  // (else: keep shortening; the shortest eligible strip stays)
+            if (!small_ok || a.B * n_str * co_tiles >= kWant) break;  // (else: keep shortening; the shortest eligible strip stays)
         }
         if (!R) return false;
     }
@@ -1012,7 +1023,7 @@ void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR, SEP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     }
-    const int strips = ((a.B + n_img - 1) / n_img) * (a.H / R);
+    const int strips = ((a.B + n_img - 1) / n_img) * ((a.H + R - 1) / R);
     dim3 grid(PAIR ? (strips + 1) / 2 : strips * (a.Cout / 128));
     const int linear = (n_img == 1 && R * (a.W + 2) <= NT * 32) ? 1 : 0;
     hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR, SEP>), grid, dim3(256), lds, s, a, R, n_img, linear);
