@@ -2,6 +2,8 @@
 items 2-4): the headline config (B = 32 frames, K = 4, 640x640, 1M-row gallery) through the full three-slot / dual-activation-set
 pipeline with batches in flight, and 1080p frames letterboxed to the 640x640 detector input (the `if` branch of
 src/retinaface.cpp:112-116 and :177-181)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -235,3 +237,31 @@ def test_config0_one_jpeg_ir_se_two_face_gallery(frt, orc, synth, blobs):
     codec.close()
     det.close()
     rec.close()
+
+
+def test_bench_line_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` (the driver's command, short): ONE JSON line with the contract's fields, the roofline
+    object of the dominant kernel (live HIP-event duration, counter traffic from profiles/) and the bounded cpu_baseline leg."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2"], capture_output=True, text=True,
+                         timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "faces/sec" and "workload" in d["config"]
+    assert d["value"] > 5000 and abs(d["value"] - d["config"]["faces_per_step"] / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and 0.05 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 1e7
+    assert "conv_patch_kernel" in r["kernel"] and r["launches"] == 34
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "faces/sec" and c["sample"]
