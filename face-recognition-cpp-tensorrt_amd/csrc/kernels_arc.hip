@@ -1176,8 +1176,22 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
         //  registers for it.  4 / 16 / 32 faces: 12.4 -> 12.0, 14.0 -> 13.5, 18.7 -> 18.9 us per launch, batch-1 call 1.286 -> 1.280 ms
         //  (profiles/r03f_small_batch_wr.txt): a small-batch launch is prologue + four chunk hand-overs + epilogue + dispatch, not
         //  weight latency.)
-        case CV_P_NT2: return launch_patch_t<5, 1, 5, false, 0, false, 2, 1>(a, R, n_img, s);
-        case CV_P_NT1: return launch_patch_t<5, 1, 5, false, 0, false, 1, 1>(a, R, n_img, s);
+        case CV_P_NT2:
+#ifdef FRT_ABLATE
+            if (abl == 1) return launch_patch_t<5, 1, 5, false, 1, false, 2, 1>(a, R, n_img, s);
+            if (abl == 2) return launch_patch_t<5, 1, 5, false, 2, false, 2, 1>(a, R, n_img, s);
+            if (abl == 5) return launch_patch_t<5, 1, 5, false, 5, false, 2, 1>(a, R, n_img, s);
+            if (abl == 6) return launch_patch_t<5, 1, 5, false, 6, false, 2, 1>(a, R, n_img, s);
+#endif
+            return launch_patch_t<5, 1, 5, false, 0, false, 2, 1>(a, R, n_img, s);
+        case CV_P_NT1:
+#ifdef FRT_ABLATE
+            if (abl == 1) return launch_patch_t<5, 1, 5, false, 1, false, 1, 1>(a, R, n_img, s);
+            if (abl == 2) return launch_patch_t<5, 1, 5, false, 2, false, 1, 1>(a, R, n_img, s);
+            if (abl == 5) return launch_patch_t<5, 1, 5, false, 5, false, 1, 1>(a, R, n_img, s);
+            if (abl == 6) return launch_patch_t<5, 1, 5, false, 6, false, 1, 1>(a, R, n_img, s);
+#endif
+            return launch_patch_t<5, 1, 5, false, 0, false, 1, 1>(a, R, n_img, s);
         case CV_V1_22: return launch_conv_t<2, 2>(a, s);
         case CV_V1_14: return launch_conv_t<1, 4>(a, s);
         case CV_G2_22:
