@@ -184,6 +184,60 @@ class SmiSampler:
         self._t.join(10)
 
 
+def visible_devices():
+    """HIP devices this process can see, counted in a child process (the launcher itself must not initialise HIP: the ranks it starts
+    set GPU_MAX_HW_QUEUES before they do)."""
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as e; print(e.load_pkg().device_count())" % ROOT)
+    try:
+        o = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        return int(o.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError, subprocess.SubprocessError):
+        return 0
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run with N ranks (LOCAL_RANK -> device)."""
+    import socket
+    check = os.environ.get("FRT_BENCH_LAUNCH_CHECK") == "1"   # CPU test of this launcher: no devices needed
+    if not check:
+        have = visible_devices()
+        if have < n:
+            print("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to run (a %d-rank job on fewer devices would not measure "
+                  "what it says)" % (n, have, n), file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, json_out):
+    """FRT_BENCH_LAUNCH_CHECK=1 (tests/test_distributed.py, no GPU): every rank joins a gloo group and rank 0 reports how many ranks really
+    started - the launcher's contract (`n_gpus` == --gpus) without a device."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29513")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([1, int(os.environ.get("LOCAL_RANK", "0"))], dtype=torch.int64)
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if int(t[0]) != args.gpus:
+        print("launch check: %d ranks joined, --gpus %d" % (int(t[0]), args.gpus), file=sys.stderr)
+        return 3
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": int(t[0]), "local_rank_sum": int(t[1])}), file=json_out, flush=True)
+    return 0
+
+
 def main():
     # the contract is ONE JSON line on stdout: keep the real stdout for it and send everything else that writes to fd 1 (RCCL prints a
     # five-line version banner there when its communicator is created) to stderr
@@ -215,8 +269,23 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (no side measurements)")
     ap.add_argument("--smi-trace", default=None, help="write the rocm-smi power/clock samples taken during the timed region to this file")
+    ap.add_argument("--wait-spin-us", type=int, default=50000,
+                    help="how long libfrt's host waits busy-poll before they back off (frt_set_wait_spin_us).  The library's default is 200 us "
+                         "(a server's request threads must not burn cores); this driver owns its core and one late wake-up is a third of a "
+                         "20-step region, so it asks for 50 ms and says so in config.host_wait")
     args = ap.parse_args()
     depth = max(1, min(4, args.in_flight))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher - one rank per GPU under torch.distributed.run
+        # (the same command line the driver uses), rank 0's JSON line passes through on stdout.  Never a silent one-rank run.
+        os.dup2(json_out.fileno(), 1)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus and os.environ.get("FRT_BENCH_FORCE_DIST") != "1":
+        raise SystemExit("bench.py: WORLD_SIZE (%s) != --gpus (%d): start as many ranks as --gpus says" % (os.environ["WORLD_SIZE"], args.gpus))
+    if os.environ.get("FRT_BENCH_LAUNCH_CHECK") == "1":
+        raise SystemExit(launch_check(args, json_out))
     # Hardware queues (read by the HIP runtime when it initialises, i.e. before torch / libfrt are imported).  ROCm multiplexes a process's
     # streams onto GPU_MAX_HW_QUEUES (default 4) in-order hardware queues per priority class.  Alone, the pipeline is 1.2 % faster on the
     # default (39.05 k against 38.5 - 38.7 k faces/s with 6 / 8 / 12 queues, one box); with RCCL in the process and the per-step record
@@ -235,10 +304,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if frt.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libfrt has no CPU path)")
+    if local_rank >= frt.device_count():
+        raise SystemExit("bench.py: rank %d has no device of its own (LOCAL_RANK %d, %d visible)" % (rank, local_rank, frt.device_count()))
+    frt.set_wait_spin_us(args.wait_spin_us)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("FRT_BENCH_FORCE_DIST") == "1"  # the env switch exercises the RCCL path on one GPU
     s = frt.synth
@@ -648,6 +718,14 @@ def main():
                            "note": "max(serial stage time) / pipelined step time: 1.0 = the step costs what its slowest stage costs alone "
                                    "(stage times: HIP events around each stage in 3 extra serial steps on this rank)"}
 
+    # how many ranks really took part (counted over the process group, not read from the environment)
+    n_ranks = 1
+    if use_dist:
+        nr = torch.tensor([1], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nr, op=dist.ReduceOp.SUM)
+        n_ranks = int(nr.item())
+    if n_ranks != args.gpus:
+        raise SystemExit("bench.py: %d rank(s) took part, --gpus %d" % (n_ranks, args.gpus))
     if rank == 0:
         if args.sharded_gallery:
             boundary = "HBM-resident frames -> merged top-1 on the device"
@@ -664,7 +742,7 @@ def main():
             "metric": "faces/sec end-to-end (detect+embed+match), 640x640 batch=32, 1M gallery",
             "value": round(total_faces_per_step * args.steps / dt, 2),
             "unit": "faces/sec",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -680,7 +758,8 @@ def main():
                        "boundary": boundary,
                        "frames_per_step_per_gpu": B, "faces_per_frame": K, "faces_per_step": total_faces_per_step,
                        "gallery_rows": args.gallery, "h2d_bytes_per_step": 0 if (args.resident or args.sharded_gallery) else int(batches[0].nbytes),
-                       "gallery_load_s": round(gallery_load_s, 3), "parallelism": par},
+                       "gallery_load_s": round(gallery_load_s, 3), "parallelism": par,
+                       "host_wait": "frt_set_wait_spin_us(%d): this driver busy-polls for results (library default 200 us, then sleeping polls)" % args.wait_spin_us},
             "roofline": roofline,
             "cpu_baseline": None,
         }

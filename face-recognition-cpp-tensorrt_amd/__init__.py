@@ -44,6 +44,7 @@ ABI = {
     "frt_last_error": (ctypes.c_char_p, []),
     "frt_version": (ctypes.c_char_p, []),
     "frt_device_count": (_i, []),
+    "frt_set_wait_spin_us": (ctypes.c_long, [ctypes.c_long]),
     "frt_detector_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, ctypes.POINTER(_vp)]),
     "frt_detector_destroy": (None, [_vp]),
     "frt_detector_num_anchors": (_i, [_vp]),
@@ -149,6 +150,11 @@ def _ptr(a):
 
 def device_count():
     return lib.frt_device_count()
+
+
+def set_wait_spin_us(us):
+    """How long blocking entry points busy-poll before backing off to sleeping polls (frt_set_wait_spin_us); returns the previous value."""
+    return int(lib.frt_set_wait_spin_us(int(us)))
 
 
 def write_weights(path, state, kind):

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "frt_host.hpp"
@@ -55,36 +57,62 @@ struct Arena {
     }
 };
 
-// Host waits poll first.  hipEventSynchronize / hipStreamSynchronize park the thread on an interrupt; in the 20-step benchmark region (one wait
-// every 3 ms) that wake-up was observed 20 - 30 ms late about once in four processes - the GPU finished all three batches in flight while the
-// host slept (profiles/r03v_step_times.txt; with polling 12 of 12 processes within 1 %, r03w_step_times.txt) - and an ordinary wake-up costs
-// tens of microseconds on every synchronous call.  Polling costs a core while waiting; FRT_WAIT_SPIN_US bounds it (default 50 000 us, then
-// the blocking wait takes over; 0: block at once).
+// Host waits: spin briefly, then poll at a low duty cycle, then block.
+//   1. busy-poll hipEventQuery / hipStreamQuery for FRT_WAIT_SPIN_US (default 200 us; frt_set_wait_spin_us): a reply that is about to arrive
+//      is picked up without a sleep / wake-up round trip (tens of microseconds on every synchronous call);
+//   2. then query once per ~50 us sleep (nanosleep: the thread is off the core in between, ~1 % of a core) for up to 2 s.  The reference's
+//      server is .multithreaded() (src/app.cpp:367): every request thread waiting in findFace / forward must not burn a core for the whole
+//      GPU latency, which the 50 ms busy-poll of round 3 did;
+//   3. then hipEventSynchronize / hipStreamSynchronize (interrupt wait) - an idle pipeline costs nothing.
+// Why not (3) at once: in the 20-step benchmark region (one wait every 3 ms) the interrupt wake-up was observed 20 - 30 ms late about once in
+// four processes - the GPU finished all three batches in flight while the host slept (profiles/r03v_step_times.txt; polling: 12 of 12
+// processes within 1 %, r03w_step_times.txt).  A throughput driver that owns its core may raise the spin (bench.py sets 50 000 and says so).
+static std::atomic<long> g_wait_spin_us{-1};
 static long wait_spin_us() {
-    static const long v = [] {
+    long v = g_wait_spin_us.load(std::memory_order_relaxed);
+    if (v < 0) {
         const char *e = getenv("FRT_WAIT_SPIN_US");
-        return e ? atol(e) : 50000L;
+        v = e ? std::max(0L, atol(e)) : 200L;
+        g_wait_spin_us.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+static long wait_poll_us() {
+    static const long v = [] {
+        const char *e = getenv("FRT_WAIT_POLL_US");
+        return e ? std::max(0L, atol(e)) : 2000000L;
     }();
     return v;
 }
 template <class Query>
 static bool spin_until_done(Query &&query) {
-    const long spin_us = wait_spin_us();
-    if (spin_us <= 0) return false;
+    const long spin_us = wait_spin_us(), poll_us = wait_poll_us();
+    if (spin_us <= 0 && poll_us <= 0) return false;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int it = 0;; ++it) {
+    auto elapsed_us = [&] { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
+    bool queried = false;
+    auto done = [&]() -> bool {
         const hipError_t q = query();
         if (q == hipSuccess) {
-            if (it) (void)hipGetLastError();  // "not ready" is an answer, not an error: do not leave it behind as the thread's last error
+            if (queried) (void)hipGetLastError();  // "not ready" is an answer, not an error: do not leave it behind as the thread's last error
             return true;
         }
         if (q != hipErrorNotReady) HIPCHK(q);
-        if ((it & 63) == 63 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) {
-            (void)hipGetLastError();
-            return false;
+        queried = true;
+        return false;
+    };
+    if (spin_us > 0)
+        for (int it = 0;; ++it) {
+            if (done()) return true;
+            if ((it & 15) == 15 && elapsed_us() > spin_us) break;
+            __builtin_ia32_pause();
         }
-        __builtin_ia32_pause();
+    while (poll_us > 0 && elapsed_us() < spin_us + poll_us) {
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (done()) return true;
     }
+    (void)hipGetLastError();
+    return false;
 }
 static void wait_event_spinning(hipEvent_t ev) {
     if (!spin_until_done([&] { return hipEventQuery(ev); })) HIPCHK(hipEventSynchronize(ev));
@@ -1571,7 +1599,8 @@ struct frt_pipeline {
         // consecutive calls' match stages sit on DIFFERENT streams (their recogniser passes') but share the matcher's scratch and this
         // pipeline's d_idx / d_sim: each one starts behind the previous one's end (they rarely meet: 0.3 ms every 3.3 ms, half a
         // period apart - which is exactly why an unordered pair showed up as one failing equality test in several hundred)
-        if (pipe3 && mat && mat->busy) HIPCHK(hipStreamWaitEvent(ms, mat->ev_busy, 0));
+        // (the serial branch too: an object-level frt_matcher_top1_dev / topk_dev on another stream shares d_partial / the pair lists with this stage)
+        if (mat && mat->busy) HIPCHK(hipStreamWaitEvent(ms, mat->ev_busy, 0));
         run_part(GraphKey{2, nullptr, results_dev, embeds_dev, n, slot, align ? 1 : 0, gen}, ms, [&](hipStream_t st) {
             if (have_gallery) mat->top1_dev(emb_slot, F, d_idx, d_sim, st);
             {
@@ -1601,6 +1630,11 @@ extern "C" {
 
 const char *frt_last_error(void) { return frthost::last_error().c_str(); }
 const char *frt_version(void) { return "libfrt 0.1 (gfx950)"; }
+long frt_set_wait_spin_us(long microseconds) {
+    const long prev = wait_spin_us();
+    g_wait_spin_us.store(std::max(0L, microseconds), std::memory_order_relaxed);
+    return prev;
+}
 int frt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -2516,16 +2550,14 @@ int frt_pipeline_check_overlap(frt_pipeline *p, float *ratio_out) {
     int rc = guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
+        std::lock_guard<std::mutex> la(p->async_mu);  // same order as pipeline_submit_impl: async_mu, then run_mu
         std::lock_guard<std::mutex> lk(p->run_mu);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
         if (p->stream) HIPCHK(hipStreamSynchronize(p->stream));
-        {
-            std::lock_guard<std::mutex> la(p->async_mu);
-            p->ensure_stream();
-            p->ensure_async();  // the upload stream of frt_pipeline_submit / run takes part
-        }
+        p->ensure_stream();
+        p->ensure_async();  // the upload stream of frt_pipeline_submit / run takes part
         p->self_check(true);
         if (ratio_out) *ratio_out = p->overlap_ratio;
     });

@@ -48,7 +48,8 @@ Rccl &rccl() {
             if (r.handle) break;
         }
         if (!r.handle) {
-            r.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+            const char *e = dlerror();  // (one call: dlerror() clears the state it returns)
+            r.error = std::string("librccl not found: ") + (e ? e : "?");
             return;
         }
         auto sym = [&](const char *n) {

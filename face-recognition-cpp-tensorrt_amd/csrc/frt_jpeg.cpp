@@ -198,9 +198,14 @@ struct BitReader {
     uint64_t acc = 0;   // bits are consumed from the top
     int cnt = 0;        // valid bits in acc
     int marker = 0;     // pending marker (0: none); once hit, zero bits are supplied
+    int fed_zeros = 0;  // zero bytes supplied past the end of the data (a marker or the end of the buffer)
+    // the segment has nothing left: more than a full bit buffer of made-up zeros has been handed out.  A scan that goes on from here only
+    // decodes zeros; the walkers stop it (what has been decoded stands) so that a short crafted stream cannot buy whole-image passes
+    bool dry() const { return fed_zeros > 16; }
     void refill() {
         while (cnt <= 56) {
             int b = 0;
+            if (marker || p >= n) ++fed_zeros;
             if (!marker && p < n) {
                 b = d[p];
                 if (b == 0xFF) {
@@ -234,6 +239,7 @@ struct BitReader {
     bool restart(int expect) {
         acc = 0;
         cnt = 0;
+        fed_zeros = 0;
         if (!marker) {  // the marker has not been reached by the bit buffer yet: scan for it (skipping padding bits already consumed)
             while (p + 1 < n && !(d[p] == 0xFF && d[p + 1] != 0 && d[p + 1] != 0xFF)) ++p;
             if (p + 1 >= n) return false;
@@ -265,6 +271,8 @@ inline int decode_sym(BitReader &br, const HuffTable &t) {
 }
 
 inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+// DC predictor update, kept in the 16-bit range the coefficient has anyway (unsigned arithmetic: crafted streams cannot overflow an int)
+inline int dc_add(int pred, int diff) { return (int)(int16_t)(uint16_t)((unsigned)pred + (unsigned)diff); }
 
 }  // namespace
 
@@ -291,7 +299,7 @@ int decode_scan(const uint8_t *d, size_t n, const Parsed &P, int16_t *coef, std:
                     int16_t *blk = coef + (c.block0 + (size_t)(my * c.v + v) * c.bw + (mx * c.h + hh)) * 64;
                     int s = decode_sym(br, dct);
                     if (s < 0 || s > 11) return fail(err, "jpeg: corrupt DC code");
-                    if (s) pred[ci] += extend(br.get(s), s);
+                    if (s) pred[ci] = dc_add(pred[ci], extend(br.get(s), s));
                     blk[0] = (int16_t)pred[ci];
                     for (int k = 1; k < 64;) {
                         const int rs = decode_sym(br, act);
@@ -371,7 +379,7 @@ int decode_progressive(const uint8_t *d, size_t n, Parsed &P, int16_t *coef, std
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
             return fail(err, "jpeg: two SOF markers");
         } else if (m == 0xDA) {
-            if (++n_scans > 1000) return fail(err, "jpeg: too many scans");
+            if (++n_scans > 4 * 64 * h.ncomp) return fail(err, "jpeg: too many scans");  // (a full spectral / successive-approximation script is far below)
             if (sl < 1) return fail(err, "jpeg: short SOS");
             const int ns = s[0];
             if (ns < 1 || ns > h.ncomp || sl < 1 + 2 * ns + 3) return fail(err, "jpeg: bad SOS");
@@ -404,7 +412,7 @@ int decode_progressive(const uint8_t *d, size_t n, Parsed &P, int16_t *coef, std
                 // interleaved DC scan (or the only component's DC scan): MCU order, component planes padded to whole MCUs
                 const int total_mcu = h.mcux * h.mcuy;
                 int until = h.restart_interval ? h.restart_interval : total_mcu + 1;
-                for (int mcu = 0; mcu < total_mcu; ++mcu) {
+                for (int mcu = 0; mcu < total_mcu && !br.dry(); ++mcu) {
                     if (until == 0) {
                         if (!br.restart(rst)) return fail(err, "jpeg: missing restart marker");
                         rst = (rst + 1) & 7;
@@ -421,8 +429,8 @@ int decode_progressive(const uint8_t *d, size_t n, Parsed &P, int16_t *coef, std
                                 if (Ah == 0) {
                                     const int sz = decode_sym(br, P.dc[sc[i].td]);
                                     if (sz < 0 || sz > 11) return fail(err, "jpeg: corrupt DC code");
-                                    if (sz) pred[i] += extend(br.get(sz), sz);
-                                    blk[0] = (int16_t)(pred[i] * (1 << Al));
+                                    if (sz) pred[i] = dc_add(pred[i], extend(br.get(sz), sz));
+                                    blk[0] = (int16_t)((unsigned)pred[i] << Al);
                                 } else if (br.get(1)) {
                                     blk[0] = (int16_t)(blk[0] | p1);
                                 }
@@ -436,7 +444,7 @@ int decode_progressive(const uint8_t *d, size_t n, Parsed &P, int16_t *coef, std
                 const int total = bwn * bhn;
                 int until = h.restart_interval ? h.restart_interval : total + 1;
                 const HuffTable &act = P.ac[sc[0].ta];
-                for (int b = 0; b < total; ++b) {
+                for (int b = 0; b < total && !br.dry(); ++b) {
                     if (until == 0) {
                         if (!br.restart(rst)) return fail(err, "jpeg: missing restart marker");
                         rst = (rst + 1) & 7;
@@ -451,8 +459,8 @@ int decode_progressive(const uint8_t *d, size_t n, Parsed &P, int16_t *coef, std
                         if (Ah == 0) {
                             const int sz = decode_sym(br, P.dc[sc[0].td]);
                             if (sz < 0 || sz > 11) return fail(err, "jpeg: corrupt DC code");
-                            if (sz) pred[0] += extend(br.get(sz), sz);
-                            blk[0] = (int16_t)(pred[0] * (1 << Al));
+                            if (sz) pred[0] = dc_add(pred[0], extend(br.get(sz), sz));
+                            blk[0] = (int16_t)((unsigned)pred[0] << Al);
                         } else if (br.get(1)) {
                             blk[0] = (int16_t)(blk[0] | p1);
                         }

@@ -52,6 +52,11 @@ const char *frt_last_error(void);
 const char *frt_version(void);
 /* Number of visible HIP devices (0 when none). */
 int frt_device_count(void);
+/* How long a blocking entry point (findFace, forward, frt_pipeline_wait ...) busy-polls for the device before it backs off: the wait spins
+ * for `microseconds` (default 200, or FRT_WAIT_SPIN_US), then polls once per ~50 us sleep (the thread is off its core in between), then
+ * parks in the interrupt wait.  Process-wide.  A server with many request threads keeps the default; a throughput driver that owns its
+ * core may raise it (bench.py uses 50 000 and reports it).  Returns the previous value. */
+long frt_set_wait_spin_us(long microseconds);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Detector  ==  class RetinaFace (src/retinaface.h:18-23)

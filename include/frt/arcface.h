@@ -194,10 +194,24 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     std::tuple<std::vector<std::string>, std::vector<float>> getOutputs(float *output_sims) {
         std::vector<std::string> names;
         std::vector<float> sims;
-        if (output_sims == m_out && m_top_valid && m_top_idx.size() == croppedFaces.size()) {  // the matrix featureMatching() just produced
+        bool fast = output_sims == m_out && m_top_valid && m_top_idx.size() == croppedFaces.size();  // the matrix featureMatching() just produced
+        // the device maxima are only a shortcut for LOCAL, in-range rows: "no row wins" (-1: a row of NaNs - std::max_element answers 0 there)
+        // and indices shifted by a shard's row offset go through the host scan below (or answer row 0 when no matrix was materialised)
+        for (size_t i = 0; fast && i < m_top_idx.size(); ++i)
+            if (m_top_idx[i] < 0 || (size_t)m_top_idx[i] >= classNames.size() || m_top_idx[i] >= classCount) fast = false;
+        if (fast) {
             for (size_t i = 0; i < croppedFaces.size(); ++i) {
                 names.push_back(classNames[(size_t)m_top_idx[i]]);
                 sims.push_back(m_top_sim[i]);
+            }
+            return std::make_tuple(names, sims);
+        }
+        if (output_sims == m_out && !m_materialize) {  // nothing to scan: the reference's answer for a row without a maximum is element 0
+            for (size_t i = 0; i < croppedFaces.size(); ++i) {
+                const int k = i < m_top_idx.size() ? m_top_idx[i] : -1;
+                const bool ok = k >= 0 && (size_t)k < classNames.size();
+                names.push_back(classNames[ok ? (size_t)k : 0]);
+                sims.push_back(i < m_top_sim.size() ? m_top_sim[i] : 0.f);
             }
             return std::make_tuple(names, sims);
         }
@@ -217,7 +231,10 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
         std::vector<float> sims((size_t)n);
         matmul.top1(m_embeds.data(), n, idx.data(), sims.data());
         std::vector<std::string> names;
-        for (int i = 0; i < n; ++i) names.push_back(classNames[(size_t)idx[(size_t)i]]);
+        for (int i = 0; i < n; ++i) {
+            const int k = idx[(size_t)i];  // -1: no row won (NaN similarities); the reference's max_element answers element 0
+            names.push_back(classNames[(k >= 0 && (size_t)k < classNames.size()) ? (size_t)k : 0]);
+        }
         return std::make_tuple(names, sims);
     }
     // src/arcface.cpp:219-231: drawing only, not on the hot path (not even called by app.cpp); real OpenCV required.

@@ -100,3 +100,33 @@ def test_world_size_2_gloo(frt):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] and r[2] and r[3] for r in res), res
+
+
+def _bench(args, env_extra, timeout=300):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` as the driver types it (no torch.distributed.run around it) must start two ranks: under the launch-check
+    stub (no device needed) both join a gloo group and rank 0 reports the number of ranks that really took part (round-3 review item 1:
+    it used to run ONE rank and print n_gpus 1)."""
+    import json
+    o = _bench(["--gpus", "2", "--steps", "2"], {"FRT_BENCH_LAUNCH_CHECK": "1"})
+    assert o.returncode == 0, o.stderr[-2000:]
+    lines = [l for l in o.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, o.stdout          # ONE JSON line, from rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["local_rank_sum"] == 1   # LOCAL_RANK 0 and 1: one device each
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """Without devices (this container) `--gpus 2` exits non-zero with a message that says why; so does a rank count that contradicts --gpus."""
+    o = _bench(["--gpus", "2", "--steps", "2"], {})
+    assert o.returncode != 0 and "refusing to run" in o.stderr and not o.stdout.strip()
+    o = _bench(["--gpus", "4", "--steps", "2"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert o.returncode != 0 and "WORLD_SIZE" in o.stderr
