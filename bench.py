@@ -45,6 +45,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense; /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # same guide: fp32 matrix / vector
+PEAK_HBM_BPS = 8.0e12            # same guide: HBM3E
+DET_ACT_BYTES_PER_640_FRAME = 27.45e6 * 4  # detector activations (fp32) written + read once per 640x640 frame
 DEPTH = 3                        # batches in flight at the host boundary
 
 
@@ -96,42 +99,49 @@ def _cpu_host_work(heads, embeds, gallery, frames, K, budget_s):
 
 
 def cpu_baseline(det_sd, rec_sd, gallery, frames, K):
+    """The oracle timed on this box's host cores.  The all-core leg used to be SLOWER than one thread (torch-CPU oversubscribed on a
+    256-thread host: 3.3 against 10.9 faces/s, round-3 review item 12): the primary value is now the best of a thread sweep, with the
+    thread count it was reached at in `cores`."""
     import torch
 
     import oracle
     from oracle import nets
     ncpu = int(torch.get_num_threads())
+    nproc = os.cpu_count() or 1
     H, W = frames.shape[1:3]
     heads = []
     for fr in frames[:8]:
         loc, conf = nets.retinaface_forward(det_sd, oracle.det_preprocess(fr, H, W)[None])
         heads.append((loc[0], conf[0]))
-    out = {}
-    f, n, dt = _cpu_full(det_sd, rec_sd, gallery, frames, K, 10.0)
-    full_all = f / dt
-    sample_full = "%d frame(s), %d faces, %.1f s" % (n, f, dt)
-    f, n, dt = _cpu_host_work(heads, None, gallery, frames[:8], K, 4.0)
-    host_all = f / dt  # (the oracle's C code is single-threaded; "all cores" only changes NumPy/torch internals)
-    torch.set_num_threads(1)
+    sweep = {}
     try:
-        f, n, dt = _cpu_full(det_sd, rec_sd, gallery, frames, K, 8.0)
-        full_1 = f / dt
-        sample_full_1 = "%d frame(s), %d faces, %.1f s" % (n, f, dt)
-        f, n, dt = _cpu_host_work(heads, None, gallery, frames[:8], K, 4.0)
+        for nt in [t for t in (1, 4, 8, 16, 32, 64) if t <= nproc]:
+            torch.set_num_threads(nt)
+            _cpu_full(det_sd, rec_sd, gallery, frames[:1], K, 0.0)  # thread pool up, caches warm
+            f, n, dt = _cpu_full(det_sd, rec_sd, gallery, frames, K, 6.0 if nt == 1 else 3.0)
+            sweep[nt] = {"value": round(f / dt, 3), "sample": "%d frame(s), %d faces, %.1f s" % (n, f, dt)}
+        best = max(sweep, key=lambda t: sweep[t]["value"])
+        torch.set_num_threads(best)
+        f, n, dt = _cpu_host_work(heads, None, gallery, frames[:8], K, 3.0)
+        host_best = f / dt  # (the oracle's C code is single-threaded; more threads only change NumPy/torch internals)
+        torch.set_num_threads(1)
+        f, n, dt = _cpu_host_work(heads, None, gallery, frames[:8], K, 3.0)
         host_1 = f / dt
     finally:
         torch.set_num_threads(ncpu)
-    out = {"value": round(full_all, 3), "unit": "faces/sec", "cores": ncpu, "kind": "port",
+    out = {"value": sweep[best]["value"], "unit": "faces/sec", "cores": best, "kind": "port",
            "sample": "full CPU pipeline (oracle nets fp32 on torch-CPU, C post-processing/crop, NumPy %dx512 match) on frames of the same "
-                     "640x640 workload, one at a time like the reference: %s" % (gallery.shape[0], sample_full),
-           "single_thread": {"value": round(full_1, 3), "cores": 1, "sample": sample_full_1},
+                     "640x640 workload, one at a time like the reference; best of a thread sweep, reached with %d threads: %s"
+                     % (gallery.shape[0], best, sweep[best]["sample"]),
+           "thread_sweep": {str(t): v for t, v in sweep.items()},
+           "single_thread": {"value": sweep[1]["value"], "cores": 1, "sample": sweep[1]["sample"]},
            "reference_host_work_only": {
                "what": "only the work the reference itself does on the host around its TensorRT/cuBLASLt calls: letterbox+normalise, anchor "
                        "regeneration+decode+sort+NMS, crop+bicubic+normalise, arg-max over a materialised [F,N] fp32 row per face "
                        "(retinaface.cpp:106-136,154-271; arcface.cpp:3-17,116-129,203-217); network outputs precomputed",
-               "value": round(host_all, 3), "unit": "faces/sec", "cores": ncpu,
+               "value": round(host_best, 3), "unit": "faces/sec", "cores": best,
                "single_thread": {"value": round(host_1, 3), "cores": 1}},
-           "host": {"nproc": os.cpu_count(), "cpu": _cpu_model()}}
+           "host": {"nproc": nproc, "cpu": _cpu_model()}}
     return out
 
 
@@ -712,6 +722,33 @@ def main():
                     "recogniser": st.get("crop_faces", 0) + st.get("align_faces", 0) + st.get("embed_network", 0),
                     "match": st.get("match_top1", 0) + st.get("match_topk", 0) + st.get("pack_results", 0)}
         step_ms = 1e3 * dt / args.steps
+        if roofline is not None and max(stage_ms.values()) > 0:
+            # every stage against ITS bound (round-3 review item 14): algorithmic bytes / flops of one step over the stage's own serial time
+            wk = {k: v[1] / 3 for k, v in agg.items()}
+            det_bytes = DET_ACT_BYTES_PER_640_FRAME * (H * W) / (640.0 * 640.0) * B
+            det_flop = wk.get("det_network", 0.0)
+            rec_flop = wk.get("embed_network", 0.0)
+            n_rows = int(frt.lib.frt_matcher_num_rows(rec.matmul._h))
+            scan_b = (2 if (n_rows >= 32768 or args.sharded_gallery) else 4) * 512.0 * n_rows   # fp16 shadow scan (screened) or the fp32 rows
+            mt_ms = st.get("match_top1", 0) + st.get("match_topk", 0)
+
+            def frac(x, ms, peak):
+                return round(x / (ms * 1e-3) / peak, 4) if ms > 0 else None
+            roofline["stages"] = {
+                "detector": {"bound": "hbm", "ms": round(stage_ms["detector"], 4), "bytes": int(det_bytes), "flop": det_flop,
+                             "achieved_TBps": round(det_bytes / (stage_ms["detector"] * 1e-3) / 1e12, 3) if stage_ms["detector"] > 0 else None,
+                             "frac_hbm": frac(det_bytes, stage_ms["detector"], PEAK_HBM_BPS),
+                             "frac_fp32_matrix": frac(det_flop, stage_ms["detector"], PEAK_FP32_MATRIX_TFLOPS * 1e12),
+                             "note": "fp32 NCHW activations, every tensor written once and read once (27.45 M elements per 640x640 frame, DESIGN 3)"},
+                "recogniser": {"bound": "mfma", "ms": round(stage_ms["recogniser"], 4), "flop": rec_flop,
+                               "achieved_TFLOPs": round(rec_flop / (stage_ms["recogniser"] * 1e-3) / 1e12, 1) if stage_ms["recogniser"] > 0 else None,
+                               "frac_mfma": frac(rec_flop, stage_ms["recogniser"], PEAK_FP16_MFMA_TFLOPS * 1e12),
+                               "note": "crop + all %d faces through ArcFace; flop = every conv / linear of the pass" % F},
+                "match": {"bound": "hbm", "ms": round(mt_ms, 4), "bytes": int(scan_b),
+                          "achieved_TBps": round(scan_b / (mt_ms * 1e-3) / 1e12, 3) if mt_ms > 0 else None,
+                          "frac_hbm": frac(scan_b, mt_ms, PEAK_HBM_BPS),
+                          "note": "one scan of the gallery per call (%d rows x 512 x %d B)" % (n_rows, 2 if (n_rows >= 32768 or args.sharded_gallery) else 4)},
+                "note": "serial stage times: HIP events around each stage in 3 extra untimed serial steps; peaks 8 TB/s HBM, 157.3 TF fp32 matrix, 2.5 PF fp16 MFMA"}
         if max(stage_ms.values()) > 0:
             overlap_eff = {"value": round(max(stage_ms.values()) / step_ms, 4), "serial_stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                            "serial_sum_ms": round(sum(stage_ms.values()), 4), "step_ms": round(step_ms, 4),

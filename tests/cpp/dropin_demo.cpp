@@ -39,6 +39,39 @@ int main(int argc, char **argv) {
         std::printf("selftest %s\n", ok == 3 ? "ok" : "FAILED");
         return ok == 3 ? 0 : 1;
     }
+    if (argc == 8 && std::string(argv[1]) == "--recognize") {
+        // POST /recognize, src/app.cpp:243-287: ONE face image already at the recogniser's input size, a Bbox that covers the whole frame
+        // (x2 / y2 touch the far corner), rec_maxBatchSize 1, the recogniser constructed for the VIDEO frame size (src/app.cpp:55-57)
+        //   dropin_demo --recognize <rec.frtw> <face.bin (u8 BGR 112x112x3)> <videoFrameWidth> <videoFrameHeight> <gallery.bin> <n>
+        const int n = std::atoi(argv[7]);
+        std::vector<char> fb = slurp(argv[3]), gb = slurp(argv[6]);
+        std::vector<int> recInputShape = {3, 112, 112};
+        ArcFaceIR50 recognizer(gLogger, argv[2], std::atoi(argv[4]), std::atoi(argv[5]), "input", "output", recInputShape, 512, 1, 4, 0.65f);
+        recognizer.initKnownEmbeds(n);
+        const float *g = reinterpret_cast<const float *>(gb.data());
+        for (int i = 0; i < n; ++i) recognizer.addEmbedding(std::to_string(i), const_cast<float *>(g + (size_t)i * 512));
+        recognizer.initMatMul();
+        cv::Mat frame(112, 112, CV_8UC3, fb.data());
+        std::vector<struct Bbox> outputBbox;
+        for (int round = 0; round < 2; ++round) {  // twice: the handler clears its vectors and is called again
+            Bbox bbox;
+            bbox.x1 = 0;
+            bbox.y1 = 0;
+            bbox.x2 = recInputShape[1];
+            bbox.y2 = recInputShape[2];
+            bbox.score = 1;
+            outputBbox.push_back(bbox);
+            recognizer.forward(frame, outputBbox);
+            float *output_sims = recognizer.featureMatching();
+            std::vector<std::string> names;
+            std::vector<float> sims;
+            std::tie(names, sims) = recognizer.getOutputs(output_sims);
+            if (names.size() != 1) return 7;
+            std::printf("recognize %s %.9g %.9g\n", names[0].c_str(), sims[0], output_sims[std::atoi(names[0].c_str())]);
+            outputBbox.clear();
+        }
+        return 0;
+    }
     if (argc != 8) return 2;
     const int rows = std::atoi(argv[4]), cols = std::atoi(argv[5]), n = std::atoi(argv[7]);
     std::vector<char> fb = slurp(argv[3]), gb = slurp(argv[6]);

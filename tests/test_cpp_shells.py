@@ -76,6 +76,43 @@ def test_inference_call_sequence_matches_python_binding(demo, frt, synth, blobs,
 
 
 @pytest.mark.gpu
+def test_recognize_call_shape(demo, frt, synth, blobs, orc, tmp_path):
+    """POST /recognize (src/app.cpp:243-287): a 112x112 image - smaller than the frame size the recogniser was constructed for - with
+    Bbox{0, 0, 112, 112} touching the far corner, rec_maxBatchSize 1, forward -> featureMatching -> getOutputs; through the C++ shell
+    (twice, like two requests) and the ctypes binding, against the oracle's crop + IR-50 + top-1."""
+    from oracle import match as omatch
+    from oracle import nets
+    rpath, rsd = blobs("ir")
+    N = 500
+    face = synth.make_frame(11, 112, 112)
+    boxes = np.zeros(1, frt.BBOX_DTYPE)
+    boxes[0] = (0, 0, 112, 112, 1.0)
+    ocrop = orc.crop_faces(face, boxes)
+    assert np.array_equal(ocrop[0], face)  # a whole-frame ROI at the target size: cv::resize to the same size copies
+    oemb = nets.arcface_forward(rsd, orc.face_normalize(ocrop))
+    gal = synth.make_gallery(N)
+    gal[321] = oemb[0]
+    rec = frt.ArcFaceIR50(rpath, 640, 480, (3, 112, 112), 512, 1, 4, 0.65)   # constructed for the video frames, not for this image
+    emb = rec.forward(face, boxes)
+    assert float((emb[0] * oemb[0]).sum()) > 1 - 1e-4
+    rec.setGallery(gal)
+    rec.initMatMul()
+    names, sims = rec.matchTop1()
+    oidx, osim = omatch.top1(emb, gal)
+    assert names == [str(int(oidx[0]))] == ["321"] and abs(sims[0] - osim[0]) < 1e-5
+    rec.close()
+    (tmp_path / "face.bin").write_bytes(face.tobytes())
+    (tmp_path / "gal.bin").write_bytes(gal.tobytes())
+    out = subprocess.run([demo, "--recognize", rpath, str(tmp_path / "face.bin"), "640", "480", str(tmp_path / "gal.bin"), str(N)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l.split() for l in out.stdout.splitlines() if l.startswith("recognize")]
+    assert len(lines) == 2
+    for l in lines:
+        assert l[1] == "321" and abs(float(l[2]) - float(osim[0])) < 1e-5 and abs(float(l[3]) - float(l[2])) < 1e-6
+
+
+@pytest.mark.gpu
 def test_rccl_communicator_from_plain_cpp(tmp_path):
     """frt_comm_* (ncclAllGather bound from librccl at run time) driven by a C++ program with no Python / torch in the process: the
     one-process-per-GPU form (unique id + create) and the one-process / all-devices form (create_all + all_gather_multi)."""
