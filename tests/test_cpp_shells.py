@@ -99,7 +99,7 @@ def test_recognize_call_shape(demo, frt, synth, blobs, orc, tmp_path):
     rec.initMatMul()
     names, sims = rec.matchTop1()
     oidx, osim = omatch.top1(emb, gal)
-    assert names == [str(int(oidx[0]))] == ["321"] and abs(sims[0] - osim[0]) < 1e-5
+    assert [int(v) for v in names] == [int(oidx[0])] == [321] and abs(sims[0] - osim[0]) < 1e-5
     rec.close()
     (tmp_path / "face.bin").write_bytes(face.tobytes())
     (tmp_path / "gal.bin").write_bytes(gal.tobytes())
