@@ -94,6 +94,13 @@ ABI = {
     "frt_comm_sync": (_i, [_vp]),
     "frt_embedder_set_se_fused": (_i, [_vp, _i]),
     "frt_jpeg_encode_batch_after": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "frt_detector_geometry": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "frt_coalescer_create": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_vp)]),
+    "frt_coalescer_destroy": (None, [_vp]),
+    "frt_coalescer_infer": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _vp]),
+    "frt_coalescer_infer_crops": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _vp, _vp]),
+    "frt_pipeline_submit_crops": (_i, [_vp, _vp, _i, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_long)]),
+    "frt_coalescer_stats": (_i, [_vp, _vp, _vp]),
     "frt_pipeline_create": (_i, [_vp, _vp, _vp, _i, ctypes.POINTER(_vp)]),
     "frt_pipeline_destroy": (None, [_vp]),
     "frt_pipeline_run": (_i, [_vp, _vp, _i, _vp, _vp]),
@@ -557,6 +564,47 @@ class ArcFaceIR50:
             lib.frt_embedder_destroy(self._h)
             self._h = _vp()
         self.matmul.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# request coalescer (opt-in): concurrent one-frame requests -> pipeline batches (frt_coalescer_*)
+# ----------------------------------------------------------------------------------------------------------------------
+class Coalescer:
+    def __init__(self, detector, recognizer, max_frames, window_us=100, match=True):
+        self._h = _vp()
+        self.det, self.rec = detector, recognizer
+        self.max_faces = detector.maxFacesPerScene
+        _check(lib.frt_coalescer_create(detector._h, recognizer._h, recognizer.matmul._h if match else None, int(max_frames), int(window_us),
+                                        ctypes.byref(self._h)))
+
+    def infer(self, frame, want_embeds=True, want_crops=False):
+        """One frame (u8 BGR [H, W, 3]) -> (records of its boxes, embeddings [n, 512] or None[, u8 crops [n, 112, 112, 3]]).  Blocks; call
+        it from many threads."""
+        frame = np.ascontiguousarray(frame, np.uint8)
+        res = np.zeros(self.max_faces, RESULT_DTYPE)
+        emb = np.zeros((self.max_faces, 512), np.float32) if want_embeds else None
+        crops = np.zeros((self.max_faces, 112, 112, 3), np.uint8) if want_crops else None
+        n = ctypes.c_int(0)
+        _check(lib.frt_coalescer_infer_crops(self._h, _ptr(frame), frame.shape[0], frame.shape[1], frame.shape[1] * 3, _ptr(res), _ptr(emb), _ptr(crops),
+                                             ctypes.byref(n)))
+        out = (res[:n.value], (emb[:n.value] if want_embeds else None))
+        return out + (crops[:n.value],) if want_crops else out
+
+    def stats(self):
+        b, f = ctypes.c_long(0), ctypes.c_long(0)
+        _check(lib.frt_coalescer_stats(self._h, ctypes.byref(b), ctypes.byref(f)))
+        return int(b.value), int(f.value)
+
+    def close(self):
+        if self._h:
+            lib.frt_coalescer_destroy(self._h)
+            self._h = _vp()
 
     def __del__(self):
         try:

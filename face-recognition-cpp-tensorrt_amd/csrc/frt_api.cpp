@@ -1283,6 +1283,7 @@ struct frt_pipeline {
         uint8_t *d_frames = nullptr;
         frt_face_result *d_results = nullptr;
         float *d_embeds = nullptr;
+        uint8_t *d_crops = nullptr;  // u8 BGR 112x112 crops of the batch's faces (frt_pipeline_submit_crops)
         hipEvent_t ev_h2d = nullptr, ev_out = nullptr;
         long ticket = -1;  // ticket whose results ev_out guards; -1: never used
     };
@@ -1290,6 +1291,7 @@ struct frt_pipeline {
     hipStream_t copy_stream = nullptr;
     int copy_prio = 0;
     hipEvent_t ev_frames = nullptr;  // set by submit for the next run(): the detector stream waits for it
+    uint8_t *crops_req = nullptr;    // set by submit for the next run(): the crop kernel also writes the u8 crops there
     long next_ticket = 0;
     std::mutex async_mu;
     void ensure_async() {
@@ -1304,6 +1306,7 @@ struct frt_pipeline {
             b.d_frames = arena.alloc<uint8_t>((size_t)max_frames * det->g.frame_h * det->g.frame_w * 3);
             b.d_results = arena.alloc<frt_face_result>(F);
             b.d_embeds = arena.alloc<float>(F * 512);
+            b.d_crops = arena.alloc<uint8_t>(F * 112 * 112 * 3);
             HIPCHK(hipEventCreateWithFlags(&b.ev_h2d, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&b.ev_out, hipEventDisableTiming));
         }
@@ -1560,7 +1563,10 @@ struct frt_pipeline {
         }
         const bool have_gallery = mat && mat->N > 0;
         const unsigned gen = mat ? mat->generation : 0u;
-        run_part(GraphKey{0, frames_dev, nullptr, nullptr, n, slot, align ? 1 : 0, 0u}, ds, [&](hipStream_t st) {
+        uint8_t *crops_out = crops_req;  // (one call only)
+        crops_req = nullptr;
+        const int akey = (align ? 1 : 0) | (crops_out ? 2 : 0);
+        run_part(GraphKey{0, frames_dev, nullptr, nullptr, n, slot, akey, 0u}, ds, [&](hipStream_t st) {
             det->forward_frames(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, st);
             det->postprocess(n, st, slot_boxes[slot], slot_nout[slot], slot_landmarks[slot]);  // straight into this call's slot
         });
@@ -1575,15 +1581,15 @@ struct frt_pipeline {
         float *emb_slot = slot_embeds[slot];
         int *valid = slot_valid[slot];
         // (a pass on activation set k follows the pass two calls back on the same set: ordered by its stream and by ev_done[slot])
-        run_part(GraphKey{1, frames_dev, nullptr, nullptr, n, slot, align ? 1 : 0, (unsigned)eset}, es, [&](hipStream_t st) {
+        run_part(GraphKey{1, frames_dev, nullptr, nullptr, n, slot, akey, (unsigned)eset}, es, [&](hipStream_t st) {
             if (align) {
                 ProfScope ps(2, "align_faces", (double)F * 112 * 112 * 3, st);
                 launch_align_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, slot_landmarks[slot],
-                                   nout, max_faces, F, 0, nullptr, chw, valid, st);
+                                   nout, max_faces, F, 0, crops_out, chw, valid, st);
             } else {
                 ProfScope ps(2, "crop_faces", (double)F * 112 * 112 * 3, st);
                 launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, boxes, nout, max_faces,
-                                  F, 0, 112, 112, nullptr, chw, valid, st);
+                                  F, 0, 112, 112, crops_out, chw, valid, st);
             }
             for (int f0 = 0; f0 < F; f0 += emb->max_batch) {
                 const int nf = std::min(emb->max_batch, F - f0);
@@ -1601,7 +1607,7 @@ struct frt_pipeline {
         // period apart - which is exactly why an unordered pair showed up as one failing equality test in several hundred)
         // (the serial branch too: an object-level frt_matcher_top1_dev / topk_dev on another stream shares d_partial / the pair lists with this stage)
         if (mat && mat->busy) HIPCHK(hipStreamWaitEvent(ms, mat->ev_busy, 0));
-        run_part(GraphKey{2, nullptr, results_dev, embeds_dev, n, slot, align ? 1 : 0, gen}, ms, [&](hipStream_t st) {
+        run_part(GraphKey{2, nullptr, results_dev, embeds_dev, n, slot, akey, gen}, ms, [&](hipStream_t st) {
             if (have_gallery) mat->top1_dev(emb_slot, F, d_idx, d_sim, st);
             {
                 ProfScope ps(2, "pack_results", (double)F, st);
@@ -1712,6 +1718,15 @@ void frt_detector_destroy(frt_detector *d) {
 }
 
 int frt_detector_num_anchors(const frt_detector *d) { return d ? d->g.A : 0; }
+int frt_detector_geometry(const frt_detector *d, int *frame_w, int *frame_h, int *max_batch, int *max_faces, int *device) {
+    if (!d) return FRT_ERR_INVALID;
+    if (frame_w) *frame_w = d->g.frame_w;
+    if (frame_h) *frame_h = d->g.frame_h;
+    if (max_batch) *max_batch = d->max_batch;
+    if (max_faces) *max_faces = d->g.max_faces;
+    if (device) *device = d->device;
+    return FRT_OK;
+}
 
 int frt_detector_find_faces_batch(frt_detector *d, const uint8_t *bgr, int n_frames, int rows, int cols, size_t row_stride,
                                   size_t frame_stride, frt_bbox *out, int *n_out) {
@@ -2642,7 +2657,8 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable) {
 }
 
 // queue one batch through a staging set; caller holds neither mutex
-static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, bool synchronous = false) {
+static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, bool synchronous = false,
+                                 uint8_t *crops_host = nullptr) {
     if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
     use_device(p->det->device);
     std::lock_guard<std::mutex> lk(p->async_mu);   // staging sets + ticket order
@@ -2669,10 +2685,12 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
         p->ev_frames = b.ev_h2d;  // the stages that read the frames (detector, crop) wait for the copy; the caller's stream does not
     }
     p->serial_call = lone;
+    p->crops_req = crops_host ? b.d_crops : nullptr;
     try {
         pipeline_lock_run(p, b.d_frames, n_frames, b.d_results, embeds_out ? b.d_embeds : nullptr);
     } catch (...) {
         p->ev_frames = nullptr;
+        p->crops_req = nullptr;
         p->serial_call = false;
         throw;
     }
@@ -2680,6 +2698,7 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     const int F = n_frames * p->max_faces;
     HIPCHK(hipMemcpyAsync(results, b.d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
     if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, b.d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
+    if (crops_host) HIPCHK(hipMemcpyAsync(crops_host, b.d_crops, (size_t)F * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(b.ev_out, s));
     b.ticket = ticket;
     p->next_ticket = ticket + 1;
@@ -2715,6 +2734,14 @@ int frt_pipeline_submit(frt_pipeline *p, const uint8_t *frames, int n_frames, fr
     return guarded([&] {
         if (!p || !frames || !results || !ticket_out) raise(FRT_ERR_INVALID, "null argument");
         *ticket_out = pipeline_submit_impl(p, frames, n_frames, results, embeds_out);
+    });
+}
+
+int frt_pipeline_submit_crops(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, uint8_t *crops_out,
+                              long *ticket_out) {
+    return guarded([&] {
+        if (!p || !frames || !results || !ticket_out) raise(FRT_ERR_INVALID, "null argument");
+        *ticket_out = pipeline_submit_impl(p, frames, n_frames, results, embeds_out, false, crops_out);
     });
 }
 

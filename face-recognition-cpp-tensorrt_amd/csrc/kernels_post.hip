@@ -249,9 +249,12 @@ __global__ void pack_results_kernel(const frt_bbox *__restrict__ boxes, const in
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     frt_face_result r;
-    r.box = boxes[f];
     r.frame = f / max_faces;
-    const bool ok = (f % max_faces) < n_boxes[r.frame] && valid[f] != 0;
+    const bool used = (f % max_faces) < n_boxes[r.frame];
+    // an unused slot reads as all zeros (score 0 - a detection's score is above the threshold): "box present, ROI empty" (valid 0, score > 0)
+    // stays distinguishable from "no box", which the request coalescer needs to hand findFace its exact box list
+    r.box = used ? boxes[f] : frt_bbox{0, 0, 0, 0, 0.f};
+    const bool ok = used && valid[f] != 0;
     r.valid = ok ? 1 : 0;
     r.match_idx = (ok && idx) ? idx[f] : -1;
     r.match_sim = (ok && sim) ? sim[f] : 0.f;

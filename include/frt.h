@@ -70,6 +70,8 @@ int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int 
 void frt_detector_destroy(frt_detector *d);
 /* m_OUTPUT_SIZE_BASE (src/retinaface.cpp:13): anchors per frame */
 int frt_detector_num_anchors(const frt_detector *d);
+/* What the detector was created for (any out pointer may be NULL). */
+int frt_detector_geometry(const frt_detector *d, int *frame_w, int *frame_h, int *max_batch, int *max_faces, int *device);
 
 /* RetinaFace::findFace (src/retinaface.cpp:147-152).  bgr: u8 HWC frame of exactly frame_h x frame_w, row_stride bytes
  * per row.  out: capacity max_faces.  n_out: number of boxes written (score-descending, after NMS and cap). */
@@ -231,7 +233,7 @@ typedef struct frt_face_result {
     int32_t frame;     /* frame index inside the batch                          */
     int32_t match_idx; /* gallery row of the best match (-1: no gallery)        */
     float match_sim;   /* its cosine similarity                                 */
-    int32_t valid;     /* 0: slot unused (fewer than max_faces boxes) or empty ROI */
+    int32_t valid;     /* 0: slot unused (fewer than max_faces boxes: box is all zeros, score 0) or empty ROI (box kept, score > 0) */
 } frt_face_result;
 
 /* Borrows the three objects (they must outlive the pipeline and live on the same device).  max_frames <= detector
@@ -250,6 +252,11 @@ int frt_pipeline_run(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_f
  * in order.  frt_pipeline_run (below the same path: submit + wait) may be called from several threads at once. */
 int frt_pipeline_submit(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, long *ticket_out);
 int frt_pipeline_wait(frt_pipeline *p, long ticket);
+/* frt_pipeline_submit that also returns the faces' u8 BGR 112x112 crops (what CroppedFace.face holds after ArcFaceIR50::forward,
+ * src/arcface.cpp:3-17; the reply step JPEG-encodes one of them, src/app.cpp:328): crops_out [n_frames*max_faces][112][112][3], may be
+ * NULL.  Crops of unused / empty-ROI slots are unspecified. */
+int frt_pipeline_submit_crops(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, uint8_t *crops_out,
+                              long *ticket_out);
 /* Same with everything resident in HBM: frames_dev u8 [n_frames][rows][cols][3]; results_dev / embeds_dev device
  * buffers (embeds_dev may be NULL).  Asynchronous on the pipeline stream; frt_pipeline_sync() waits. */
 int frt_pipeline_run_dev(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev);
@@ -284,6 +291,29 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
  * and mode repeat is captured on its second occurrence and replayed afterwards; callers that never repeat their buffers stay
  * on eager launches.  Automatically off while frt_profile_enable() records events. */
 int frt_pipeline_set_graph(frt_pipeline *p, int enable);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Request coalescing (opt-in).  The reference answers ONE frame per request (src/app.cpp:293-352) from a Crow server that runs
+ * .multithreaded() (src/app.cpp:367); a one-frame call is 4 faces and leaves the device idle.  A coalescer gathers the frames of
+ * requests that are being served at the same time into one pipeline batch: every request thread calls frt_coalescer_infer with its
+ * frame and blocks; frames that arrive while earlier batches run (or within window_us of the first one when the device is idle)
+ * travel together through frt_pipeline_submit; each caller gets its own frame's results.  Borrows the three objects like
+ * frt_pipeline_create (m may be NULL or empty: no match).  max_frames <= the detector's max_batch.  Thread-safe.
+ * The C++ shells use it behind RetinaFace::findFace / ArcFaceIR50::forward / featureMatching when asked to
+ * (RetinaFace::coalesceWith, or FRT_COALESCE=<frames> in the environment).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct frt_coalescer frt_coalescer;
+int frt_coalescer_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int max_frames, int window_us, frt_coalescer **out);
+void frt_coalescer_destroy(frt_coalescer *c);
+/* One frame of the detector's frame size in, its max_faces result slots out (frt_face_result, frame = 0; slots [0, *n_boxes) hold the
+ * boxes findFace returns, in its order); embeds_out (may be NULL) [max_faces][512].  Blocks until the frame's batch has completed. */
+int frt_coalescer_infer(frt_coalescer *c, const uint8_t *bgr, int rows, int cols, size_t row_stride, frt_face_result *results, float *embeds_out,
+                        int *n_boxes);
+/* Same, and the faces' u8 BGR 112x112 crops (crops_out [max_faces][112][112][3], may be NULL) - everything ArcFaceIR50::forward leaves behind. */
+int frt_coalescer_infer_crops(frt_coalescer *c, const uint8_t *bgr, int rows, int cols, size_t row_stride, frt_face_result *results, float *embeds_out,
+                              uint8_t *crops_out, int *n_boxes);
+/* Batches submitted and frames carried so far (frames / batches = the mean batch the load produced). */
+int frt_coalescer_stats(frt_coalescer *c, long *batches_out, long *frames_out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Frame ingest: the caller's `cv::resize(img, img, Size(frameWidth, frameHeight))` (src/app.cpp:166,301;

@@ -13,6 +13,7 @@
 #include <cassert>
 #include <tuple>
 
+#include "coalesce.h"
 #include "common.h"
 #include "cvlite.h"
 #include "matmul.h"
@@ -58,8 +59,8 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
   public:
     ArcFaceIR50(TRTLogger gLogger, const std::string engineFile, int frameWidth, int frameHeight, std::string inputName, std::string outputName,
                 std::vector<int> inputShape, int outputDim, int maxBatchSize, int maxFacesPerScene, float knownPersonThreshold, int device = 0)
-        : h_(nullptr), m_frameWidth(frameWidth), m_frameHeight(frameHeight), m_OUTPUT_D(outputDim), m_maxBatchSize(maxBatchSize),
-          m_maxFacesPerScene(maxFacesPerScene), m_knownPersonThresh(knownPersonThreshold), matmul(device) {
+        : croppedFaces(this), h_(nullptr), m_id(frtdetail::nextObjectId()), m_frameWidth(frameWidth), m_frameHeight(frameHeight), m_OUTPUT_D(outputDim),
+          m_maxBatchSize(maxBatchSize), m_maxFacesPerScene(maxFacesPerScene), m_knownPersonThresh(knownPersonThreshold), matmul(device) {
         (void)gLogger;
         (void)inputName;
         (void)outputName;
@@ -67,13 +68,37 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
         m_INPUT_C = inputShape[0];
         m_INPUT_H = inputShape[1];
         m_INPUT_W = inputShape[2];
-        checkFrtStatus(frt_embedder_create(engineFile.c_str(), m_INPUT_C, m_INPUT_H, m_INPUT_W, outputDim, maxBatchSize, device, &h_));
+        // FRT_COALESCE=<frames>: the recogniser must be able to take the faces of a coalesced batch in one pass
+        const int envFrames = frtdetail::coalesceEnv().frames;
+        const int devBatch = std::max(maxBatchSize, envFrames * maxFacesPerScene);
+        checkFrtStatus(frt_embedder_create(engineFile.c_str(), m_INPUT_C, m_INPUT_H, m_INPUT_W, outputDim, devBatch, device, &h_));
         std::cout << "[INFO] Loading ArcFace Engine...\n";
         croppedFaces.reserve((size_t)maxFacesPerScene);
+        if (envFrames > 0) {
+            try {
+                frtdetail::autoLink(false, frtdetail::Pending{device, frameWidth, frameHeight, devBatch, nullptr, h_, matmul.handle(), &m_link});
+            } catch (...) {
+                frt_embedder_destroy(h_);
+                throw;
+            }
+        }
     }
     ~ArcFaceIR50() {
+        frtdetail::autoUnlink(false, &m_link);
+        if (m_link) m_link->shutdown();  // the coalescer borrows this object's embedder and matcher
         frt_embedder_destroy(h_);
-        frt_pinned_free(m_out);
+    }
+    // Opt-in request coalescing (include/frt/coalesce.h): findFace() calls of concurrent request threads on `detector` share one device
+    // batch - detector, crop, recogniser, top-1 - and this object's forward() / featureMatching() / getOutputs() on the same thread, frame
+    // and boxes answer from what that batch computed.  maxFrames 0: the detector's maxBatchSize (construct both objects with room:
+    // detector maxBatchSize >= maxFrames, recogniser maxBatchSize >= maxFrames * maxFacesPerScene).  FRT_COALESCE=<frames>[:<window_us>]
+    // in the environment does all of this without a code change.
+    template <class Detector>
+    void coalesceWith(Detector &detector, int maxFrames = 0, int windowUs = 100) {
+        std::shared_ptr<frtdetail::CoalesceLink> l = frtdetail::makeLink(detector.handle(), h_, matmul.handle(), maxFrames, windowUs);
+        if (m_link) m_link->shutdown();
+        m_link = l;
+        detector.attachCoalescer(l);
     }
     ArcFaceIR50(const ArcFaceIR50 &) = delete;
     ArcFaceIR50 &operator=(const ArcFaceIR50 &) = delete;
@@ -118,13 +143,15 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     // src/arcface.cpp:166-187
     void forward(cv::Mat image, std::vector<struct Bbox> outputBbox) {
         const int n = (int)outputBbox.size();
-        croppedFaces.clear();
-        m_top_valid = false;
-        m_embeds.assign((size_t)std::max(n, 1) * m_OUTPUT_D, 0.f);
+        State &s = st();
+        s.croppedFaces.clear();
+        s.top_valid = s.from_record = false;
+        s.embeds.assign((size_t)std::max(n, 1) * m_OUTPUT_D, 0.f);
         if (!n) return;
+        if (forwardFromRecord(s, image, outputBbox)) return;  // a coalesced findFace() of this thread already computed everything
         std::vector<unsigned char> crops((size_t)n * m_INPUT_H * m_INPUT_W * 3);
         checkFrtStatus(frt_embedder_forward(h_, image.data, image.rows, image.cols, (size_t)image.step, reinterpret_cast<const frt_bbox *>(outputBbox.data()), n,
-                                            m_embeds.data(), crops.data()));
+                                            s.embeds.data(), crops.data()));
         for (int i = 0; i < n; ++i) {
             CroppedFace c;
             c.face = cv::Mat(m_INPUT_H, m_INPUT_W, CV_8UC3, &crops[(size_t)i * m_INPUT_H * m_INPUT_W * 3]).clone();
@@ -139,12 +166,13 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     // Optional alignment mode (no reference counterpart): forward() with the 5-point similarity warp instead of the bbox crop.
     void forwardAligned(cv::Mat image, std::vector<struct Bbox> outputBbox, const std::vector<std::array<float, 10>> &landmarks) {
         const int n = (int)landmarks.size();
-        croppedFaces.clear();
-        m_top_valid = false;
-        m_embeds.assign((size_t)std::max(n, 1) * m_OUTPUT_D, 0.f);
+        State &s = st();
+        s.croppedFaces.clear();
+        s.top_valid = s.from_record = false;
+        s.embeds.assign((size_t)std::max(n, 1) * m_OUTPUT_D, 0.f);
         if (!n) return;
         std::vector<unsigned char> crops((size_t)n * m_INPUT_H * m_INPUT_W * 3);
-        checkFrtStatus(frt_embedder_forward_aligned(h_, image.data, image.rows, image.cols, (size_t)image.step, landmarks[0].data(), n, m_embeds.data(),
+        checkFrtStatus(frt_embedder_forward_aligned(h_, image.data, image.rows, image.cols, (size_t)image.step, landmarks[0].data(), n, s.embeds.data(),
                                                     crops.data()));
         for (int i = 0; i < n; ++i) {
             CroppedFace c;
@@ -167,34 +195,41 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     // altogether for callers that, like src/app.cpp:309-310, only ever hand the pointer on to getOutputs (the buffer then holds
     // stale values; default: on, the reference's contract).
     float *featureMatching() {
-        if (classNames.size() > 0 && croppedFaces.size() > 0) {
-            const size_t n = croppedFaces.size();
-            const size_t need = n * (size_t)classCount * sizeof(float);
-            if (need > m_out_cap) {
-                frt_pinned_free(m_out);
-                m_out = nullptr;
-                m_out_cap = 0;
+        State &s = st();
+        if (classNames.size() > 0 && s.croppedFaces.size() > 0) {
+            const size_t n = s.croppedFaces.size();
+            const size_t need = std::max<size_t>(m_materialize ? n * (size_t)classCount * sizeof(float) : 0, sizeof(float));
+            if (need > s.out_cap) {
+                frt_pinned_free(s.out);
+                s.out = nullptr;
+                s.out_cap = 0;
                 void *p = nullptr;
                 checkFrtStatus(frt_pinned_alloc(need, matmul.device(), &p));
-                m_out = static_cast<float *>(p);
-                m_out_cap = need;
+                s.out = static_cast<float *>(p);
+                s.out_cap = need;
             }
-            m_top_idx.resize(n);
-            m_top_sim.resize(n);
-            m_top_valid = false;
-            matmul.calculateTop1(m_embeds.data(), (int)n, m_materialize ? m_out : nullptr, m_top_idx.data(), m_top_sim.data());
-            m_top_valid = true;
+            // coalesced request, matrix not wanted: the batch's match stage already holds this frame's first maxima
+            if (s.from_record && s.top_valid && !m_materialize) return s.out;
+            s.top_idx.resize(n);
+            s.top_sim.resize(n);
+            s.top_valid = false;
+            matmul.calculateTop1(s.embeds.data(), (int)n, m_materialize ? s.out : nullptr, s.top_idx.data(), s.top_sim.data());
+            s.top_valid = true;
         } else {
             throw "Feature matching: No faces in database or no faces found";
         }
-        return m_out;
+        return s.out;
     }
     void setMaterializeSimilarities(bool on) { m_materialize = on; }
     // src/arcface.cpp:203-217: first maximum per row (std::max_element), no threshold here
     std::tuple<std::vector<std::string>, std::vector<float>> getOutputs(float *output_sims) {
         std::vector<std::string> names;
         std::vector<float> sims;
-        bool fast = output_sims == m_out && m_top_valid && m_top_idx.size() == croppedFaces.size();  // the matrix featureMatching() just produced
+        State &s = st();
+        float *const m_out = s.out;
+        const std::vector<int> &m_top_idx = s.top_idx;
+        const std::vector<float> &m_top_sim = s.top_sim;
+        bool fast = output_sims == m_out && s.top_valid && m_top_idx.size() == croppedFaces.size();  // the matrix featureMatching() just produced
         // the device maxima are only a shortcut for LOCAL, in-range rows: "no row wins" (-1: a row of NaNs - std::max_element answers 0 there)
         // and indices shifted by a shard's row offset go through the host scan below (or answer row 0 when no matrix was materialised)
         for (size_t i = 0; fast && i < m_top_idx.size(); ++i)
@@ -225,11 +260,17 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     }
     // Extension: featureMatching + getOutputs fused on the device (no F x N matrix, no host scan).
     std::tuple<std::vector<std::string>, std::vector<float>> matchTop1() {
-        if (classNames.empty() || croppedFaces.empty()) throw "Feature matching: No faces in database or no faces found";
-        const int n = (int)croppedFaces.size();
+        State &s = st();
+        if (classNames.empty() || s.croppedFaces.empty()) throw "Feature matching: No faces in database or no faces found";
+        const int n = (int)s.croppedFaces.size();
         std::vector<int> idx((size_t)n);
         std::vector<float> sims((size_t)n);
-        matmul.top1(m_embeds.data(), n, idx.data(), sims.data());
+        if (s.from_record && s.top_valid && (int)s.top_idx.size() == n) {  // coalesced request: computed by the batch's match stage
+            idx = s.top_idx;
+            sims = s.top_sim;
+        } else {
+            matmul.top1(s.embeds.data(), n, idx.data(), sims.data());
+        }
         std::vector<std::string> names;
         for (int i = 0; i < n; ++i) {
             const int k = idx[(size_t)i];  // -1: no row won (NaN similarities); the reference's max_element answers element 0
@@ -253,25 +294,80 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
         (void)sims;
 #endif
     }
-    const float *embeddings() const { return m_embeds.data(); }
+    const float *embeddings() const { return st().embeds.data(); }
     frt_embedder *handle() { return h_; }
     MatMul &matcher() { return matmul; }
+    bool coalescing() const { return m_link && m_link->c; }
 
-    std::vector<struct CroppedFace> croppedFaces;
+  private:
+    // What a call leaves behind for the next call of the same request - per calling THREAD (include/frt/coalesce.h): the reference keeps
+    // it in the object and shares the object between its server's threads.
+    struct State {
+        std::vector<struct CroppedFace> croppedFaces;
+        std::vector<float> embeds;
+        float *out = nullptr;  // page-locked [F x N] similarity matrix (reused; the reference leaks new float[F*N] per call)
+        size_t out_cap = 0;
+        bool top_valid = false, from_record = false;
+        std::vector<int> top_idx;
+        std::vector<float> top_sim;
+        ~State() { frt_pinned_free(out); }
+    };
+    State &st() const { return frtdetail::perThread<State>(m_id); }
+    static std::vector<struct CroppedFace> &croppedFacesOf(const ArcFaceIR50 *o) { return o->st().croppedFaces; }
+
+  public:
+    // `std::vector<struct CroppedFace> croppedFaces` of the reference (src/arcface.h:37), one per calling thread
+    frtdetail::PerThreadVector<struct CroppedFace, ArcFaceIR50, &ArcFaceIR50::croppedFacesOf> croppedFaces;
     // static int classCount: inherited from ArcFaceIR50Statics<> above (src/arcface.h:39, arcface.cpp:19)
 
   private:
+    // forward() of a frame this thread's coalesced findFace() has just analysed: same frame bytes (pointer, size, sampled fingerprint),
+    // same boxes, every ROI non-empty -> embeddings, crops and first maxima come from the record
+    bool forwardFromRecord(State &s, const cv::Mat &image, const std::vector<struct Bbox> &boxes) {
+        if (!m_link) return false;
+        frtdetail::FrameRecord &fr = frtdetail::frameRecord();
+        const size_t n = boxes.size();
+        if (fr.link != m_link.get() || fr.data != image.data || fr.rows != image.rows || fr.cols != image.cols || fr.boxes.size() != n ||
+            m_INPUT_H != 112 || m_INPUT_W != 112 || m_OUTPUT_D != 512)
+            return false;
+        for (size_t i = 0; i < n; ++i)
+            if (std::memcmp(&fr.boxes[i], &boxes[i], sizeof(Bbox)) != 0 || !fr.res[i].valid) return false;
+        if (fr.print != frtdetail::framePrint(image.data, image.rows, image.cols, (size_t)image.step)) return false;
+        s.embeds.assign(fr.embeds.begin(), fr.embeds.begin() + (long)(n * 512));
+        bool matched = true;
+        s.top_idx.resize(n);
+        s.top_sim.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            CroppedFace c;
+            c.face = cv::Mat(112, 112, CV_8UC3, &fr.crops[i * 112 * 112 * 3]).clone();
+            // faceMat = the recogniser's input tensor as preprocessFace() leaves it (src/arcface.cpp:105-114): planar RGB, (x - 127.5) / 128 -
+            // both steps are exact in binary floating point, so this host loop IS the device kernel's output, bit for bit
+            c.faceMat = cv::Mat(3 * 112, 112, CV_32FC1);
+            float *t = c.faceMat.ptr<float>(0);
+            const unsigned char *px = c.face.data;
+            for (int k = 0; k < 112 * 112; ++k)
+                for (int ch = 0; ch < 3; ++ch) t[ch * 112 * 112 + k] = ((float)px[k * 3 + (2 - ch)] - 127.5f) * 0.0078125f;
+            c.x1 = boxes[i].x1;
+            c.y1 = boxes[i].y1;
+            c.x2 = boxes[i].x2;
+            c.y2 = boxes[i].y2;
+            s.croppedFaces.push_back(c);
+            s.top_idx[i] = fr.res[i].match_idx;
+            s.top_sim[i] = fr.res[i].match_sim;
+            if (fr.res[i].match_idx < 0) matched = false;  // the batch ran without a gallery
+        }
+        s.from_record = true;
+        s.top_valid = matched;
+        return true;
+    }
     frt_embedder *h_;
+    uint64_t m_id;
     int m_frameWidth, m_frameHeight, m_INPUT_C, m_INPUT_H, m_INPUT_W, m_OUTPUT_D, m_maxBatchSize, m_maxFacesPerScene;
     float m_knownPersonThresh;
-    std::vector<float> m_embeds;
-    float *m_out = nullptr;  // page-locked [F x N] similarity matrix (object-owned, reused; the reference leaks new float[F*N] per call)
-    size_t m_out_cap = 0;
-    bool m_materialize = true, m_top_valid = false;
-    std::vector<int> m_top_idx;
-    std::vector<float> m_top_sim;
+    bool m_materialize = true;
     std::vector<std::string> classNames;
     MatMul matmul;
+    std::shared_ptr<frtdetail::CoalesceLink> m_link;
 };
 
 #endif  // FRT_ARCFACE_H

@@ -4,9 +4,12 @@
 #ifndef FRT_RETINAFACE_H
 #define FRT_RETINAFACE_H
 
+#include <algorithm>
 #include <array>
 #include <cassert>
+#include <cstring>
 
+#include "coalesce.h"
 #include "common.h"
 #include "cvlite.h"
 
@@ -23,21 +26,66 @@ class RetinaFace {
     RetinaFace(TRTLogger gLogger, const std::string engineFile, int frameWidth, int frameHeight, std::string inputName,
                std::vector<std::string> outputNames, std::vector<int> inputShape, int maxBatchSize, int maxFacesPerScene,
                float nms_threshold, float bbox_threshold, int device = 0)
-        : h_(nullptr), m_maxFacesPerScene(maxFacesPerScene), m_maxBatchSize(maxBatchSize) {
+        : h_(nullptr), m_maxFacesPerScene(maxFacesPerScene), m_maxBatchSize(maxBatchSize), m_frameWidth(frameWidth), m_frameHeight(frameHeight) {
         (void)gLogger;
         (void)inputName;
         assert(inputShape.size() == 3);   // src/retinaface.cpp:8
         assert(outputNames.size() == 2);  // src/retinaface.cpp:86
+        const int envFrames = frtdetail::coalesceEnv().frames;  // FRT_COALESCE=<frames>: room for a coalesced batch (include/frt/coalesce.h)
+        const int devBatch = std::max(maxBatchSize, envFrames);
         checkFrtStatus(frt_detector_create(engineFile.c_str(), frameWidth, frameHeight, inputShape[0], inputShape[1], inputShape[2],
-                                           maxBatchSize, maxFacesPerScene, nms_threshold, bbox_threshold, device, &h_));
+                                           devBatch, maxFacesPerScene, nms_threshold, bbox_threshold, device, &h_));
         std::cout << "[INFO] Loading RetinaFace Engine...\n";
+        if (envFrames > 0) {
+            try {
+                frtdetail::autoLink(true, frtdetail::Pending{device, frameWidth, frameHeight, devBatch, h_, nullptr, nullptr, &m_link});
+            } catch (...) {
+                frt_detector_destroy(h_);
+                throw;
+            }
+        }
     }
-    ~RetinaFace() { frt_detector_destroy(h_); }
+    ~RetinaFace() {
+        frtdetail::autoUnlink(true, &m_link);
+        if (m_link) m_link->shutdown();  // the coalescer borrows this object's detector
+        frt_detector_destroy(h_);
+    }
+    // set by ArcFaceIR50::coalesceWith(detector)
+    void attachCoalescer(const std::shared_ptr<frtdetail::CoalesceLink> &l) {
+        if (m_link && m_link != l) m_link->shutdown();
+        m_link = l;
+    }
+    bool coalescing() const { return m_link && m_link->c; }
+    // batches submitted / frames carried by the coalescer so far (frames / batches = the batch size the load produced)
+    bool coalesceStats(long &batches, long &frames) const {
+        batches = frames = 0;
+        return m_link && m_link->c && frt_coalescer_stats(m_link->c, &batches, &frames) == FRT_OK;
+    }
     RetinaFace(const RetinaFace &) = delete;
     RetinaFace &operator=(const RetinaFace &) = delete;
 
     // src/retinaface.cpp:147-152.  img must be CV_8UC3 of frameWidth x frameHeight (the caller resizes, src/app.cpp:301).
     std::vector<struct Bbox> findFace(cv::Mat &img) {
+        if (m_link && m_link->c && img.rows == m_frameHeight && img.cols == m_frameWidth) {
+            // coalesced: this frame joins the batch that the requests being served right now form together; the batch runs detector, crop,
+            // recogniser and top-1 in one device pass and this thread keeps its frame's share for forward() / featureMatching()
+            frtdetail::FrameRecord &fr = frtdetail::frameRecord();
+            const size_t K = (size_t)m_maxFacesPerScene;
+            fr.link = nullptr;
+            fr.res.resize(K);
+            fr.embeds.resize(K * 512);
+            fr.crops.resize(K * 112 * 112 * 3);
+            int n = 0;
+            checkFrtStatus(frt_coalescer_infer_crops(m_link->c, img.data, img.rows, img.cols, (size_t)img.step, fr.res.data(), fr.embeds.data(), fr.crops.data(), &n));
+            fr.boxes.resize((size_t)n);
+            for (int i = 0; i < n; ++i) std::memcpy(&fr.boxes[(size_t)i], &fr.res[(size_t)i].box, sizeof(Bbox));
+            fr.data = img.data;
+            fr.rows = img.rows;
+            fr.cols = img.cols;
+            fr.print = frtdetail::framePrint(img.data, img.rows, img.cols, (size_t)img.step);
+            fr.link = m_link.get();
+            return fr.boxes;
+        }
         std::vector<struct Bbox> out((size_t)m_maxFacesPerScene);
         int n = 0;
         checkFrtStatus(frt_detector_find_faces(h_, img.data, img.rows, img.cols, (size_t)img.step, reinterpret_cast<frt_bbox *>(out.data()), &n));
@@ -80,7 +128,8 @@ class RetinaFace {
 
   private:
     frt_detector *h_;
-    int m_maxFacesPerScene, m_maxBatchSize;
+    int m_maxFacesPerScene, m_maxBatchSize, m_frameWidth, m_frameHeight;
+    std::shared_ptr<frtdetail::CoalesceLink> m_link;
 };
 
 #endif  // FRT_RETINAFACE_H

@@ -6,6 +6,10 @@
 // loop with the fused matchTop1() extension.  T threads model Crow's multithreaded server (src/app.cpp:367); every thread owns its
 // objects (the reference's classes are not thread-safe), on the device `devices[t % n]` - the one-process / several-devices shape.
 //   dropin_bench <det.frtw> <rec.frtw> <frames.bin (u8 BGR [n][rows][cols][3])> <n_frames> <rows> <cols> <gallery rows N> <threads> <iters> <devices e.g. 0,0,1>
+//                [shared|own] [coalesce frames] [window us]
+// "shared": ONE detector and ONE recogniser (one gallery on the device) used by all T threads - the reference's own shape (its handlers
+// capture the two global objects by reference, src/app.cpp:52-57,243,293); the shells keep every call's results per calling thread.
+// coalesce frames > 0 (shared only): recognizer.coalesceWith(detector, frames, window) - concurrent requests share one device batch.
 // Prints one JSON line.
 #include <chrono>
 #include <cmath>
@@ -27,7 +31,7 @@ struct Stat {
 };
 
 int main(int argc, char **argv) {
-    if (argc != 11) {
+    if (argc < 11 || argc > 14) {
         std::fprintf(stderr, "usage: see the header comment\n");
         return 2;
     }
@@ -40,6 +44,10 @@ int main(int argc, char **argv) {
         if (*p == ',') ++p;
     }
     if (devices.empty() || T < 1 || n_frames < 1) return 2;
+    const bool shared = argc > 11 && std::string(argv[11]) == "shared";
+    const int co_frames = argc > 12 ? std::atoi(argv[12]) : 0, co_window = argc > 13 ? std::atoi(argv[13]) : 100;
+    if (co_frames > 0 && !shared) return 2;
+    const int n_sets = shared ? 1 : T;
     std::ifstream f(argv[3], std::ios::binary);
     std::vector<unsigned char> fb((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     if (fb.size() < (size_t)n_frames * rows * cols * 3) return 2;
@@ -71,14 +79,15 @@ int main(int argc, char **argv) {
         RetinaFace *det;
         ArcFaceIR50 *rec;
     };
-    std::vector<Objs> objs((size_t)T);
+    std::vector<Objs> objs((size_t)n_sets);
     // construction as in src/app.cpp:52-57 and gallery load as in src/db.cpp:316-346, one set of objects per thread.  Sequential: the
     // reference's `static int classCount` (src/arcface.h:39) is process-wide, so every instance is loaded from a count of zero and all
     // of them end up agreeing on classCount == N.
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < n_sets; ++t) {
         const int dev = devices[(size_t)t % devices.size()];
-        objs[(size_t)t].det = new RetinaFace(gLogger, argv[1], cols, rows, "input_det", {"output_det0", "output_det1"}, {3, rows, cols}, 1, 4, 0.4f, 0.6f, dev);
-        objs[(size_t)t].rec = new ArcFaceIR50(gLogger, argv[2], cols, rows, "input", "output", {3, 112, 112}, 512, 4, 4, 0.65f, dev);
+        const int det_batch = co_frames > 0 ? co_frames : 1, rec_batch = co_frames > 0 ? 4 * co_frames : 4;
+        objs[(size_t)t].det = new RetinaFace(gLogger, argv[1], cols, rows, "input_det", {"output_det0", "output_det1"}, {3, rows, cols}, det_batch, 4, 0.4f, 0.6f, dev);
+        objs[(size_t)t].rec = new ArcFaceIR50(gLogger, argv[2], cols, rows, "input", "output", {3, 112, 112}, 512, rec_batch, 4, 0.65f, dev);
         const Clock::time_point t0 = Clock::now();
         ArcFaceIR50 &rec = *objs[(size_t)t].rec;
         ArcFaceIR50::classCount = 0;
@@ -86,6 +95,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < N; ++i) rec.addEmbedding(std::string(), &gal[(size_t)i * 512]);
         rec.initMatMul();
         load_ms[(size_t)t] = ms_since(t0);
+        if (co_frames > 0) rec.coalesceWith(*objs[(size_t)t].det, co_frames, co_window);
     }
     // mode 0: featureMatching + getOutputs with the matrix materialised (the reference's contract); 1: same calls, matrix not
     // materialised (setMaterializeSimilarities(false)); 2: matchTop1 extension
@@ -93,13 +103,13 @@ int main(int argc, char **argv) {
     std::vector<Stat> res[3];
     for (int mode = 0; mode < 3; ++mode) {
         st.assign((size_t)T, Stat());
+        for (Objs &o : objs) o.rec->setMaterializeSimilarities(mode == 0);
         const Clock::time_point w0 = Clock::now();
         std::vector<std::thread> th;
         for (int t = 0; t < T; ++t)
             th.emplace_back([&, t, mode] {
-                RetinaFace &detector = *objs[(size_t)t].det;
-                ArcFaceIR50 &recognizer = *objs[(size_t)t].rec;
-                recognizer.setMaterializeSimilarities(mode == 0);
+                RetinaFace &detector = *objs[shared ? 0 : (size_t)t].det;
+                ArcFaceIR50 &recognizer = *objs[shared ? 0 : (size_t)t].rec;
                 Stat &s = st[(size_t)t];
                 std::vector<std::string> names;
                 std::vector<float> sims;
@@ -138,8 +148,13 @@ int main(int argc, char **argv) {
         wall[mode] = ms_since(w0);
         res[mode] = st;
     }
-    std::printf("{\"gallery_rows\": %d, \"threads\": %d, \"devices\": \"%s\", \"iters_per_thread\": %d, \"gallery_load_ms_per_thread\": %.1f, \"fastpath_mismatches\": %d",
-                N, T, argv[10], iters, load_ms[0], mismatch[0]);
+    int mism = 0;
+    for (int v : mismatch) mism += v;
+    long co_b = 0, co_f = 0;
+    objs[0].det->coalesceStats(co_b, co_f);
+    std::printf("{\"gallery_rows\": %d, \"threads\": %d, \"devices\": \"%s\", \"objects\": \"%s\", \"coalesce_frames\": %d, \"coalesce_window_us\": %d, "
+                "\"coalesced_batches\": %ld, \"coalesced_frames\": %ld, \"iters_per_thread\": %d, \"gallery_load_ms_per_thread\": %.1f, \"fastpath_mismatches\": %d",
+                N, T, argv[10], shared ? "shared" : "one set per thread", co_frames, co_window, co_b, co_f, iters, load_ms[0], mism);
     const char *tag[3] = {"featureMatching_getOutputs", "featureMatching_getOutputs_no_matrix", "matchTop1"};
     for (int mode = 0; mode < 3; ++mode) {
         Stat a;
@@ -162,5 +177,5 @@ int main(int argc, char **argv) {
         delete o.det;
         delete o.rec;
     }
-    return mismatch[0] ? 3 : 0;
+    return mism ? 3 : 0;
 }

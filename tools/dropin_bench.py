@@ -26,9 +26,11 @@ def build(outdir):
     return exe
 
 
-def run(exe, dpath, rpath, frames_path, n_frames, H, W, gallery, threads, iters, devices="0"):
-    out = subprocess.run([exe, dpath, rpath, frames_path, str(n_frames), str(H), str(W), str(gallery), str(threads), str(iters), devices],
-                         capture_output=True, text=True, timeout=3000)
+def run(exe, dpath, rpath, frames_path, n_frames, H, W, gallery, threads, iters, devices="0", shared=False, coalesce=0, window_us=100):
+    cmd = [exe, dpath, rpath, frames_path, str(n_frames), str(H), str(W), str(gallery), str(threads), str(iters), devices]
+    if shared or coalesce:
+        cmd += ["shared", str(coalesce), str(window_us)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=3000)
     if out.returncode != 0:
         raise RuntimeError("dropin_bench failed (%d): %s %s" % (out.returncode, out.stdout[-2000:], out.stderr[-2000:]))
     return json.loads(next(l for l in out.stdout.splitlines() if l.startswith("{")))
@@ -42,6 +44,9 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--devices", default="0")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--shared", action="store_true", help="one detector + one recogniser shared by all threads (the reference's shape)")
+    ap.add_argument("--coalesce", type=int, default=0, help="recognizer.coalesceWith(detector, N frames) (implies --shared)")
+    ap.add_argument("--window-us", type=int, default=100)
     args = ap.parse_args()
     import __graft_entry__ as entry
     frt = entry.load_pkg()
@@ -57,7 +62,7 @@ def main():
     report = {"what": "src/app.cpp:304-310 through the drop-in shells, one 640x640 frame per call, K = 4 faces per frame, %d-row fp32 gallery" % args.gallery,
               "runs": []}
     for t in args.threads:
-        r = run(exe, dpath, rpath, fpath, args.frames, H, W, args.gallery, t, args.iters, args.devices)
+        r = run(exe, dpath, rpath, fpath, args.frames, H, W, args.gallery, t, args.iters, args.devices, args.shared, args.coalesce, args.window_us)
         report["runs"].append(r)
         print(json.dumps(r), flush=True)
     if args.out:
