@@ -208,6 +208,8 @@ bool conv_s2_se_fused(const ConvMfmaArgs &a);  // IR-SE tail in the stride-2 str
 const char *conv_s2_label(const ConvMfmaArgs &a);
 bool conv_small_applies(const ConvMfmaArgs &a);              // kernels_arc_small.hip: 3x3 convs of a small batch (few pixel tiles)
 bool launch_conv_small(const ConvMfmaArgs &a, hipStream_t s);
+bool conv_ks_applies(const ConvMfmaArgs &a);                 // kernels_arc_ks.hip: 3x3 stride 1 at 14x14x256 / 7x7x512, medium batches (K split over the waves)
+bool launch_conv_ks(const ConvMfmaArgs &a, hipStream_t s);
 bool conv64_applies(const ConvMfmaArgs &a);                 // kernels_arc_c64.hip: Cin = Cout = 64, 3x3, stride 1
 bool launch_conv64(const ConvMfmaArgs &a, hipStream_t s);
 const char *conv_kernel_label(const ConvMfmaArgs &a);  // kernel symbol (as rocprofv3 prints it) a launch resolves to

@@ -1069,6 +1069,7 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
                                   "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3>",
                                   "conv_patch_kernel<5, 1, 5, false, 0, false, 2, 1, 3>", "conv_patch_kernel<5, 1, 5, false, 0, false, 1, 1, 3>"};
     if (conv_small_applies(a)) return a.mode == EPI_BN_ADD_BN && a.scx ? "conv_small_kernel<true>" : "conv_small_kernel<false>";
+    if (conv_ks_applies(a)) return "conv_ks_kernel";
     if (const char *l2 = conv_s2_label(a)) return l2;
     if (conv64_applies(a))
         return a.mode == EPI_PRELU ? "conv64_kernel<0, 0>" : (a.mode == EPI_BN ? "conv64_kernel<1, 0>" : "conv64_kernel<2, 0>");
@@ -1112,7 +1113,7 @@ static bool se_fused_fits_device() {
 bool conv_se_fused(const ConvMfmaArgs &a0) {
     ConvMfmaArgs a = a0;
     a.mode = EPI_BN_ADD_BN;  // same eligibility as the plain unit tail (shortcut with the output's geometry)
-    if (!a.se_pool || !a.sc || !a.out1 || conv_small_applies(a) || conv64_applies(a)) return false;
+    if (!a.se_pool || !a.sc || !a.out1 || conv_small_applies(a) || conv_ks_applies(a) || conv64_applies(a)) return false;
     if (!se_fused_fits_device()) return false;
     if (conv_s2_applies(a)) return conv_s2_se_fused(a);
     int R = 0, n_img = 0;
@@ -1124,6 +1125,7 @@ bool conv_se_fused(const ConvMfmaArgs &a0) {
 
 void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
     if (launch_conv_small(a, s)) return;  // a small batch's few pixel tiles: one (32 couts x 32 pixels) unit per workgroup (kernels_arc_small.hip)
+    if (launch_conv_ks(a, s)) return;     // medium batches at 14x14x256 / 7x7x512: one 32-cout block x a strip, K split over the waves (kernels_arc_ks.hip)
     if (launch_conv64(a, s)) return;  // dedicated 64 -> 64 stride-1 kernel (kernels_arc_c64.hip)
     if (launch_conv_s2(a, s)) return;  // stride-2 strip kernel on de-interleaved phase planes (kernels_arc_s2.hip)
     int R = 0, n_img = 0;
