@@ -82,19 +82,26 @@ def test_forward_crops_and_embeds_like_the_oracle(frt, orc, synth, blobs):
 
 
 def test_batch_of_128_equals_small_batches(frt, synth, blobs):
-    """Benchmark batch (128 faces) vs the same faces in batches of 32: identical embeddings (strip walks of the persistent conv
-    kernels, grid-dependent tile variants and the split-K linear must be batch-size independent per face).  Batches of 8 take the
-    small-batch kernel (kernels_arc_small.hip) for most layers - another fp32 summation order, so fp16 roundings of activations flip:
-    as close to the 128-face result as either is to the fp32 oracle."""
+    """Benchmark batch (128 faces) vs the same faces in batches of 64: identical embeddings (strip walks of the persistent conv
+    kernels, grid-dependent tile variants and the split-K linear must be batch-size independent per face).  Batches of 32 take the
+    medium-batch kernel (kernels_arc_ks.hip) and batches of 8 the small-batch kernel (kernels_arc_small.hip) for most layers - K split
+    over the waves, another fp32 summation order, so fp16 roundings of activations flip: as close to the 128-face result as either is
+    to the fp32 oracle."""
     path, _ = blobs("ir")
     big = frt.ArcFaceIR50(path, maxBatchSize=128)
-    mid = frt.ArcFaceIR50(path, maxBatchSize=32)
+    mid = frt.ArcFaceIR50(path, maxBatchSize=64)
+    med = frt.ArcFaceIR50(path, maxBatchSize=32)
     small = frt.ArcFaceIR50(path, maxBatchSize=8)
     x = np.random.default_rng(11).standard_normal((128, 3, 112, 112)).astype(np.float32) * 0.5
     e = big.doInference(x)
-    for f0 in (0, 32, 96):
-        em = mid.doInference(x[f0:f0 + 32])
-        assert np.abs(e[f0:f0 + 32] - em).max() < 2e-6, (f0, np.abs(e[f0:f0 + 32] - em).max())
+    for f0 in (0, 64):
+        em = mid.doInference(x[f0:f0 + 64])
+        assert np.abs(e[f0:f0 + 64] - em).max() < 2e-6, (f0, np.abs(e[f0:f0 + 64] - em).max())
+    for f0 in (0, 96):
+        em = med.doInference(x[f0:f0 + 32])
+        assert (e[f0:f0 + 32] * em).sum(1).min() > 1 - 1e-5 and np.abs(e[f0:f0 + 32] - em).max() < 1e-3, f0
+        assert np.array_equal(med.doInference(x[f0 + 5:f0 + 32])[:20], em[5:25])  # position / batch size inside the class: bit for bit
+    med.close()
     for f0 in (0, 40, 120):
         es = small.doInference(x[f0:f0 + 8])
         assert (e[f0:f0 + 8] * es).sum(1).min() > 1 - 1e-5 and np.abs(e[f0:f0 + 8] - es).max() < 1e-3, f0
@@ -123,6 +130,28 @@ def test_small_batches_match_the_oracle(frt, synth, blobs, mode):
 
 
 @pytest.mark.parametrize("mode", ["ir", "ir_se"])
+def test_medium_batches_match_the_oracle(frt, synth, blobs, mode):
+    """16, 24 and 40 faces per pass take the medium-batch kernel (kernels_arc_ks.hip: one 32-cout block x a strip per workgroup, K split
+    over the four waves; half-image strips up to 20 faces, whole-image strips above, 7x7 images whole), 9 / 10 sit on the boundary to the
+    small-batch kernel, 41 / 48 on the boundary back to the strip kernels: against the fp32 oracle (model_irse.py:48-66, 139-156), and the
+    same face must embed bit for bit wherever it sits in a batch of its class."""
+    from oracle import nets
+    path, sd = blobs(mode)
+    x = np.random.default_rng(29).standard_normal((48, 3, 112, 112)).astype(np.float32) * 0.5
+    want = nets.arcface_forward(sd, x[:10])
+    for F in (9, 10, 16, 24, 40, 41, 48):
+        rec = frt.ArcFaceIR50(path, maxBatchSize=F)
+        e = rec.doInference(x[:F])
+        e2 = rec.doInference(np.concatenate([x[F - 4:F], x[:F - 4]]))
+        rec.close()
+        assert np.isfinite(e).all()
+        n = min(F, 10)
+        assert (e[:n] * want[:n]).sum(1).min() > 1 - COS_TOL, (mode, F)
+        assert np.abs(e[:n] - want[:n]).max() < 2e-3, (mode, F)
+        assert np.array_equal(e2[4:], e[:F - 4]) and np.array_equal(e2[:4], e[F - 4:]), (mode, F)
+
+
+@pytest.mark.parametrize("mode", ["ir", "ir_se"])
 def test_every_batch_size_class_embeds_alike(frt, synth, blobs, mode):
     """The strip heights, images per strip and (IR-SE) which units run the SE tail inside conv2's epilogue all follow the batch size;
     odd batch sizes leave a last strip with a single image.  The same faces must embed alike (fp16 rounding flips only) whatever
@@ -132,7 +161,7 @@ def test_every_batch_size_class_embeds_alike(frt, synth, blobs, mode):
     ref = frt.ArcFaceIR50(path, maxBatchSize=8)
     want = np.concatenate([ref.doInference(x[i:i + 8]) for i in (0, 24, 92)])  # faces 0-7, 24-31, 92-99
     ref.close()
-    for F in (1, 3, 16, 33, 64, 100):
+    for F in (1, 3, 12, 16, 21, 33, 40, 64, 100):
         rec = frt.ArcFaceIR50(path, maxBatchSize=F)
         e = rec.doInference(x[:F])
         rec.close()
