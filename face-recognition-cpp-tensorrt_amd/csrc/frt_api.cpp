@@ -1009,6 +1009,9 @@ struct frt_matcher {
     // screened top-1 (fp16 shadow gallery; see kernels_match.hip).  Off for small galleries, for widths the coarse kernel is not
     // instantiated for (anything but 64 / 128 / 256 / 512) and with FRT_MATCH_SCREEN=0.
     half_t *d_g16 = nullptr;   // fp16 shadow of d_gallery, or the fp16-STORED gallery itself
+    uint8_t *d_g8 = nullptr;   // int8 shadow of d_gallery (round 4: fp32-stored galleries with 512 columns take this instead of the fp16 shadow)
+    float *d_g8_scale = nullptr;
+    float gerr = 0.f;          // largest quantisation error norm of the int8 rows (part of the screening bound)
     bool store16 = false;      // current gallery is fp16-stored
     bool want16 = false;       // storage mode of the NEXT init / gallery_begin (frt_matcher_set_storage)
     float gmax_norm = 0.f;
@@ -1138,6 +1141,11 @@ struct frt_matcher {
         if (busy) HIPCHK(hipEventSynchronize(ev_busy));
         float *old32 = d_gallery;
         half_t *old16 = d_g16;
+        if (d_g8) (void)hipFree(d_g8);  // (the streams were synchronised above: no scan is reading it)
+        if (d_g8_scale) (void)hipFree(d_g8_scale);
+        d_g8 = nullptr;
+        d_g8_scale = nullptr;
+        gerr = 0.f;
         ++generation;
         N = ld.rows;
         D = ld.D;
@@ -1160,19 +1168,33 @@ struct frt_matcher {
         if (N > 0 && (screen || store16)) {  // fp16 shadow copy (fp32 storage) + the largest row norm (rounding bound of the screening pass)
             int *d_bits = nullptr;
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_bits), sizeof(int)));
+            // fp32-stored galleries of 512 columns are screened through an INT8 shadow (half the bytes of the per-call scan; kernels_match.hip);
+            // FRT_MATCH_I8=0 / FRT_MATCH_FAST=0 keep the fp16 shadow (A/B measurements, the round-2 tile-list path)
+            const char *i8_env = getenv("FRT_MATCH_I8"), *fast_env = getenv("FRT_MATCH_FAST");
+            const bool use_i8 = screen && !store16 && D == 512 && !(i8_env && i8_env[0] == '0') && !(fast_env && fast_env[0] == '0');
+            int *d_ebits = nullptr;
             if (store16) {
                 launch_gallery_norm16(d_g16, N, D, d_bits, stream);
+            } else if (use_i8) {
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_ebits), sizeof(int)));
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_g8), gallery8_bytes(N, D)));
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_g8_scale), ((size_t)(N + 127) / 128) * 128 * sizeof(float)));
+                launch_gallery_shadow8(d_gallery, N, D, d_g8, d_g8_scale, d_ebits, d_bits, stream);
             } else {
                 HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_g16), gallery16_elems(N, D) * sizeof(half_t)));
                 launch_gallery_shadow(d_gallery, N, D, d_g16, d_bits, stream);
             }
-            int bits = 0;
+            int bits = 0, ebits = 0;
             HIPCHK(hipMemcpyAsync(&bits, d_bits, sizeof(int), hipMemcpyDeviceToHost, stream));
+            if (d_ebits) HIPCHK(hipMemcpyAsync(&ebits, d_ebits, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             (void)hipFree(d_bits);
-            float n2;
+            if (d_ebits) (void)hipFree(d_ebits);
+            float n2, e2;
             std::memcpy(&n2, &bits, 4);
+            std::memcpy(&e2, &ebits, 4);
             gmax_norm = std::sqrt(n2);
+            gerr = std::sqrt(e2);
         }
         q_cap = 0;  // partial scratch depends on `blocks`
         if (d_partial) {
@@ -1223,8 +1245,13 @@ struct frt_matcher {
     void top1_dev(const float *queries_dev, int F, int32_t *idx_dev, float *sim_dev, hipStream_t s) {
         ProfScope ps(2, "match_top1", 2.0 * D * (double)N * F, s);
         // the partial scratch is [blocks][F]
-        if (screen)  // (d_gallery == nullptr with fp16 storage: the exact re-rank then reads the stored fp16 rows)
-            launch_match_top1_screened(d_gallery, d_g16, N, D, queries_dev, F, gmax_norm, scr, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
+        if (screen) {  // (d_gallery == nullptr with fp16 storage: the exact re-rank then reads the stored fp16 rows)
+            ScreenScratch w = scr;
+            w.g8 = d_g8;
+            w.g8_scale = d_g8_scale;
+            w.gerr = gerr;
+            launch_match_top1_screened(d_gallery, d_g16, N, D, queries_dev, F, gmax_norm, w, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
+        }
         else if (store16)
             launch_match_top1_h(d_g16, N, D, queries_dev, F, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
         else
@@ -1234,7 +1261,11 @@ struct frt_matcher {
     // exact top-k lists [F][k] (idx_dev / sim_dev device pointers); queries fp32 on the device
     void topk_dev(const float *queries_dev, int F, int k, int32_t *idx_dev, float *sim_dev, hipStream_t s) {
         ProfScope ps(2, "match_topk", 2.0 * D * (double)N * F, s);
-        launch_match_topk(d_gallery, d_g16, N, D, queries_dev, F, k, screen, gmax_norm, scr, d_kth, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
+        ScreenScratch w = scr;
+        w.g8 = d_g8;
+        w.g8_scale = d_g8_scale;
+        w.gerr = gerr;
+        launch_match_topk(d_gallery, d_g16, N, D, queries_dev, F, k, screen, gmax_norm, w, d_kth, d_partial, blocks, idx_dev, sim_dev, row_offset, s);
         HIPCHK(hipGetLastError());
     }
 };
@@ -2115,7 +2146,8 @@ void frt_matcher_destroy(frt_matcher *m) {
         (void)hipStreamDestroy(m->stream);
     }
     if (m->ev_busy) (void)hipEventDestroy(m->ev_busy);
-    for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full, (void *)m->d_g16, (void *)m->d_kth})
+    for (void *p : {(void *)m->d_gallery, (void *)m->d_q, (void *)m->d_sim, (void *)m->d_idx, (void *)m->d_partial, (void *)m->d_full, (void *)m->d_g16, (void *)m->d_kth,
+                    (void *)m->d_g8, (void *)m->d_g8_scale})
         if (p) (void)hipFree(p);
     m->free_screen_scratch();
     delete m;

@@ -58,7 +58,14 @@ struct ScreenScratch {
     int pair_cap;
     int *ctl;                     // [4]: pair count, overflow flag
     unsigned long long *qkey;     // [F] packed (similarity, ~row) winners of the scalar re-rank
+    // int8 shadow gallery (round 4; fast path, D = 512, fp32-stored galleries): null -> the fp16 shadow is scanned
+    const uint8_t *g8;            // fragment-ordered biased bytes (value + 128), gallery8_bytes(N, D)
+    const float *g8_scale;        // [tiles * 128] per-row scale (row = scale * int8 row + error)
+    float gerr;                   // max over rows of || row - scale * int8 row ||
 };
+size_t gallery8_bytes(int N, int D);
+// fp32 rows -> int8 shadow (+ per-row scales, largest quantisation error norm^2 and largest row norm^2 as float bit patterns, atomicMax)
+void launch_gallery_shadow8(const float *gallery, int N, int D, uint8_t *g8, float *scale, int *max_err2_bits, int *max_norm2_bits, hipStream_t s);
 void launch_gallery_shadow(const float *gallery, int N, int D, half_t *g16, int *max_norm2_bits, hipStream_t s);
 void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, int D, const float *queries, int F, float gmax_norm,
                                 const ScreenScratch &w, MatchPartial *partial, int partial_blocks, int32_t *idx_out, float *sim_out,

@@ -439,6 +439,195 @@ __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restr
     }
 }
 
+// ---------------------------------------------------------------- int8 shadow gallery (round 4)
+// The coarse scan is HBM-bound: one pass over the shadow gallery per call, whatever the number of queries (1.02 GB as fp16 at N = 1M:
+// 0.20 - 0.24 ms of a 3.2 ms step, and 0.20 of a 0.80 ms four-frame step).  The screening only needs a similarity that is within a KNOWN
+// distance of the exact one, so the shadow can be coarser than fp16 as long as its error is bounded: rows are stored as int8 with a
+// per-row scale, row = scale * q8 + e, and the largest error norm E = max_r ||e_r|| is measured when the shadow is built.  Then
+//   |S~ - S| <= ||q16 - q|| * ||g|| + ||q16|| * ||e|| + accumulation  <=  ||q|| * (0.7e-3 * max||g|| + 1.02 * E)
+// (Cauchy-Schwarz; the query is still rounded to fp16, the products q16 * q8 are exact in fp32).  For unit-norm 512-d rows E is ~ 0.01, the
+// band 2 * delta ~ 0.02 keeps a handful of tiles per query, and the exact pair re-rank behind it is unchanged - so are the results, bit
+// for bit.  Half the bytes: 0.51 GB per scan.  The matrix cores still run fp16 x fp16: the bytes are widened in registers - a byte u =
+// q8 + 128 becomes the fp16 bit pattern 0x6400 | u = 1024 + u (one v_perm_b32 per two values), minus 1152 (one v_pk_add_f16 per two).
+// Layout: [128-row tile][32-row wave block][32-wide k pair][lane = (k half, row)][16 bytes = k-step 2p, k-step 2p + 1]: every load of a
+// wave is one contiguous kilobyte covering two MFMA k-steps.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half8 i8x8_to_half8(unsigned d0, unsigned d1) {
+    union {
+        unsigned u[4];
+        half2_t h[4];
+        half8 v;
+    } x;
+    x.u[0] = __builtin_amdgcn_perm(0x64646464u, d0, 0x04010400u);
+    x.u[1] = __builtin_amdgcn_perm(0x64646464u, d0, 0x04030402u);
+    x.u[2] = __builtin_amdgcn_perm(0x64646464u, d1, 0x04010400u);
+    x.u[3] = __builtin_amdgcn_perm(0x64646464u, d1, 0x04030402u);
+    const half2_t bias = {(_Float16)-1152.0f, (_Float16)-1152.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x.h[i] = x.h[i] + bias;
+    return x.v;
+}
+
+// one wave per gallery row (D = 512: 8 values per lane): scale = max|g| / 127, q = rint(g / scale), error norm^2 and row norm^2 -> atomicMax
+__global__ __launch_bounds__(256) void gallery_to_i8_kernel(const float *__restrict__ in, int N, uint8_t *__restrict__ out, float *__restrict__ scale,
+                                                            int *__restrict__ max_err2_bits, int *__restrict__ max_norm2_bits) {
+    constexpr int D = 512;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= N) return;
+    const float *row = in + (long)g * D + lane * 8;
+    const floatx4 a = *reinterpret_cast<const floatx4 *>(row), b = *reinterpret_cast<const floatx4 *>(row + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    float m = 0.f, n2 = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        m = fmaxf(m, fabsf(v[e]));
+        n2 += v[e] * v[e];
+        bad = bad || !(fabsf(v[e]) < INFINITY);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off));
+        n2 += __shfl_xor(n2, off);
+        bad = bad || __shfl_xor((int)bad, off);
+    }
+    const float sc = m > 0.f ? m / 127.f : 0.f, inv = m > 0.f ? 127.f / m : 0.f;
+    float e2 = 0.f;
+    unsigned long long packed = 0ull;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float q = rintf(v[e] * inv);
+        q = fminf(fmaxf(q, -127.f), 127.f);
+        if (bad) q = 0.f;
+        const float d = v[e] - sc * q;
+        e2 += d * d;
+        packed |= (unsigned long long)(unsigned)((int)q + 128) << (8 * e);
+    }
+    for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+    // k = lane * 8 + e: k-step ks = lane >> 1, k half hi = lane & 1
+    const int ks = lane >> 1, hi = lane & 1;
+    const long off = ((((long)(g >> 7) * 4 + ((g >> 5) & 3)) * (D / 32) + (ks >> 1)) * 64 + hi * 32 + (g & 31)) * 16 + (ks & 1) * 8;
+    *reinterpret_cast<unsigned long long *>(out + off) = packed;
+    if (lane == 0) {
+        scale[g] = bad ? 0.f : sc;
+        // a non-finite row has no bound: NaN poisons the maxima (the NaN bit pattern is above every finite float's) and the selection
+        // then takes every tile, which sends the call through the exact scan
+        atomicMax(max_err2_bits, __float_as_int(bad ? NAN : e2 * 1.0001f));
+        atomicMax(max_norm2_bits, __float_as_int(bad ? NAN : n2));
+    }
+}
+
+// match_coarse_kernel over the int8 shadow (D = 512): same persistent structure, same outputs (per-wave maxima per tile, per-workgroup
+// maxima per query); the A ring holds 16 x 16 bytes per lane = one tile, each register feeds two k-steps after widening
+__global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__restrict__ G8, const float *__restrict__ gscale, int N, int F,
+                                                              float *__restrict__ tilemax, int num_tiles, const float *__restrict__ Q32,
+                                                              float *__restrict__ wgmax, int *__restrict__ ctl, unsigned long long *__restrict__ qkey) {
+    constexpr int D = 512, KS = D / 16, KP = D / 32, QP = D + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    half_t *Qs = reinterpret_cast<half_t *>(smem2);  // [128][QP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int q0 = blockIdx.y * 128;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid < 4) ctl[tid] = 0;
+        for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
+    }
+    for (int i = tid; i < 128 * (D / 8); i += 256) {
+        const int q = i / (D / 8), c = i - q * (D / 8);
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q0 + q < F) {
+            const floatx4 a = *reinterpret_cast<const floatx4 *>(Q32 + (long)(q0 + q) * D + c * 8), b = *reinterpret_cast<const floatx4 *>(Q32 + (long)(q0 + q) * D + c * 8 + 4);
+            v = half8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+        }
+        *reinterpret_cast<half8 *>(Qs + q * QP + c * 8) = v;
+    }
+    float rmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    bool rnan = false;
+    int tile = blockIdx.x;
+    if (tile >= num_tiles) {
+        for (int i = tid; i < 128; i += 256)
+            if (q0 + i < F) wgmax[(long)blockIdx.x * F + q0 + i] = -INFINITY;
+        return;
+    }
+    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+    auto frag_ptr = [&](int t) { return reinterpret_cast<const uint4_t *>(G8 + (((long)t * 4 + wave) * KP) * 1024) + lane; };  // + kp * 64 (1 KB) per k pair
+    auto scale_ptr = [&](int t) { return gscale + (long)t * 128 + wave * 32 + 4 * hi; };                                        // + 8 j: rows 8 j + 4 hi + (0..3)
+    uint4_t areg[KP];
+    floatx4 sreg[4];
+    {
+        const uint4_t *gp = frag_ptr(tile);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) areg[kp] = __builtin_nontemporal_load(gp + kp * 64);
+        const float *sp = scale_ptr(tile);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sreg[j] = *reinterpret_cast<const floatx4 *>(sp + 8 * j);
+    }
+    __syncthreads();
+    const half_t *qb = Qs + r * QP + 8 * hi;
+    for (; tile < num_tiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const int nt = next < num_tiles ? next : tile;
+        const uint4_t *gn = frag_ptr(nt);
+        floatx16 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+        half8 bq[2][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bq[0][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bq[(ks + 1) & 1][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP + (ks + 1) * 16);
+            }
+            const uint4_t raw = areg[ks >> 1];
+            const half8 af = (ks & 1) ? i8x8_to_half8(raw[2], raw[3]) : i8x8_to_half8(raw[0], raw[1]);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bq[ks & 1][n], acc[n], 0, 0, 0);
+            if (ks & 1) areg[ks >> 1] = __builtin_nontemporal_load(gn + (ks >> 1) * 64);  // both k-steps of the pair consumed: refill with the next tile's
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int gbase = tile * 128 + wave * 32;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int g = gbase + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (g < N) m = fmaxf(m, acc[n][e] * sreg[e >> 2][e & 3]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const int q = q0 + n * 32 + r;
+            if (hi == 0 && q < F) tilemax[((long)q * num_tiles + tile) * 4 + wave] = m;
+            rnan = rnan || (m != m);
+            rmax[n] = fmaxf(rmax[n], m);
+        }
+        {
+            const float *sp = scale_ptr(nt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sreg[j] = *reinterpret_cast<const floatx4 *>(sp + 8 * j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem2);
+    if (hi == 0) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) red[wave * 128 + n * 32 + r] = rnan ? NAN : rmax[n];
+    }
+    __syncthreads();
+    if (tid < 128 && q0 + tid < F) {
+        float m = red[tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float o = red[w * 128 + tid];
+            m = (m != m || o != o) ? NAN : fmaxf(m, o);
+        }
+        wgmax[(long)blockIdx.x * F + q0 + tid] = m;
+    }
+}
+
 // Tile selection in two fully parallel steps (it used to be one workgroup per query walking its 31 252 coarse entries twice: 128
 // workgroups, 80 us).  Step 1: grid (segments, queries) - maximum of a segment of the query's coarse entries.  Step 2: same grid -
 // the query's best coarse maximum from the segment maxima, ||q||, then every tile of the segment within 2*delta of the best goes on the
@@ -605,8 +794,9 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t *__restric
 // similarity wins and among equal similarities the LOWER row.  More pairs than the list holds (non-finite inputs, degenerate
 // galleries): the overflow flag routes the call through the unscreened exact scan instead (gate argument below).
 struct MatchPair {
-    int q, tile;
+    int q, tile;  // tile: bits 0 - 27 the 128-row tile, bits 28 - 31 which of its four 32-row blocks are inside the band
 };
+constexpr int PAIR_TILE_MASK = (1 << 28) - 1;
 constexpr int CTL_COUNT = 0, CTL_OVERFLOW = 1;
 constexpr int FB_BLOCKS = 128;  // workgroups of the gated fallback scan (it returns at once in the normal case: keep the empty launch small)
 
@@ -620,7 +810,10 @@ __device__ __forceinline__ float unmono_bits(unsigned m) { return __uint_as_floa
 // entry within 2*delta of it becomes a pair
 __global__ __launch_bounds__(256) void match_select_pairs_kernel(const float *__restrict__ tilemax, int num_tiles, const float *__restrict__ wgmax, int n_wg,
                                                                  int F, const float *__restrict__ Q, int D, float gmax_norm, MatchPair *__restrict__ pairs,
-                                                                 int pair_cap, int *__restrict__ ctl, const float *__restrict__ kth = nullptr) {
+                                                                 int pair_cap, int *__restrict__ ctl, const float *__restrict__ kth = nullptr,
+                                                                 float c_round = 1.2e-3f, float gerr = 0.f) {
+    // c_round / gerr: |S~ - S| <= ||q|| * (c_round * max||g|| + 1.02 * gerr).  fp16 shadow: two fp16 roundings (1.2e-3), no storage error;
+    // int8 shadow: one rounding (the query's: 0.7e-3) + the measured quantisation error norm of the rows
     // kth != nullptr (top-k): the threshold hangs on the query's k-th largest coarse entry (match_kth_kernel; see match_select_kernel)
     __shared__ float sm[4], sn[4];
     __shared__ int snan[4];
@@ -648,18 +841,34 @@ __global__ __launch_bounds__(256) void match_select_pairs_kernel(const float *__
     if (kth) m = kth[q];
     const bool anynan = snan[0] | snan[1] | snan[2] | snan[3];
     const float qn = sqrtf(sn[0] + sn[1] + sn[2] + sn[3]);
-    const float delta = 1.2e-3f * qn * gmax_norm;
+    const float delta = qn * (c_round * gmax_norm + 1.02f * gerr);
     // same rule as match_select_kernel: fp16 overflow / non-finite inputs -> no valid bound -> every tile (which overflows the pair list
     // and sends the call through the exact full scan)
-    const float thr = (!anynan && qn < 6.0e4f && gmax_norm < 6.0e4f && m == m && m > -INFINITY && m < INFINITY) ? m - 2.f * delta : -INFINITY;
+    const float thr = (!anynan && qn < 6.0e4f && gmax_norm < 6.0e4f && gerr < 6.0e4f && m == m && m > -INFINITY && m < INFINITY) ? m - 2.f * delta : -INFINITY;
     const int t0 = (int)((long)num_tiles * seg / SEL_SEG), t1 = (int)((long)num_tiles * (seg + 1) / SEL_SEG);
     const floatx4 *row = reinterpret_cast<const floatx4 *>(tilemax + (long)q * num_tiles * 4);
-    for (int t = t0 + tid; t < t1; t += 256) {
-        const floatx4 e = row[t];
-        if (!(e[0] < thr) || !(e[1] < thr) || !(e[2] < thr) || !(e[3] < thr)) {
-            const int i = atomicAdd(&ctl[CTL_COUNT], 1);
-            if (i < pair_cap) pairs[i] = MatchPair{q, t};
-            else ctl[CTL_OVERFLOW] = 1;
+    const int lane = tid & 63;
+    for (int tb = t0; tb < t1; tb += 256) {  // (uniform trip count: the ballot below needs whole waves)
+        const int t = tb + tid;
+        unsigned mask = 0u;
+        if (t < t1) {
+            const floatx4 e = row[t];
+            // (the re-rank reads only the flagged 32-row blocks: with the wider band of the int8 shadow a query that matches nothing lists
+            //  a dozen tiles, and whole tiles were 256 KB of fp32 rows per pair - 125 us of re-rank at 128 such queries)
+            mask = (!(e[0] < thr) ? 1u : 0u) | (!(e[1] < thr) ? 2u : 0u) | (!(e[2] < thr) ? 4u : 0u) | (!(e[3] < thr) ? 8u : 0u);
+        }
+        // one atomic per wave (1 400 single increments of one counter cost 35 us)
+        const unsigned long long bal = __ballot(mask != 0u);
+        if (bal) {
+            const int first = __ffsll((long long)bal) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(&ctl[CTL_COUNT], __popcll(bal));
+            base = __shfl(base, first);
+            if (mask) {
+                const int i = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (i < pair_cap) pairs[i] = MatchPair{q, (int)((unsigned)t | (mask << 28))};
+                else ctl[CTL_OVERFLOW] = 1;
+            }
         }
     }
 }
@@ -685,9 +894,10 @@ __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__res
         __syncthreads();  // the previous pair's readers of qs / rv are done
         for (int k = tid * 4; k < D; k += 512) *reinterpret_cast<floatx4 *>(qs + k) = *reinterpret_cast<const floatx4 *>(E + (long)pr.q * D + k);
         __syncthreads();
-        const long g = (long)pr.tile * 128 + tid;
+        const long g = (long)(pr.tile & PAIR_TILE_MASK) * 128 + tid;
+        const bool live = g < N && ((((unsigned)pr.tile >> 28) >> (tid >> 5)) & 1u);  // this row's 32-row block is inside the band
         float acc = 0.f;
-        if (g < N) {
+        if (live) {
             // k order of the exact kernel: per 32-wide step, for ks in 0..3, for s in 0..3: k = 8 ks + s (lanes 0-31 of the MFMA), then
             // k = 8 ks + 4 + s (lanes 32-63) - one fused multiply-add each
 #pragma unroll 8
@@ -701,8 +911,8 @@ __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__res
                 }
             }
         }
-        float v = g < N ? acc : -INFINITY;
-        int i = g < N ? (int)g : INT_MAX;
+        float v = live ? acc : -INFINITY;
+        int i = live ? (int)g : INT_MAX;
         if (prev_sim && i != INT_MAX) {
             const float ps = prev_sim[(long)pr.q * prev_stride];
             const int pi = prev_idx[(long)pr.q * prev_stride];
@@ -854,7 +1064,26 @@ void launch_gallery_norm16(const half_t *g16, int N, int D, int *max_norm2_bits,
     hipLaunchKernelGGL(row_norm_max_kernel<half_t>, dim3((N + 3) / 4), dim3(256), 0, s, g16, N, D, max_norm2_bits);
 }
 
+size_t gallery8_bytes(int N, int D) { return (size_t)((N + 127) / 128) * 128 * D; }
+void launch_gallery_shadow8(const float *gallery, int N, int D, uint8_t *g8, float *scale, int *max_err2_bits, int *max_norm2_bits, hipStream_t s) {
+    const size_t rows = (size_t)((N + 127) / 128) * 128;
+    (void)hipMemsetAsync(max_err2_bits, 0, sizeof(int), s);
+    (void)hipMemsetAsync(max_norm2_bits, 0, sizeof(int), s);
+    (void)hipMemsetAsync(g8, 0x80, gallery8_bytes(N, D), s);  // pad rows of the last tile: value 0
+    (void)hipMemsetAsync(scale, 0, rows * sizeof(float), s);
+    if (D != 512 || N <= 0) return;
+    hipLaunchKernelGGL(gallery_to_i8_kernel, dim3((N + 3) / 4), dim3(256), 0, s, gallery, N, g8, scale, max_err2_bits, max_norm2_bits);
+}
+
 constexpr int COARSE_WG = 256;  // persistent workgroups of the coarse scan (one per CU)
+static void launch_coarse_i8(const ScreenScratch &w, int N, const float *q32, int F, int tiles, hipStream_t s) {
+    const size_t lds = (size_t)128 * (512 + 8) * sizeof(half_t);
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 g(tiles < COARSE_WG ? tiles : COARSE_WG, (F + 127) / 128);
+    hipLaunchKernelGGL(match_coarse_i8_kernel, g, dim3(256), lds, s, w.g8, w.g8_scale, N, F, w.tilemax, tiles, q32, w.wgmax, w.ctl, w.qkey);
+}
 template <int D>
 static void launch_coarse_t(const half_t *g16, int N, const half_t *q16, int F, float *tilemax, int tiles, hipStream_t s, const float *q32 = nullptr,
                             float *wgmax = nullptr, int *ctl = nullptr, unsigned long long *qkey = nullptr) {
@@ -905,7 +1134,9 @@ void launch_match_topk(const float *gallery, const half_t *g16, int N, int D, co
         // passes of the scalar pair re-rank (a few microseconds each), pass j restricted to the rows behind winner j - 1.  With the
         // all-gathered queries of a node (configs[4]: 2 048 of them per rank) the tile-list path would re-rank every query against every
         // listed tile, k times.
-        switch (D) {
+        const bool i8 = w.g8 && D == 512;
+        if (i8) launch_coarse_i8(w, N, queries, F, tiles_, s);
+        else switch (D) {
             case 64: launch_coarse_t<64>(g16, N, nullptr, F, w.tilemax, tiles_, s, queries, w.wgmax, w.ctl, w.qkey); break;
             case 128: launch_coarse_t<128>(g16, N, nullptr, F, w.tilemax, tiles_, s, queries, w.wgmax, w.ctl, w.qkey); break;
             case 256: launch_coarse_t<256>(g16, N, nullptr, F, w.tilemax, tiles_, s, queries, w.wgmax, w.ctl, w.qkey); break;
@@ -913,7 +1144,7 @@ void launch_match_topk(const float *gallery, const half_t *g16, int N, int D, co
         }
         hipLaunchKernelGGL(match_kth_kernel, dim3(F), dim3(256), 0, s, w.tilemax, tiles_ * 4, k, kth_scratch);
         hipLaunchKernelGGL(match_select_pairs_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles_, w.wgmax, COARSE_WG, F, queries, D, gmax_norm,
-                           reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl, (const float *)kth_scratch);
+                           reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl, (const float *)kth_scratch, i8 ? 0.7e-3f : 1.2e-3f, i8 ? w.gerr : 0.f);
         const int *gate = w.ctl + CTL_OVERFLOW;
         for (int j = 0; j < k; ++j) {
             const float *ps = j ? sim_out + (j - 1) : nullptr;
@@ -969,7 +1200,9 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
     const int tiles = (N + BM - 1) / BM;
     if (w.pairs && w.wgmax && tiles >= COARSE_WG) {  // fast path (round 3): coarse (queries converted on load, per-workgroup maxima) -> pairs -> scalar re-rank -> unpack
         const int n_wg = COARSE_WG;
-        switch (D) {
+        const bool i8 = w.g8 && D == 512;  // int8 shadow (fp32-stored galleries): half the bytes of the scan, same answers
+        if (i8) launch_coarse_i8(w, N, queries, F, tiles, s);
+        else switch (D) {
             case 64: launch_coarse_t<64>(g16, N, nullptr, F, w.tilemax, tiles, s, queries, w.wgmax, w.ctl, w.qkey); break;
             case 128: launch_coarse_t<128>(g16, N, nullptr, F, w.tilemax, tiles, s, queries, w.wgmax, w.ctl, w.qkey); break;
             case 256: launch_coarse_t<256>(g16, N, nullptr, F, w.tilemax, tiles, s, queries, w.wgmax, w.ctl, w.qkey); break;
@@ -977,7 +1210,7 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
         }
         // (with F > 128 every query block y writes its own columns of wgmax: [n_wg][F])
         hipLaunchKernelGGL(match_select_pairs_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles, w.wgmax, n_wg, F, queries, D, gmax_norm,
-                           reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl, (const float *)nullptr);
+                           reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl, (const float *)nullptr, i8 ? 0.7e-3f : 1.2e-3f, i8 ? w.gerr : 0.f);
         const int rr_grid = 1024;
         if (gallery)
             hipLaunchKernelGGL((match_rerank_pairs_kernel<float>), dim3(rr_grid), dim3(128), (size_t)D * sizeof(float), s, gallery, N, D, queries,

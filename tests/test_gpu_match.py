@@ -285,3 +285,44 @@ def test_calculate_top1_is_the_matrix_and_its_row_maxima_in_one_call(frt, synth)
         i3, s3 = m.top1(q)
         assert np.array_equal(i2, i) and np.array_equal(s2, s) and np.array_equal(i3, i) and np.array_equal(s3, s)
         m.close()
+
+
+@pytest.mark.gpu
+def test_int8_shadow_screening_is_exact_whatever_the_rows_look_like(frt, synth):
+    """Round 4: fp32-stored 512-column galleries are screened through an INT8 shadow (per-row scale, measured error norm in the bound,
+    kernels_match.hip).  Rows that stress the quantiser - one huge element (everything else rounds to 0), tiny rows, all-zero rows,
+    un-normalised rows 3x longer than the rest, near-duplicates whose difference is far below one int8 step, exact duplicates across
+    tiles - and queries that match nothing (widest candidate band) must still give the full-matrix scan's answer bit for bit; a NaN /
+    inf row voids the bound and the call must take the exact scan and still agree."""
+    rng = np.random.default_rng(8)
+    N = 70000 + 77
+    g = synth.make_gallery(N).copy()
+    g[100] = 0
+    g[100, 3] = 1.0                              # one-hot: scale = 1/127, every other element quantises to 0
+    g[200] *= 1e-6                               # tiny row
+    g[300] = 0                                   # all-zero row (scale 0)
+    g[400:410] *= 3.0                            # un-normalised rows dominate max||g|| and the error norm
+    g[5000] = g[64000]                           # exact duplicates 59 000 rows apart: first index wins
+    g[6000] = g[64001] * (1 + 1e-6)              # near-duplicate: the int8 rows are identical, the exact re-rank separates them
+    q = np.concatenate([g[[100, 200, 64000, 64001, 6000, 405]], rng.standard_normal((58, 512)).astype(np.float32)])
+    q[:6] /= np.maximum(np.linalg.norm(q[:6], axis=1, keepdims=True), 1e-30)
+    q[6:] /= np.linalg.norm(q[6:], axis=1, keepdims=True)
+    m = frt.MatMul(0)
+    m.init(g)
+    i, s = m.top1(q)
+    full = m.calculate(q)
+    assert np.array_equal(i, full.argmax(1).astype(np.int32)) and np.array_equal(s, full.max(1))
+    assert i[2] == 5000 and i[1] == full[1].argmax()
+    ti, ts = m.topk(q, 4)
+    order = np.argsort(-full, axis=1, kind="stable")[:, :4]
+    assert np.array_equal(ti, order.astype(np.int32)) and np.array_equal(ts, np.take_along_axis(full, order, 1))
+    # a non-finite row: no bound -> every call goes through the exact scan (NaN never wins, std::max_element's rule)
+    g2 = g.copy()
+    g2[12345, 7] = np.nan
+    g2[23456, 9] = np.inf
+    m.init(g2)
+    i2, s2 = m.top1(q[:8])
+    full2 = m.calculate(q[:8])
+    want = np.array([np.nanargmax(np.where(np.isnan(r), -np.inf, r)) for r in full2], np.int32)
+    assert np.array_equal(i2, want)
+    m.close()
