@@ -234,6 +234,14 @@ __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strip
     }
 }
 
+// Round 4, built, measured and parked in tools/experiments/conv64_in_unit0_input_layer_fused.hip: this kernel computing its own input
+// patch from the 3-channel crop (the input layer - 4 MFMAs, 16 gathers and a 64-value fp32 PReLU / BN epilogue per 32 patch pixels - inside
+// the strip loop, so that the 205 MB tensor z is never written or read).  Bit-identical to the two-kernel path (goldens green) and
+// SLOWER: 379 us at 128 faces against 78 (arc_input_mfma_kernel) + 169 (this kernel) = 247 us (profiles/r04k_unit0_fused_in.txt).  The
+// strip loop runs one wave per SIMD; the patch build is ~ 3 000 VALU / LDS / store instructions per strip and wave in the same in-order
+// stream as the 144 MFMAs (7 261 instructions in the kernel, 800 of them AGPR moves at 498 registers), where the stand-alone input
+// kernel spreads the same work over sixteen waves per CU and is bound by its 256 MB of HBM writes.  410 MB of traffic saved, 132 us lost.
+
 // Round 3, measured and removed: a variant in which a wave owns BOTH 32-cout blocks (288 weight registers) and half of the strip's
 // pixel tiles, so that every B fragment read from LDS feeds two MFMAs (half the LDS traffic per MFMA, the bound named above).  Correct,
 // no spills in the PReLU / BN forms - and slower (profiles/r03b_embed_ab.txt, one box, rocprofv3 averages at 128 faces): the three PReLU
