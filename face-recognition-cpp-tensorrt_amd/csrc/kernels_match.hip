@@ -517,7 +517,11 @@ __global__ __launch_bounds__(256) void gallery_to_i8_kernel(const float *__restr
 }
 
 // match_coarse_kernel over the int8 shadow (D = 512): same persistent structure, same outputs (per-wave maxima per tile, per-workgroup
-// maxima per query); the A ring holds 16 x 16 bytes per lane = one tile, each register feeds two k-steps after widening
+// maxima per query); the A ring holds 16 x 16 bytes per lane = one tile, each register feeds two k-steps after widening.
+// NQB = 32-query blocks per workgroup (1, 2 or 4): a call with few queries - one frame's faces, a four-frame batch - neither computes nor
+// keeps in LDS the empty query blocks, and two to four workgroups then share a CU (with all four blocks the scan is not HBM-bound:
+// 173 us for 0.51 GB; with one block it is).
+template <int NQB>
 __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__restrict__ G8, const float *__restrict__ gscale, int N, int F,
                                                               float *__restrict__ tilemax, int num_tiles, const float *__restrict__ Q32,
                                                               float *__restrict__ wgmax, int *__restrict__ ctl, unsigned long long *__restrict__ qkey) {
@@ -526,12 +530,12 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
     half_t *Qs = reinterpret_cast<half_t *>(smem2);  // [128][QP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hi = lane >> 5;
-    const int q0 = blockIdx.y * 128;
+    const int q0 = blockIdx.y * (32 * NQB);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         if (tid < 4) ctl[tid] = 0;
         for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
     }
-    for (int i = tid; i < 128 * (D / 8); i += 256) {
+    for (int i = tid; i < 32 * NQB * (D / 8); i += 256) {
         const int q = i / (D / 8), c = i - q * (D / 8);
         half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (q0 + q < F) {
@@ -540,11 +544,13 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
         }
         *reinterpret_cast<half8 *>(Qs + q * QP + c * 8) = v;
     }
-    float rmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float rmax[NQB];
+#pragma unroll
+    for (int n = 0; n < NQB; ++n) rmax[n] = -INFINITY;
     bool rnan = false;
     int tile = blockIdx.x;
     if (tile >= num_tiles) {
-        for (int i = tid; i < 128; i += 256)
+        for (int i = tid; i < 32 * NQB; i += 256)
             if (q0 + i < F) wgmax[(long)blockIdx.x * F + q0 + i] = -INFINITY;
         return;
     }
@@ -567,30 +573,30 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
         const int next = tile + gridDim.x;
         const int nt = next < num_tiles ? next : tile;
         const uint4_t *gn = frag_ptr(nt);
-        floatx16 acc[4];
+        floatx16 acc[NQB];
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NQB; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-        half8 bq[2][4];
+        half8 bq[2][NQB];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bq[0][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP);
+        for (int n = 0; n < NQB; ++n) bq[0][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) bq[(ks + 1) & 1][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP + (ks + 1) * 16);
+                for (int n = 0; n < NQB; ++n) bq[(ks + 1) & 1][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP + (ks + 1) * 16);
             }
             const uint4_t raw = areg[ks >> 1];
             const half8 af = (ks & 1) ? i8x8_to_half8(raw[2], raw[3]) : i8x8_to_half8(raw[0], raw[1]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bq[ks & 1][n], acc[n], 0, 0, 0);
+            for (int n = 0; n < NQB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bq[ks & 1][n], acc[n], 0, 0, 0);
             if (ks & 1) areg[ks >> 1] = __builtin_nontemporal_load(gn + (ks >> 1) * 64);  // both k-steps of the pair consumed: refill with the next tile's
         }
         __builtin_amdgcn_sched_barrier(0);
         const int gbase = tile * 128 + wave * 32;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NQB; ++n) {
             float m = -INFINITY;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -614,14 +620,14 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
     float *red = reinterpret_cast<float *>(smem2);
     if (hi == 0) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) red[wave * 128 + n * 32 + r] = rnan ? NAN : rmax[n];
+        for (int n = 0; n < NQB; ++n) red[wave * (32 * NQB) + n * 32 + r] = rnan ? NAN : rmax[n];
     }
     __syncthreads();
-    if (tid < 128 && q0 + tid < F) {
+    if (tid < 32 * NQB && q0 + tid < F) {
         float m = red[tid];
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-            const float o = red[w * 128 + tid];
+            const float o = red[w * (32 * NQB) + tid];
             m = (m != m || o != o) ? NAN : fmaxf(m, o);
         }
         wgmax[(long)blockIdx.x * F + q0 + tid] = m;
@@ -1076,14 +1082,22 @@ void launch_gallery_shadow8(const float *gallery, int N, int D, uint8_t *g8, flo
 }
 
 constexpr int COARSE_WG = 256;  // persistent workgroups of the coarse scan (one per CU)
-static void launch_coarse_i8(const ScreenScratch &w, int N, const float *q32, int F, int tiles, hipStream_t s) {
-    const size_t lds = (size_t)128 * (512 + 8) * sizeof(half_t);
+template <int NQB>
+static void launch_coarse_i8_t(const ScreenScratch &w, int N, const float *q32, int F, int tiles, hipStream_t s) {
+    const size_t lds = (size_t)32 * NQB * (512 + 8) * sizeof(half_t);
     static bool attr_done[FRT_MAX_DEVICES] = {};
     if (frt_first_use_on_device(attr_done))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 g(tiles < COARSE_WG ? tiles : COARSE_WG, (F + 127) / 128);
-    hipLaunchKernelGGL(match_coarse_i8_kernel, g, dim3(256), lds, s, w.g8, w.g8_scale, N, F, w.tilemax, tiles, q32, w.wgmax, w.ctl, w.qkey);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_i8_kernel<NQB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // wgmax is [COARSE_WG][F]: the grid never exceeds COARSE_WG workgroups per query block (smaller query blocks leave room for several per CU)
+    dim3 g(tiles < COARSE_WG ? tiles : COARSE_WG, (F + 32 * NQB - 1) / (32 * NQB));
+    hipLaunchKernelGGL(match_coarse_i8_kernel<NQB>, g, dim3(256), lds, s, w.g8, w.g8_scale, N, F, w.tilemax, tiles, q32, w.wgmax, w.ctl, w.qkey);
 }
+static void launch_coarse_i8(const ScreenScratch &w, int N, const float *q32, int F, int tiles, hipStream_t s) {
+    if (F <= 32) launch_coarse_i8_t<1>(w, N, q32, F, tiles, s);
+    else if (F <= 64) launch_coarse_i8_t<2>(w, N, q32, F, tiles, s);
+    else launch_coarse_i8_t<4>(w, N, q32, F, tiles, s);
+}
+
 template <int D>
 static void launch_coarse_t(const half_t *g16, int N, const half_t *q16, int F, float *tilemax, int tiles, hipStream_t s, const float *q32 = nullptr,
                             float *wgmax = nullptr, int *ctl = nullptr, unsigned long long *qkey = nullptr) {
