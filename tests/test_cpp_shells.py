@@ -124,6 +124,30 @@ def test_rccl_communicator_from_plain_cpp(tmp_path):
     assert out.returncode == 0 and "comm ok" in out.stdout, out.stdout + out.stderr
 
 
+def build_multi_device(outdir):
+    exe = os.path.join(outdir, "multi_device_pipeline")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "multi_device_pipeline.cpp"), "-o", exe, os.path.join(PKG, "libfrt.so"), "-L/opt/rocm/lib", "-lamdhip64",
+                           "-lpthread", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.mark.gpu
+def test_one_process_drives_every_visible_device(frt, synth, blobs, tmp_path):
+    """tests/cpp/multi_device_pipeline.cpp: ONE process (the reference's shape, src/app.cpp:52-57,367), one host thread per visible device
+    on frt_pipeline_submit / wait, every step's records exchanged with a grouped ncclAllGather from libfrt (frt_comm_create_all +
+    frt_comm_all_gather_multi) - no launcher, no Python in the process.  On a one-GPU box this is a 1-device run of the same code."""
+    import json
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    synth.make_frames(6, 640, 640).tofile(str(tmp_path / "frames.bin"))
+    exe = build_multi_device(str(tmp_path))
+    out = subprocess.run([exe, dpath, rpath, str(tmp_path / "frames.bin"), "4", "40000", "8", "all"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    r = json.loads(next(l for l in out.stdout.splitlines() if l.startswith("{")))
+    assert r["devices"] == frt.device_count() and r["gather_mismatches"] == 0 and r["faces"] >= 8 * 4 * r["devices"], r
+
+
 @pytest.mark.gpu
 def test_dropin_call_sequence_threads_and_fast_getoutputs(frt, tmp_path):
     """tests/cpp/dropin_bench.cpp at a small size: src/app.cpp:304-310 verbatim through the shells from 3 threads with their own objects
