@@ -95,7 +95,15 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
     // ---- depthwise role: one 4-pixel segment, CH_PASS-strided channels
     const int seg = threadIdx.x % SEGS, chl = threadIdx.x / SEGS;
     const PixMap ms = map_pixel<MODE2D, TP>(lid, seg * 4, a.B, a.Ho, a.Wo, tiles_x, tiles_y);
+#ifdef FRT_ABLATE
+    // timing build, linear tiles only (tiles_x is unused there; FRT_DWPW_ABLATE): bit 0 no output stores, bit 1 every workgroup reads the
+    // first rows of image 0 (cache-resident input).  Round 4, 128 -> 128 block at 40x40, 32 frames: 45 us -> 44 (no stores) / 44 (cached
+    // input) / 38 (both) in the ablation build - the launch is not memory-bound; profiles/r04o_det_ablations.txt
+    const int abl = MODE2D ? 0 : tiles_x;
+    const float *inb = a.in + (long)((ms.ok && !(abl & 2)) ? ms.b : 0) * a.Cin * HW;
+#else
     const float *inb = a.in + (long)(ms.ok ? ms.b : 0) * a.Cin * HW;
+#endif
     int roff[3];
     bool rok[3];
 #pragma unroll
@@ -103,6 +111,9 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
         const int iy = ms.oy * STRIDE - 1 + k;
         rok[k] = ms.ok && iy >= 0 && iy < a.H;
         roff[k] = rok[k] ? iy * a.W + ms.ox * STRIDE : 0;
+#ifdef FRT_ABLATE
+        if (abl & 2) roff[k] = rok[k] ? (iy % 3) * a.W + ms.ox * STRIDE : 0;
+#endif
     }
     const bool left_ok = ms.ox > 0;                            // column ox*STRIDE - 1 exists
     const bool right_ok = STRIDE == 1 && ms.ox + 4 < a.W;      // column ox + 4 exists (stride 1 only)
@@ -265,6 +276,9 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
             if (co < a.Cout) {
                 float v = acc[cb][e] + a.bp[co];
                 if (a.relu) v = fmaxf(v, 0.f);
+#ifdef FRT_ABLATE
+                if ((abl & 1) && v != 12345.678f) continue;
+#endif
                 ob[(long)co * HoWo] = v;
             }
         }
@@ -413,6 +427,9 @@ void launch_fused(const DwPwArgs &a, hipStream_t s) {
     } else {
         nblocks = ((long)a.B * a.Ho * a.Wo + TP - 1) / TP;
     }
+#ifdef FRT_ABLATE
+    if (!MODE2D) tiles_x = frt_tuning_env("FRT_DWPW_ABLATE") ? atoi(frt_tuning_env("FRT_DWPW_ABLATE")) : 0;
+#endif
     const unsigned cgroups = (unsigned)((a.Cout + 32 * NCW * CBW - 1) / (32 * NCW * CBW));
     const dim3 grid((unsigned)nblocks, cgroups);
     static const bool split = !(frt_tuning_env("FRT_DET_PW_SPLIT") && frt_tuning_env("FRT_DET_PW_SPLIT")[0] == '0');
