@@ -729,7 +729,11 @@ def main():
             det_flop = wk.get("det_network", 0.0)
             rec_flop = wk.get("embed_network", 0.0)
             n_rows = int(frt.lib.frt_matcher_num_rows(rec.matmul._h))
-            scan_b = (2 if (n_rows >= 32768 or args.sharded_gallery) else 4) * 512.0 * n_rows   # fp16 shadow scan (screened) or the fp32 rows
+            # bytes per element of the per-call scan: int8 shadow (fp32-stored galleries, round 4), fp16 shadow / fp16-stored shard, or the fp32 rows
+            i8 = (not args.sharded_gallery and n_rows >= 32768 and os.environ.get("FRT_MATCH_I8") != "0" and os.environ.get("FRT_MATCH_FAST") != "0"
+                  and os.environ.get("FRT_MATCH_SCREEN") != "0")
+            scan_bpe = 1 if i8 else (2 if (n_rows >= 32768 or args.sharded_gallery) else 4)
+            scan_b = scan_bpe * 512.0 * n_rows
             mt_ms = st.get("match_top1", 0) + st.get("match_topk", 0)
 
             def frac(x, ms, peak):
@@ -747,7 +751,7 @@ def main():
                 "match": {"bound": "hbm", "ms": round(mt_ms, 4), "bytes": int(scan_b),
                           "achieved_TBps": round(scan_b / (mt_ms * 1e-3) / 1e12, 3) if mt_ms > 0 else None,
                           "frac_hbm": frac(scan_b, mt_ms, PEAK_HBM_BPS),
-                          "note": "one scan of the gallery per call (%d rows x 512 x %d B)" % (n_rows, 2 if (n_rows >= 32768 or args.sharded_gallery) else 4)},
+                          "note": "one scan of the %s per call (%d rows x 512 x %d B)" % ("int8 shadow gallery" if i8 else "gallery", n_rows, scan_bpe)},
                 "note": "serial stage times: HIP events around each stage in 3 extra untimed serial steps; peaks 8 TB/s HBM, 157.3 TF fp32 matrix, 2.5 PF fp16 MFMA"}
         if max(stage_ms.values()) > 0:
             overlap_eff = {"value": round(max(stage_ms.values()) / step_ms, 4), "serial_stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

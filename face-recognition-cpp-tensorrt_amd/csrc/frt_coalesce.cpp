@@ -274,6 +274,7 @@ int frt_coalescer_infer_crops(frt_coalescer *c, const uint8_t *bgr, int rows, in
         const int rc = b.rc;
         const std::string err = b.err;
         int nb = 0;
+        lk.unlock();  // the batch stays DONE until its last reader has left: the copies below need no lock (32 callers x 150 KB of crops)
         if (rc == FRT_OK) {
             const frt_face_result *src = b.h_results + (size_t)slot * c->max_faces;
             for (int k = 0; k < c->max_faces; ++k) {
@@ -284,6 +285,7 @@ int frt_coalescer_infer_crops(frt_coalescer *c, const uint8_t *bgr, int rows, in
             if (embeds_out) std::memcpy(embeds_out, b.h_embeds + (size_t)slot * c->max_faces * 512, sizeof(float) * 512 * c->max_faces);
             if (crops_out) std::memcpy(crops_out, b.h_crops + (size_t)slot * c->max_faces * frt_coalescer::kCropBytes, frt_coalescer::kCropBytes * c->max_faces);
         }
+        lk.lock();
         if (--b.readers == 0) {  // last reader out: the staging set is free again
             b.state = frt_coalescer::FREE;
             c->open_next_locked();

@@ -68,9 +68,18 @@ FRT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | head -1 >
 FRT_BENCH_FORCE_DIST=1 python bench.py --sharded-gallery --batch 64 --gallery 1250000 --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_sharded_1rank.json"
 # 3b. the drop-in shells measured (src/app.cpp:304-310 through include/frt/*.h, 1 and 8 threads, N = 1M)
 python tools/dropin_bench.py --gallery 1000000 --threads 1 8 --iters 150 --out "$OUT/${TAG}_dropin_bench.json" > /dev/null 2>&1
+# 3b'. round 4: the same call sequence from 8 / 32 request threads on ONE detector + ONE recogniser with request coalescing (frt_coalescer_*)
+for t in 8 32; do python tools/dropin_bench.py --gallery 1000000 --threads $t --iters 150 --coalesce 32 --window-us 100 --out "$OUT/${TAG}_dropin_coalesce_t$t.json" > /dev/null 2>&1; done
+python tools/dropin_bench.py --gallery 1000000 --threads 8 --iters 100 --shared --out "$OUT/${TAG}_dropin_shared_plain_t8.json" > /dev/null 2>&1
+# 3b''. round 4: one process / every visible device (tests/cpp/multi_device_pipeline.cpp); BASELINE configs[3] per-rank shape (4 frames per step)
+python tools/multi_device_bench.py --steps 100 --out "$OUT/${TAG}_multi_device.json" > /dev/null 2>&1
+python bench.py --batch 4 --no-cpu-baseline --steps 300 --resident > "$OUT/${TAG}_bench_b4_resident.json" 2>/dev/null
+python bench.py --batch 4 --no-cpu-baseline --steps 300 > "$OUT/${TAG}_bench_b4.json" 2>/dev/null
 # 3c. small batches: the small-batch recogniser path against the strip kernels and the oracle; per-launch table of a 1- and a 4-face pass
 python tools/small_batch_parity.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/${TAG}_small_batch_parity.txt"
-for nf in 1 4; do NF=$nf bash tools/layer_table.sh "A=1"; done > "$OUT/${TAG}_small_batch_layers.txt" 2>&1
+for nf in 1 4 16 32; do NF=$nf bash tools/layer_table.sh "A=1"; done > "$OUT/${TAG}_small_batch_layers.txt" 2>&1
+python tools/ks_check.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/${TAG}_medium_batch_parity.txt"
+python tools/prof_match_small.py 2>/dev/null | grep queries > "$OUT/${TAG}_match_small.txt"
 # 4. the microbenchmarks DESIGN.md quotes (sources in tools/ubench/*.hip)
 for P in clock_probe occ_probe mfma_f32_order; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -w -o /tmp/$P "$ROOT/tools/ubench/$P.hip" 2>/dev/null && timeout 120 /tmp/$P > "$OUT/${TAG}_$P.txt" 2>&1
