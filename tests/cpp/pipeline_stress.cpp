@@ -4,7 +4,8 @@
 // device code untouched) by tests/test_gpu_sanitizers.py.
 //   pipeline_stress <det.frtw> <rec.frtw> <frames.bin: 2 batches of B frames u8 HxWx3> <B> <H> <W> <gallery.bin fp32 [N][512]> <N>
 // Four threads call frt_pipeline_run concurrently (one of them mixes in object-level detector / matcher calls), the main thread keeps
-// tickets in flight through submit / wait and reloads the gallery in the middle.  Every answer must equal the quiet-device answer.
+// tickets in flight through submit / wait and reloads the gallery in the middle; then six threads send single frames through the request
+// coalescer (frt_coalescer_*).  Every answer must equal the quiet-device answer.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -111,6 +112,35 @@ int main(int argc, char **argv) {
         if (frt_pipeline_wait(pipe, tickets[9] + 100) == FRT_OK) bad.fetch_add(1);  // unknown ticket must be an error
     }
     for (std::thread &t : th) t.join();
+    // ---- round 4: the request coalescer (csrc/frt_coalesce.cpp: dispatcher + completer threads, four staging sets, per-batch condition
+    //      variables) under six caller threads, each sending single frames; every frame's boxes / matches must be its own quiet answer
+    {
+        frt_coalescer *co = nullptr;
+        CHECK(frt_coalescer_create(det, emb, mat, B, 150, &co));
+        const size_t fbytes = (size_t)H * W * 3;
+        auto cworker = [&](int t) {
+            std::vector<frt_face_result> res(K);
+            std::vector<float> embeds((size_t)K * 512);
+            std::vector<uint8_t> crops((size_t)K * 112 * 112 * 3);
+            for (int it = 0; it < 10; ++it) {
+                const int k = (t + it) & 1, fidx = (t * 3 + it) % B;
+                int n = 0;
+                CHECK(frt_coalescer_infer_crops(co, frames[k] + (size_t)fidx * fbytes, H, W, (size_t)W * 3, res.data(), (it & 1) ? embeds.data() : nullptr,
+                                                (it % 3) == 0 ? crops.data() : nullptr, &n));
+                const frt_face_result *w = &want[k][(size_t)fidx * K];
+                for (int j = 0; j < K; ++j)
+                    if (std::memcmp(&res[j].box, &w[j].box, sizeof(frt_bbox)) || res[j].match_idx != w[j].match_idx || res[j].valid != w[j].valid) bad.fetch_add(1);
+            }
+        };
+        std::vector<std::thread> ct;
+        for (int t = 0; t < 6; ++t) ct.emplace_back(cworker, t);
+        for (std::thread &t : ct) t.join();
+        long nb = 0, nf = 0;
+        CHECK(frt_coalescer_stats(co, &nb, &nf));
+        if (nf != 60 || nb < 1 || nb > 60) bad.fetch_add(1);
+        if (frt_coalescer_infer(co, frames[0], H / 2, W, (size_t)W * 3, want[0].data(), nullptr, nullptr) == FRT_OK) bad.fetch_add(1);  // wrong frame size
+        frt_coalescer_destroy(co);
+    }
     frt_pipeline_destroy(pipe);
     frt_matcher_destroy(mat);
     frt_embedder_destroy(emb);
