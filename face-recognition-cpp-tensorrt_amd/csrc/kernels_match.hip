@@ -578,20 +578,47 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
         for (int n = 0; n < NQB; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-        half8 bq[2][NQB];
+        // Software-pipelined by hand, one k-step ahead: the query fragments AND the widened gallery fragment of step ks + 1 are produced
+        // before the MFMAs of step ks, and sched_barrier pins that order.  Left to the compiler the LDS reads sat directly in front of the
+        // MFMAs that consume them (two to three exposed LDS latencies per k-step with one wave per SIMD: 370 cycles per step, the scan at
+        // 2.95 TB/s with the matrix pipe a third busy).
+        if constexpr (NQB == 4) {
+            constexpr int LA = 1;  // k-steps of lookahead (ring of LA + 1); 2 measured the same (165 against 163 us)
+            half8 bq[LA + 1][NQB], af[LA + 1];
+            auto produce = [&](int k) {  // query fragments + widened gallery fragment of k-step k into ring slot k % (LA + 1)
 #pragma unroll
-        for (int n = 0; n < NQB; ++n) bq[0][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP);
+                for (int n = 0; n < NQB; ++n) bq[k % (LA + 1)][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP + k * 16);
+                const uint4_t raw = areg[k >> 1];
+                af[k % (LA + 1)] = (k & 1) ? i8x8_to_half8(raw[2], raw[3]) : i8x8_to_half8(raw[0], raw[1]);
+                // (k odd: both k-steps of register k >> 1 are widened now - refill it with the next tile's)
+                if (k & 1) areg[k >> 1] = __builtin_nontemporal_load(gn + (k >> 1) * 64);
+            };
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
+            for (int k = 0; k < LA; ++k) produce(k);
 #pragma unroll
-                for (int n = 0; n < NQB; ++n) bq[(ks + 1) & 1][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP + (ks + 1) * 16);
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + LA < KS) produce(ks + LA);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < NQB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks % (LA + 1)], bq[ks % (LA + 1)][n], acc[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const uint4_t raw = areg[ks >> 1];
-            const half8 af = (ks & 1) ? i8x8_to_half8(raw[2], raw[3]) : i8x8_to_half8(raw[0], raw[1]);
+        } else {  // one or two query blocks: HBM-bound either way, and the compiler's own schedule measured faster (64 queries: 164 against 182 us per call)
+            half8 bq[2][NQB];
 #pragma unroll
-            for (int n = 0; n < NQB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bq[ks & 1][n], acc[n], 0, 0, 0);
-            if (ks & 1) areg[ks >> 1] = __builtin_nontemporal_load(gn + (ks >> 1) * 64);  // both k-steps of the pair consumed: refill with the next tile's
+            for (int n = 0; n < NQB; ++n) bq[0][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int n = 0; n < NQB; ++n) bq[(ks + 1) & 1][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP + (ks + 1) * 16);
+                }
+                const uint4_t raw = areg[ks >> 1];
+                const half8 af = (ks & 1) ? i8x8_to_half8(raw[2], raw[3]) : i8x8_to_half8(raw[0], raw[1]);
+#pragma unroll
+                for (int n = 0; n < NQB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bq[ks & 1][n], acc[n], 0, 0, 0);
+                if (ks & 1) areg[ks >> 1] = __builtin_nontemporal_load(gn + (ks >> 1) * 64);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         const int gbase = tile * 128 + wave * 32;
@@ -631,6 +658,132 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
             m = (m != m || o != o) ? NAN : fmaxf(m, o);
         }
         wgmax[(long)blockIdx.x * F + q0 + tid] = m;
+    }
+}
+
+// The same scan for a full 128-query block with a 2 x 2 wave tiling: wave = (row half rb, query half qh) owns the 32-row blocks 2 rb, 2 rb + 1
+// and the query blocks 2 qh, 2 qh + 1 - four accumulators as before, but every query fragment read from LDS and every widened gallery
+// fragment now feeds TWO MFMAs.  With one row block x four query blocks per wave (above) the four waves read 4 x 4 KB of query fragments per
+// k-step, exactly the CU's LDS bandwidth, and the int8 scan ran at 2.95 TB/s with the matrix pipe a third busy (profiles/r04j); here the LDS
+// traffic is halved (and the widening doubled: 512 VALU operations per tile and wave, still under the MFMA time).
+__global__ __launch_bounds__(256) void match_coarse_i8x4_kernel(const uint8_t *__restrict__ G8, const float *__restrict__ gscale, int N, int F,
+                                                                float *__restrict__ tilemax, int num_tiles, const float *__restrict__ Q32,
+                                                                float *__restrict__ wgmax, int *__restrict__ ctl, unsigned long long *__restrict__ qkey) {
+    constexpr int D = 512, KS = D / 16, KP = D / 32, QP = D + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    half_t *Qs = reinterpret_cast<half_t *>(smem2);  // [128][QP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hi = lane >> 5;
+    const int rb = wave >> 1, qh = wave & 1;
+    const int q0 = blockIdx.y * 128;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid < 4) ctl[tid] = 0;
+        for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
+    }
+    for (int i = tid; i < 128 * (D / 8); i += 256) {
+        const int q = i / (D / 8), c = i - q * (D / 8);
+        half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q0 + q < F) {
+            const floatx4 a = *reinterpret_cast<const floatx4 *>(Q32 + (long)(q0 + q) * D + c * 8), b = *reinterpret_cast<const floatx4 *>(Q32 + (long)(q0 + q) * D + c * 8 + 4);
+            v = half8{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+        }
+        *reinterpret_cast<half8 *>(Qs + q * QP + c * 8) = v;
+    }
+    float rmax[2] = {-INFINITY, -INFINITY};
+    bool rnan = false;
+    int tile = blockIdx.x;
+    if (tile >= num_tiles) {
+        for (int i = tid; i < 128; i += 256)
+            if (q0 + i < F) wgmax[(long)blockIdx.x * F + q0 + i] = -INFINITY;
+        return;
+    }
+    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+    auto frag_ptr = [&](int t, int b) { return reinterpret_cast<const uint4_t *>(G8 + (((long)t * 4 + 2 * rb + b) * KP) * 1024) + lane; };
+    auto scale_ptr = [&](int t, int b) { return gscale + (long)t * 128 + (2 * rb + b) * 32 + 4 * hi; };
+    uint4_t areg[2][KP];
+    floatx4 sreg[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const uint4_t *gp = frag_ptr(tile, b);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) areg[b][kp] = __builtin_nontemporal_load(gp + kp * 64);
+        const float *sp = scale_ptr(tile, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sreg[b][j] = *reinterpret_cast<const floatx4 *>(sp + 8 * j);
+    }
+    __syncthreads();
+    const half_t *qb = Qs + (qh * 64 + r) * QP + 8 * hi;
+    for (; tile < num_tiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const int nt = next < num_tiles ? next : tile;
+        const uint4_t *gn0 = frag_ptr(nt, 0), *gn1 = frag_ptr(nt, 1);
+        floatx16 acc[2][2];  // [row block][query block]
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[b][n][e] = 0.f;
+        half8 bq[2][2], af[2][2];  // [ring slot][query block | row block]
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bq[0][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP);
+        af[0][0] = i8x8_to_half8(areg[0][0][0], areg[0][0][1]);
+        af[0][1] = i8x8_to_half8(areg[1][0][0], areg[1][0][1]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {  // one k-step ahead, order pinned (see match_coarse_i8_kernel)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bq[(ks + 1) & 1][n] = *reinterpret_cast<const half8 *>(qb + n * 32 * QP + (ks + 1) * 16);
+                const uint4_t raw0 = areg[0][(ks + 1) >> 1], raw1 = areg[1][(ks + 1) >> 1];
+                af[(ks + 1) & 1][0] = ((ks + 1) & 1) ? i8x8_to_half8(raw0[2], raw0[3]) : i8x8_to_half8(raw0[0], raw0[1]);
+                af[(ks + 1) & 1][1] = ((ks + 1) & 1) ? i8x8_to_half8(raw1[2], raw1[3]) : i8x8_to_half8(raw1[0], raw1[1]);
+                if ((ks + 1) & 1) {
+                    areg[0][(ks + 1) >> 1] = __builtin_nontemporal_load(gn0 + ((ks + 1) >> 1) * 64);
+                    areg[1][(ks + 1) >> 1] = __builtin_nontemporal_load(gn1 + ((ks + 1) >> 1) * 64);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][0], bq[ks & 1][n], acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][1], bq[ks & 1][n], acc[1][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int gbase = tile * 128 + (2 * rb + b) * 32;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int g = gbase + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    if (g < N) m = fmaxf(m, acc[b][n][e] * sreg[b][e >> 2][e & 3]);
+                }
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const int q = q0 + (2 * qh + n) * 32 + r;
+                if (hi == 0 && q < F) tilemax[((long)q * num_tiles + tile) * 4 + 2 * rb + b] = m;
+                rnan = rnan || (m != m);
+                rmax[n] = fmaxf(rmax[n], m);
+            }
+            const float *sp = scale_ptr(nt, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sreg[b][j] = *reinterpret_cast<const floatx4 *>(sp + 8 * j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem2);  // [row half][128 queries]
+    if (hi == 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) red[rb * 128 + (2 * qh + n) * 32 + r] = rnan ? NAN : rmax[n];
+    }
+    __syncthreads();
+    if (tid < 128 && q0 + tid < F) {
+        const float a = red[tid], b = red[128 + tid];
+        wgmax[(long)blockIdx.x * F + q0 + tid] = (a != a || b != b) ? NAN : fmaxf(a, b);
     }
 }
 
@@ -1093,9 +1246,17 @@ static void launch_coarse_i8_t(const ScreenScratch &w, int N, const float *q32, 
     hipLaunchKernelGGL(match_coarse_i8_kernel<NQB>, g, dim3(256), lds, s, w.g8, w.g8_scale, N, F, w.tilemax, tiles, q32, w.wgmax, w.ctl, w.qkey);
 }
 static void launch_coarse_i8(const ScreenScratch &w, int N, const float *q32, int F, int tiles, hipStream_t s) {
-    if (F <= 32) launch_coarse_i8_t<1>(w, N, q32, F, tiles, s);
-    else if (F <= 64) launch_coarse_i8_t<2>(w, N, q32, F, tiles, s);
-    else launch_coarse_i8_t<4>(w, N, q32, F, tiles, s);
+    if (F <= 32) return launch_coarse_i8_t<1>(w, N, q32, F, tiles, s);
+    if (F <= 64) return launch_coarse_i8_t<2>(w, N, q32, F, tiles, s);
+    // (the 2 x 2 wave tiling below halves the LDS reads and doubles the widening: 179 us against 163 for the 1 x 4 tiling - tuning switch only)
+    static const bool x4 = frt_tuning_env("FRT_MATCH_I8X4") && frt_tuning_env("FRT_MATCH_I8X4")[0] == '1';
+    if (!x4) return launch_coarse_i8_t<4>(w, N, q32, F, tiles, s);
+    const size_t lds = (size_t)128 * (512 + 8) * sizeof(half_t);
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&match_coarse_i8x4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 g(tiles < COARSE_WG ? tiles : COARSE_WG, (F + 127) / 128);
+    hipLaunchKernelGGL(match_coarse_i8x4_kernel, g, dim3(256), lds, s, w.g8, w.g8_scale, N, F, w.tilemax, tiles, q32, w.wgmax, w.ctl, w.qkey);
 }
 
 template <int D>
