@@ -751,6 +751,9 @@ def main():
                 "match": {"bound": "hbm", "ms": round(mt_ms, 4), "bytes": int(scan_b),
                           "achieved_TBps": round(scan_b / (mt_ms * 1e-3) / 1e12, 3) if mt_ms > 0 else None,
                           "frac_hbm": frac(scan_b, mt_ms, PEAK_HBM_BPS),
+                          # the coarse scan is an fp16 MFMA GEMM [F x 512] x [512 x N]: with the int8 shadow and a full query block it is no longer
+                          # HBM-bound, so its matrix-core fraction is reported beside the HBM one
+                          "flop": 2.0 * 512 * n_rows * F, "frac_mfma": frac(2.0 * 512 * n_rows * F, mt_ms, PEAK_FP16_MFMA_TFLOPS * 1e12),
                           "note": "one scan of the %s per call (%d rows x 512 x %d B)" % ("int8 shadow gallery" if i8 else "gallery", n_rows, scan_bpe)},
                 "note": "serial stage times: HIP events around each stage in 3 extra untimed serial steps; peaks 8 TB/s HBM, 157.3 TF fp32 matrix, 2.5 PF fp16 MFMA"}
         if max(stage_ms.values()) > 0:
