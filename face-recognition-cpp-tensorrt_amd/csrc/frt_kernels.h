@@ -56,7 +56,7 @@ struct ScreenScratch {
     float *wgmax;                 // [coarse workgroups][F] maxima of a workgroup's coarse entries
     void *pairs;                  // (query, tile) candidate pairs
     int pair_cap;
-    int *ctl;                     // [4]: pair count, overflow flag
+    int *ctl;                     // [32] control words: overflow flag, per-sub-list pair counts (kernels_match.hip)
     unsigned long long *qkey;     // [F] packed (similarity, ~row) winners of the scalar re-rank
     // int8 shadow gallery (round 4; fast path, D = 512, fp32-stored galleries): null -> the fp16 shadow is scanned
     const uint8_t *g8;            // fragment-ordered biased bytes (value + 128), gallery8_bytes(N, D)

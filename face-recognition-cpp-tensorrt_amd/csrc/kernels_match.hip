@@ -17,6 +17,8 @@
 
 #include "frt_kernels.h"
 
+constexpr int CTL_WORDS = 32;  // control words of the fast screened path (cleared by the coarse scan; layout at CTL_OVERFLOW below)
+
 #include <limits.h>
 
 namespace {
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restr
     const int r = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.y * 128;
     if (ctl && blockIdx.x == 0 && blockIdx.y == 0) {
-        if (tid < 4) ctl[tid] = 0;
+        if (tid < CTL_WORDS) ctl[tid] = 0;
         for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
     }
     for (int i = tid; i < 128 * (D / 8); i += 256) {
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
     const int r = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.y * (32 * NQB);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (tid < 4) ctl[tid] = 0;
+        if (tid < CTL_WORDS) ctl[tid] = 0;
         for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
     }
     for (int i = tid; i < 32 * NQB * (D / 8); i += 256) {
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256) void match_coarse_i8x4_kernel(const uint8_t *_
     const int rb = wave >> 1, qh = wave & 1;
     const int q0 = blockIdx.y * 128;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (tid < 4) ctl[tid] = 0;
+        if (tid < CTL_WORDS) ctl[tid] = 0;
         for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
     }
     for (int i = tid; i < 128 * (D / 8); i += 256) {
@@ -956,7 +958,10 @@ struct MatchPair {
     int q, tile;  // tile: bits 0 - 27 the 128-row tile, bits 28 - 31 which of its four 32-row blocks are inside the band
 };
 constexpr int PAIR_TILE_MASK = (1 << 28) - 1;
-constexpr int CTL_COUNT = 0, CTL_OVERFLOW = 1;
+// ctl words: [1] overflow flag, [CTL_SEG0 + s] number of pairs in sub-list s.  The pair list is SEL_SEG sub-lists of pair_cap / SEL_SEG
+// entries, one per tile segment (= blockIdx.x of the selection): 1 400 increments of ONE counter cost 35 us of atomics (queries that match
+// nothing, int8 band), sixteen counters share them out
+constexpr int CTL_OVERFLOW = 1, CTL_SEG0 = 4;
 constexpr int FB_BLOCKS = 128;  // workgroups of the gated fallback scan (it returns at once in the normal case: keep the empty launch small)
 
 __device__ __forceinline__ unsigned mono_bits(float f) {
@@ -1020,12 +1025,13 @@ __global__ __launch_bounds__(256) void match_select_pairs_kernel(const float *__
         const unsigned long long bal = __ballot(mask != 0u);
         if (bal) {
             const int first = __ffsll((long long)bal) - 1;
+            const int sub_cap = pair_cap / SEL_SEG;
             int base = 0;
-            if (lane == first) base = atomicAdd(&ctl[CTL_COUNT], __popcll(bal));
+            if (lane == first) base = atomicAdd(&ctl[CTL_SEG0 + seg], __popcll(bal));
             base = __shfl(base, first);
             if (mask) {
                 const int i = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (i < pair_cap) pairs[i] = MatchPair{q, (int)((unsigned)t | (mask << 28))};
+                if (i < sub_cap) pairs[seg * sub_cap + i] = MatchPair{q, (int)((unsigned)t | (mask << 28))};
                 else ctl[CTL_OVERFLOW] = 1;
             }
         }
@@ -1045,11 +1051,14 @@ __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__res
     __shared__ float rv[2];
     __shared__ int ri[2];
     const int tid = threadIdx.x;
-    int count = ctl[CTL_COUNT];
     if (ctl[CTL_OVERFLOW]) return;  // the exact full scan answers this call
-    if (count > pair_cap) count = pair_cap;
-    for (int p = blockIdx.x; p < count; p += gridDim.x) {
-        const MatchPair pr = pairs[p];
+    const int sub_cap = pair_cap / SEL_SEG;
+    int maxc = 0;
+    for (int sgi = 0; sgi < SEL_SEG; ++sgi) maxc = max(maxc, min(ctl[CTL_SEG0 + sgi], sub_cap));
+    for (int p = blockIdx.x; p < maxc * SEL_SEG; p += gridDim.x) {  // virtual index over the sub-lists, interleaved
+        const int sgi = p % SEL_SEG, pi_ = p / SEL_SEG;
+        if (pi_ >= ctl[CTL_SEG0 + sgi]) continue;  // (block-uniform)
+        const MatchPair pr = pairs[sgi * sub_cap + pi_];
         __syncthreads();  // the previous pair's readers of qs / rv are done
         for (int k = tid * 4; k < D; k += 512) *reinterpret_cast<floatx4 *>(qs + k) = *reinterpret_cast<const floatx4 *>(E + (long)pr.q * D + k);
         __syncthreads();
@@ -1325,10 +1334,10 @@ void launch_match_topk(const float *gallery, const half_t *g16, int N, int D, co
             const float *ps = j ? sim_out + (j - 1) : nullptr;
             const int32_t *pi = j ? idx_out + (j - 1) : nullptr;
             if (gallery)
-                hipLaunchKernelGGL((match_rerank_pairs_kernel<float>), dim3(1024), dim3(128), (size_t)D * sizeof(float), s, gallery, N, D, queries,
+                hipLaunchKernelGGL((match_rerank_pairs_kernel<float>), dim3(2048), dim3(128), (size_t)D * sizeof(float), s, gallery, N, D, queries,
                                    reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, ps, pi, k, row_offset);
             else
-                hipLaunchKernelGGL((match_rerank_pairs_kernel<half_t>), dim3(1024), dim3(128), (size_t)D * sizeof(float), s, g16, N, D, queries,
+                hipLaunchKernelGGL((match_rerank_pairs_kernel<half_t>), dim3(2048), dim3(128), (size_t)D * sizeof(float), s, g16, N, D, queries,
                                    reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, ps, pi, k, row_offset);
             // pair-list overflow: the unscreened exact scan answers this pass instead (gated on the flag; see the top-1 path)
             const int fb = partial_blocks < FB_BLOCKS ? partial_blocks : FB_BLOCKS;
@@ -1386,7 +1395,7 @@ void launch_match_top1_screened(const float *gallery, const half_t *g16, int N, 
         // (with F > 128 every query block y writes its own columns of wgmax: [n_wg][F])
         hipLaunchKernelGGL(match_select_pairs_kernel, dim3(SEL_SEG, F), dim3(256), 0, s, w.tilemax, tiles, w.wgmax, n_wg, F, queries, D, gmax_norm,
                            reinterpret_cast<MatchPair *>(w.pairs), w.pair_cap, w.ctl, (const float *)nullptr, i8 ? 0.7e-3f : 1.2e-3f, i8 ? w.gerr : 0.f);
-        const int rr_grid = 1024;
+        const int rr_grid = 2048;  // (one pair per workgroup up to 2 048 pairs: the re-rank is one 512-long dependent fma chain per row, i.e. per-pair latency)
         if (gallery)
             hipLaunchKernelGGL((match_rerank_pairs_kernel<float>), dim3(rr_grid), dim3(128), (size_t)D * sizeof(float), s, gallery, N, D, queries,
                                reinterpret_cast<const MatchPair *>(w.pairs), w.pair_cap, w.ctl, w.qkey, (const float *)nullptr, (const int32_t *)nullptr, 1, 0);
