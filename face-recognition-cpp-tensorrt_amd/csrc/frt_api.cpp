@@ -414,6 +414,24 @@ void frt_detector::build(const frt::Blob &b) {
                 {
                     const std::vector<uint16_t> ph = pack_pw_split(w2, l.cin, l.cout);
                     if (!ph.empty()) o.dw.wph = reinterpret_cast<const half_t *>(arena.upload(ph));
+                    if (!ph.empty() && l.cout % 32 == 0) {  // the operands of dwpw_wave_kernel (kernels_det_wave.hip)
+                        std::vector<float> wp2((size_t)l.cin * 10, 0.f);  // [Cin/2][10][2]: taps 0-8, bias; the channel pair interleaved
+                        for (int ci = 0; ci < l.cin; ++ci) {
+                            for (int t = 0; t < 9; ++t) wp2[(size_t)(ci / 2) * 20 + 2 * t + (ci & 1)] = w[(size_t)ci * 9 + t];
+                            wp2[(size_t)(ci / 2) * 20 + 18 + (ci & 1)] = bias[ci];
+                        }
+                        std::vector<uint16_t> pf(ph.size());
+                        const int ng = l.cin / 16, ncb = l.cout / 32;
+                        for (int gq = 0; gq < ng; ++gq)
+                            for (int cb = 0; cb < ncb; ++cb)
+                                for (int part = 0; part < 2; ++part)
+                                    for (int ln = 0; ln < 64; ++ln)
+                                        for (int j = 0; j < 8; ++j)
+                                            pf[((((size_t)gq * ncb + cb) * 2 + part) * 64 + ln) * 8 + j] =
+                                                ph[((size_t)(cb * 32 + (ln & 31)) * ng + gq) * 32 + part * 16 + 8 * (ln >> 5) + j];
+                        o.dw.wdp = arena.upload(wp2);
+                        o.dw.wpf = reinterpret_cast<const half_t *>(arena.upload(pf));
+                    }
                 }
                 ops.push_back(o);
                 flops_per_frame += 2.0 * oh * ow * (9.0 * l.cin + (double)l.cin * l.cout);
@@ -1598,6 +1616,12 @@ struct frt_pipeline {
         crops_req = nullptr;
         const int akey = (align ? 1 : 0) | (crops_out ? 2 : 0);
         run_part(GraphKey{0, frames_dev, nullptr, nullptr, n, slot, akey, 0u}, ds, [&](hipStream_t st) {
+#ifdef FRT_TUNING
+            // timing build: FRT_PIPE_ABLATE bit 0 = no detector network after the first calls (post-processing re-reads the old head outputs),
+            // bit 1 = no recogniser network, bit 2 = no match: what each stage costs the pipelined step (profiles/r04s_stage_ablation.txt)
+            static const int pipe_abl = getenv("FRT_PIPE_ABLATE") ? atoi(getenv("FRT_PIPE_ABLATE")) : 0;
+            if (!(pipe_abl & 1) || call < 8u)
+#endif
             det->forward_frames(frames_dev, n, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, st);
             det->postprocess(n, st, slot_boxes[slot], slot_nout[slot], slot_landmarks[slot]);  // straight into this call's slot
         });
@@ -1622,6 +1646,10 @@ struct frt_pipeline {
                 launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, boxes, nout, max_faces,
                                   F, 0, 112, 112, crops_out, chw, valid, st);
             }
+#ifdef FRT_TUNING
+            static const int pipe_abl = getenv("FRT_PIPE_ABLATE") ? atoi(getenv("FRT_PIPE_ABLATE")) : 0;
+            if (!(pipe_abl & 2) || call < 8u)
+#endif
             for (int f0 = 0; f0 < F; f0 += emb->max_batch) {
                 const int nf = std::min(emb->max_batch, F - f0);
                 emb->forward_set(eset, chw + (size_t)f0 * 3 * 112 * 112, nf, valid + f0, emb_slot + (size_t)f0 * 512, st);
@@ -1639,6 +1667,10 @@ struct frt_pipeline {
         // (the serial branch too: an object-level frt_matcher_top1_dev / topk_dev on another stream shares d_partial / the pair lists with this stage)
         if (mat && mat->busy) HIPCHK(hipStreamWaitEvent(ms, mat->ev_busy, 0));
         run_part(GraphKey{2, nullptr, results_dev, embeds_dev, n, slot, akey, gen}, ms, [&](hipStream_t st) {
+#ifdef FRT_TUNING
+            static const int pipe_abl = getenv("FRT_PIPE_ABLATE") ? atoi(getenv("FRT_PIPE_ABLATE")) : 0;
+            if (!(pipe_abl & 4) || call < 8u)
+#endif
             if (have_gallery) mat->top1_dev(emb_slot, F, d_idx, d_sim, st);
             {
                 ProfScope ps(2, "pack_results", (double)F, st);

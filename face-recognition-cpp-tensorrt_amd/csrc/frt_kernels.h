@@ -140,7 +140,10 @@ struct DwPwArgs {
     float *tmp;             // scratch [B][Cin][Ho][Wo] for the split depthwise -> pointwise path (null: always fused)
     const float *wd12;      // depthwise weights packed [Cin][12] = 9 taps, bias, 2 pad (matrix-core kernel); null: scalar kernels only
     const half_t *wph;      // pointwise weights as fp16 hi/lo split [Cout][Cin/16][hi16 | lo16] (Cin % 16 == 0); null: fp32 MFMA path
+    const float *wdp;       // depthwise weights of channel pairs [Cin/2][10][2] (kernels_det_wave.hip); null: that kernel does not apply
+    const half_t *wpf;      // the split pointwise weights in fragment order [Cin/16][Cout/32][hi|lo][64][8] (kernels_det_wave.hip)
 };
+bool launch_dwpw_wave(const DwPwArgs &a, hipStream_t s);  // one wave = 64 pixels x all channels (round 4); false: shape not covered
 void launch_dwpw(const DwPwArgs &a, hipStream_t s);
 bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s);  // false: shape not covered, use the scalar kernels
 struct Conv3Args {

@@ -484,6 +484,7 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
     // everything else is faster here (16->32/2: 145 vs 100, 64->64 @80^2: 169 vs 70, 128->128 @40^2: 77 vs 59).
     // (A persistent, 3-stage software-pipelined variant of this kernel was also tried: slower on every block - fewer, fatter
     // waves hide the load latency worse than three small resident workgroups per CU do.)
+    if (launch_dwpw_wave(a, s)) return true;
     if (a.Cout <= 32 && a.Cin <= 32 && a.stride == 1 && !frt_tuning_env("FRT_DWPW_FORCE_MFMA")) return false;
     const long total = (long)a.B * a.Ho * a.Wo;
     const bool big = a.Wo >= 64 && (a.Wo % 16) == 0 && (a.Ho % 8) == 0;
