@@ -202,23 +202,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_
     // use sits behind drain(), which names the registers.  A step's reads are issued one step ahead of its arithmetic.
     static_assert(G::CHB / 4 + 2 < 256, "ds_read2_b32 offsets are 8 bits of dwords");
     floatx2 tv[2][2][9];  // [stage = step parity][pair of the step][tap]
-    auto issue_taps = [&](auto qc, floatx2(&v)[9]) {  // q = pair index over the whole channel range
-        constexpr int q = decltype(qc)::value;
+    auto issue_taps3 = [&](auto qc, auto dc, floatx2(&v)[9]) {  // q = pair index over the whole channel range, d = tap row (three reads)
+        constexpr int q = decltype(qc)::value, d = decltype(dc)::value;
         constexpr int c = q / (G::CPC / 2), pr = q % (G::CPC / 2);
-        constexpr int boff = (c % G::NBUF) * G::CHUNKB + 2 * pr * G::CHB;
-        const unsigned b0 = rb + boff, b1 = rb + boff + G::RS * 4, b2 = rb + boff + 2 * G::RS * 4;
-        asm volatile("ds_read2_b32 %0, %9 offset0:0 offset1:%12\n"
-                     "ds_read2_b32 %1, %9 offset0:1 offset1:%13\n"
-                     "ds_read2_b32 %2, %9 offset0:2 offset1:%14\n"
-                     "ds_read2_b32 %3, %10 offset0:0 offset1:%12\n"
-                     "ds_read2_b32 %4, %10 offset0:1 offset1:%13\n"
-                     "ds_read2_b32 %5, %10 offset0:2 offset1:%14\n"
-                     "ds_read2_b32 %6, %11 offset0:0 offset1:%12\n"
-                     "ds_read2_b32 %7, %11 offset0:1 offset1:%13\n"
-                     "ds_read2_b32 %8, %11 offset0:2 offset1:%14"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8])
-                     : "v"(b0), "v"(b1), "v"(b2), "n"(G::CHB / 4), "n"(G::CHB / 4 + 1), "n"(G::CHB / 4 + 2)
+        constexpr int boff = (c % G::NBUF) * G::CHUNKB + 2 * pr * G::CHB + d * G::RS * 4;
+        const unsigned b0 = rb + boff;
+        asm volatile("ds_read2_b32 %0, %3 offset0:0 offset1:%4\n"
+                     "ds_read2_b32 %1, %3 offset0:1 offset1:%5\n"
+                     "ds_read2_b32 %2, %3 offset0:2 offset1:%6"
+                     : "=&v"(v[3 * d]), "=&v"(v[3 * d + 1]), "=&v"(v[3 * d + 2])
+                     : "v"(b0), "n"(G::CHB / 4), "n"(G::CHB / 4 + 1), "n"(G::CHB / 4 + 2)
                      : "memory");
+    };
+    auto issue_taps = [&](auto qc, floatx2(&v)[9]) {
+        issue_taps3(qc, std::integral_constant<int, 0>{}, v);
+        issue_taps3(qc, std::integral_constant<int, 1>{}, v);
+        issue_taps3(qc, std::integral_constant<int, 2>{}, v);
     };
     // The step's wait names ALL eighteen tap registers: a register the wait does not name is, to the compiler, ready since the asm that
     // issued its read, and it did move such registers while the read was in flight (wrong sums in one build, right ones in the next).
@@ -330,33 +329,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_
                 for (int kq = 0; kq < 4; ++kq) bias4[cb][kq] = *reinterpret_cast<const floatx4 *>(a.bp + (cob + cb) * 32 + 8 * kq + 4 * hi);
         }
         WSTAMP(7 + st);
-        // two independent fma chains (one per channel pair) in three pieces, a third of the step's MFMAs (the PREVIOUS group's) behind each;
-        // the next step's tap reads go out after the first piece (which holds the wait for this step's)
+        // Two independent fma chains (one per channel pair), nothing between them: v_pk_fma_f32 does NOT issue under a running MFMA of the
+        // same wave (tools/ubench/mfma_pk_overlap.hip: MFMA 35 cycles, six v_pk_fma_f32 37, together 82), LDS reads and plain VALU do (MFMA +
+        // six ds_read2_b32: 96 = the reads alone; + six v_fma_f32: 44).  So the step's MFMAs (the PREVIOUS group's) go between the six
+        // three-read pieces of the next step's tap reads, and the fp16 split below is written without packed instructions.
         floatx2 oa, ob;
         landed(tv[st & 1][0], tv[st & 1][1]);
         chain3(std::integral_constant<int, 0>{}, oa, ob, tv[st & 1][0], tv[st & 1][1]);
-        if constexpr (st + 1 < G::NSTEP) {
-            issue_taps(std::integral_constant<int, 2 * st + 2>{}, tv[(st + 1) & 1][0]);
-            issue_taps(std::integral_constant<int, 2 * st + 3>{}, tv[(st + 1) & 1][1]);
-        }
-        if constexpr (g > 0) static_for<0, MF_STEP / 3>([&](auto mc) { mfma_n(std::integral_constant<int, g - 1>{}, std::integral_constant<int, k * MF_STEP + decltype(mc)::value>{}); });
-        __builtin_amdgcn_sched_barrier(0);
         chain3(std::integral_constant<int, 1>{}, oa, ob, tv[st & 1][0], tv[st & 1][1]);
-        if constexpr (g > 0)
-            static_for<MF_STEP / 3, 2 * MF_STEP / 3>([&](auto mc) { mfma_n(std::integral_constant<int, g - 1>{}, std::integral_constant<int, k * MF_STEP + decltype(mc)::value>{}); });
-        __builtin_amdgcn_sched_barrier(0);
         chain3(std::integral_constant<int, 2>{}, oa, ob, tv[st & 1][0], tv[st & 1][1]);
         if constexpr (st + 1 < G::NSTEP) load_w(std::integral_constant<int, st + 1>{});
-        if constexpr (g > 0)
-            static_for<2 * MF_STEP / 3, MF_STEP>([&](auto mc) { mfma_n(std::integral_constant<int, g - 1>{}, std::integral_constant<int, k * MF_STEP + decltype(mc)::value>{}); });
+        static_for<0, 6>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (g > 0)
+                static_for<i * MF_STEP / 6, (i + 1) * MF_STEP / 6>(
+                    [&](auto mc) { mfma_n(std::integral_constant<int, g - 1>{}, std::integral_constant<int, k * MF_STEP + decltype(mc)::value>{}); });
+            if constexpr (st + 1 < G::NSTEP) issue_taps3(std::integral_constant<int, 2 * st + 2 + i / 3>{}, std::integral_constant<int, i % 3>{}, tv[(st + 1) & 1][i / 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
             floatx2 o = pr ? ob : oa;
             o[0] = fmaxf(o[0], 0.f);
             o[1] = fmaxf(o[1], 0.f);
             const half2v h = __builtin_convertvector(o, half2v);
-            const floatx2 back = __builtin_convertvector(h, floatx2);
-            const half2v l = __builtin_convertvector(o - back, half2v);
+            float l0 = (float)h[0], l1 = (float)h[1];
+            asm("v_sub_f32 %0, %1, %0" : "+v"(l0) : "v"(o[0]));  // (asm: the compiler would fuse the two subtractions into v_pk_add_f32)
+            asm("v_sub_f32 %0, %1, %0" : "+v"(l1) : "v"(o[1]));
+            const half2v l = __builtin_convertvector(floatx2{l0, l1}, half2v);
             hp[2 * k + pr] = __builtin_bit_cast(unsigned, h);
             lp[2 * k + pr] = __builtin_bit_cast(unsigned, l);
         }
