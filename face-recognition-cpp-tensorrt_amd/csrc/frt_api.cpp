@@ -195,6 +195,7 @@ struct frt_detector {
         HeadArgs hd[3];
     };
     float *d_tmp = nullptr;  // depthwise intermediate of the split conv_dw path
+    float *d_wave_zeros = nullptr;  // zeros for dwpw_wave_kernel (input rows outside the image)
     std::vector<Op> ops;
     double flops_per_frame = 0;
     uint8_t *d_frames = nullptr;
@@ -429,6 +430,11 @@ void frt_detector::build(const frt::Blob &b) {
                                         for (int j = 0; j < 8; ++j)
                                             pf[((((size_t)gq * ncb + cb) * 2 + part) * 64 + ln) * 8 + j] =
                                                 ph[((size_t)(cb * 32 + (ln & 31)) * ng + gq) * 32 + part * 16 + 8 * (ln >> 5) + j];
+                        if (!d_wave_zeros) {
+                            d_wave_zeros = arena.alloc<float>(dwpw_wave_zero_bytes() / 4);
+                            HIPCHK(hipMemset(d_wave_zeros, 0, dwpw_wave_zero_bytes()));
+                        }
+                        o.dw.zeros = d_wave_zeros;
                         o.dw.wdp = arena.upload(wp2);
                         o.dw.wpf = reinterpret_cast<const half_t *>(arena.upload(pf));
                     }

@@ -142,7 +142,9 @@ struct DwPwArgs {
     const half_t *wph;      // pointwise weights as fp16 hi/lo split [Cout][Cin/16][hi16 | lo16] (Cin % 16 == 0); null: fp32 MFMA path
     const float *wdp;       // depthwise weights of channel pairs [Cin/2][10][2] (kernels_det_wave.hip); null: that kernel does not apply
     const half_t *wpf;      // the split pointwise weights in fragment order [Cin/16][Cout/32][hi|lo][64][8] (kernels_det_wave.hip)
+    const float *zeros;     // dwpw_wave_zero_bytes() of zeros (kernels_det_wave.hip: the source of input rows outside the image)
 };
+size_t dwpw_wave_zero_bytes();
 bool launch_dwpw_wave(const DwPwArgs &a, hipStream_t s);  // one wave = 64 pixels x all channels (round 4); false: shape not covered
 void launch_dwpw(const DwPwArgs &a, hipStream_t s);
 bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s);  // false: shape not covered, use the scalar kernels

@@ -37,21 +37,28 @@ __device__ __forceinline__ int xcd_tile(int nblocks) {  // block b runs on XCD b
     return (xcd < brem ? xcd * (bq + 1) : brem * (bq + 1) + (xcd - brem) * bq) + slot;
 }
 
-template <int CIN, int NCB, int W, int STRIDE>
+template <int CIN, int NCB, int H, int W, int STRIDE, int NBUF_>
 struct WaveGeom {
-    static constexpr int WO = W / STRIDE;                    // output row length
+    static constexpr int WO = W / STRIDE, HO = H / STRIDE;   // output map
+    static constexpr int HW = H * W, HOWO = HO * WO;
     static constexpr int SPAN = (WO + 62) / WO + 1;          // output rows 64 consecutive pixels can touch
     static constexpr int ROWS = STRIDE * (SPAN - 1) + 3;     // input rows behind them
-    static constexpr int SL = W / 4 + 1;                     // 16-byte slots per LDS row: one zero slot + the row
-    static constexpr int RS = SL * 4;                        // LDS row stride in floats
-    static constexpr int NDI = (ROWS * SL + 63) / 64;        // DMA instructions per channel
-    static constexpr int CHB = ROWS * SL * 16;               // LDS bytes per channel (the lanes behind the last slot are masked off)
+    static constexpr int SL = W / 4 + 1;                     // 16-byte slots per LDS row of one channel: one zero slot + the row
     static constexpr int CPC = 8;                            // channels per DMA chunk
-    static constexpr int LA = 3, NBUF = LA + 1;              // chunks in flight ahead of the one being consumed
-    static constexpr int CHUNKB = CPC * CHB;
-    static constexpr int NCHUNK = CIN / CPC, NG = CIN / 16;
+    static constexpr int SPC = CPC / 4;                      // steps (of 4 channels) per chunk
+    // LDS layout of a chunk: [input row][channel of the chunk][slot] - the two channels of a pair sit CHS bytes apart (the second offset of
+    // ds_read2_b32 reaches 255 dwords), and one DMA instruction covers 64 consecutive (channel, slot) positions of ONE input row
+    static constexpr int CHS = SL * 16;
+    // (+ W % 32 dwords: CPC * SL * 4 dwords is a multiple of the 32 banks; with the pad a lane's bank is its pixel index + const, rows included)
+    static constexpr int ROWB = CPC * CHS + (W % 32) * 4;
+    static constexpr int CHUNKB = ROWS * ROWB;
+    static constexpr int NDR = (CPC * SL + 63) / 64;         // DMA instructions per input row of a chunk
+    static constexpr int DMAOPS = ROWS * NDR;
+    static constexpr int NBUF = NBUF_, LA = NBUF_ - 1;       // chunks in flight ahead of the one being consumed
+    static constexpr int NCHUNK = CIN / CPC, NG = CIN / 16, NSTEP = CIN / 4;
     static constexpr int NA = 2 * NCB;                       // weight-fragment loads per 16-channel group
     static constexpr int LDS_BYTES = NBUF * CHUNKB + 16;
+    static_assert(SPC == 2 && CIN % 16 == 0 && CHS / 4 + 2 < 256 && LA >= 2, "shape not covered");
     // VMEM retires in order: "at most n operations outstanding" with n = the operations issued after the last DMA of chunk c means chunk c
     // has been delivered.  Issue order (a step = two channel pairs = 4 channels, two steps per chunk, four per 16-channel group):
     //   prologue: DMA(0 .. LA-1), A(0);   step s: [s even: DMA(s/2 + LA) at the top] ... [s % 4 == 3: A(s/4 + 1) at the end]
@@ -59,8 +66,6 @@ struct WaveGeom {
     // chunk (issued in step 2c - 1): MEASURED, a ds_read issued right behind "s_waitcnt vmcnt" can still see the old LDS contents (the
     // counter drops when the data leaves for LDS, not when it is readable); 128 cycles of s_sleep were enough, a step is 300 - 500.
     // Chunk 0 is waited for right after the prologue, followed by such a sleep.
-    static constexpr int NSTEP = CIN / 4;
-    static constexpr int DMAOPS = CPC * NDI;
     static constexpr int younger(int cw) {
         const int at_step = cw == 0 ? -1 : 2 * cw - 2;  // the wait follows the DMA issue of this step (-1: the prologue)
         int n = 0;
@@ -106,6 +111,7 @@ struct WaveArgs {  // (the few fields of DwPwArgs this kernel reads: scalar regi
     const float *in; float *out;
     const float *bp, *wdp;
     const half_t *wpf;
+    const float *zeros;  // >= ((CPC - 1) * H * W + W) * 4 + 16 bytes of zeros: the source of input rows outside the image
     int relu;
 #ifdef WAVE_STAMP
     long long *stamps;
@@ -117,43 +123,52 @@ struct WaveArgs {  // (the few fields of DwPwArgs this kernel reads: scalar regi
 #define WSTAMP(i) do { } while (0)
 #endif
 
-template <int CIN, int COUT, int NCB, int H, int W, int STRIDE>
+template <int CIN, int COUT, int NCB, int H, int W, int STRIDE, int NBUF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_wave_kernel(WaveArgs a) {
-    using G = WaveGeom<CIN, NCB, W, STRIDE>;
+    using G = WaveGeom<CIN, NCB, H, W, STRIDE, NBUF>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
-    constexpr int HW = H * W, HoWo = (H / STRIDE) * G::WO;  // (compile-time: the 128 DMA source offsets are immediates, not 128 live scalar pairs)
-    const int tpi = (HoWo + 63) >> 6;  // tiles per image
+    constexpr int HW = G::HW, HoWo = G::HOWO;  // (compile-time: the DMA source offsets are immediates, not live scalar pairs)
+    constexpr int tpi = (HoWo + 63) >> 6;      // tiles per image (the last one may be partial)
     const int lid = xcd_tile(gridDim.x);
     const int b = lid / tpi, p0 = (lid - b * tpi) * 64;
     const int y_first = p0 / G::WO;
     const int cob = (int)blockIdx.y * NCB;  // first 32-cout block of this wave
 
     WSTAMP(0);
-    // ---- zero the wave's LDS region once (pad slots and rows outside the image stay zero: the DMA never writes them)
+    // ---- zero the wave's LDS region once (the pad slots stay zero: the DMA never writes them)
     for (int o = lane * 16; o < G::LDS_BYTES; o += 1024) *reinterpret_cast<floatx4 *>(lds + o) = floatx4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    // ---- DMA role: lane + 64 * i = (LDS row j, slot s); row j = input row y_first * STRIDE - 1 + j; slot 0 = the zero pad
-    const char *dsrc[G::NDI];
-    bool dval[G::NDI];
+    // ---- DMA role: instruction i of an input row covers (channel k, slot s) = divmod(lane + 64 i, SL); slot 0 is the zero pad (masked off).
+    //      Rows outside the image come from a buffer of zeros - same number of DMA instructions for every wave (the waits count them)
+    unsigned voff[G::NDR];
+    bool lval[G::NDR];
 #pragma unroll
-    for (int i = 0; i < G::NDI; ++i) {
-        const int q = lane + 64 * i, j = q / G::SL, s = q - j * G::SL;
+    for (int i = 0; i < G::NDR; ++i) {
+        const int q = lane + 64 * i, k = q / G::SL, sl = q - k * G::SL;
+        lval[i] = q < G::CPC * G::SL && sl >= 1;
+        voff[i] = lval[i] ? (unsigned)((k * HW + (sl - 1) * 4) * 4) : 0u;
+    }
+    const char *inb = reinterpret_cast<const char *>(a.in + (long)b * CIN * HW);
+    const char *zer = reinterpret_cast<const char *>(a.zeros);
+    int rowoff[G::ROWS];  // byte offset of LDS row j's image row inside a channel plane, or -1
+#pragma unroll
+    for (int j = 0; j < G::ROWS; ++j) {
         const int iy = y_first * STRIDE - 1 + j;
-        dval[i] = j < G::ROWS && s >= 1 && iy >= 0 && iy < H;
-        dsrc[i] = reinterpret_cast<const char *>(a.in + (long)b * CIN * HW) + (dval[i] ? (iy * W + (s - 1) * 4) * 4 : 0);
+        rowoff[j] = (iy >= 0 && iy < H) ? iy * W * 4 : -1;
     }
     auto dma_chunk = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
 #pragma unroll
-        for (int i = 0; i < G::NDI; ++i)
-            if (dval[i]) {
+        for (int i = 0; i < G::NDR; ++i)
+            if (lval[i]) {
 #pragma unroll
-                for (int k = 0; k < G::CPC; ++k)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dsrc[i] + (long)(c * G::CPC + k) * HW * 4),
-                                                     (__attribute__((address_space(3))) void *)(lds + (c % G::NBUF) * G::CHUNKB + k * G::CHB + i * 1024), 16, 0,
-                                                     0);
+                for (int j = 0; j < G::ROWS; ++j) {
+                    const char *base = rowoff[j] >= 0 ? inb + ((long)c * G::CPC * HW * 4 + rowoff[j]) : zer;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + voff[i]),
+                                                     (__attribute__((address_space(3))) void *)(lds + (c % G::NBUF) * G::CHUNKB + j * G::ROWB + i * 1024), 16, 0, 0);
+                }
             }
     };
 
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_
     const int pl = min(p0 + lane, HoWo - 1);
     const int oy = pl / G::WO, ox = pl - oy * G::WO;
     const unsigned rb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds +
-                        (unsigned)((((oy - y_first) * STRIDE) * G::RS + ox * STRIDE + 3) * 4);  // LDS byte address of tap (0, 0) in channel 0 of buffer 0
+                        (unsigned)(((oy - y_first) * STRIDE) * G::ROWB + (ox * STRIDE + 3) * 4);  // LDS byte address of tap (0, 0), channel 0 of buffer 0
 
     // ---- pointwise weights: fragment stream.  The MFMAs of group g are issued under the stencil arithmetic of group g + 1, so A(g) stays
     //      live for two groups: two register sets, A(g + 1) requested when the last MFMA of group g - 1 has been issued
@@ -200,18 +215,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_
     // register pair = the first source of v_pk_fma_f32.  (Left to the compiler, the vectoriser pairs the two neighbouring taps of ONE
     // channel instead and 1 000 v_mov re-pair them.)  The compiler does not know that the results of an asm read are still in flight: every
     // use sits behind drain(), which names the registers.  A step's reads are issued one step ahead of its arithmetic.
-    static_assert(G::CHB / 4 + 2 < 256, "ds_read2_b32 offsets are 8 bits of dwords");
     floatx2 tv[2][2][9];  // [stage = step parity][pair of the step][tap]
     auto issue_taps3 = [&](auto qc, auto dc, floatx2(&v)[9]) {  // q = pair index over the whole channel range, d = tap row (three reads)
         constexpr int q = decltype(qc)::value, d = decltype(dc)::value;
         constexpr int c = q / (G::CPC / 2), pr = q % (G::CPC / 2);
-        constexpr int boff = (c % G::NBUF) * G::CHUNKB + 2 * pr * G::CHB + d * G::RS * 4;
+        constexpr int boff = (c % G::NBUF) * G::CHUNKB + 2 * pr * G::CHS + d * G::ROWB;
         const unsigned b0 = rb + boff;
         asm volatile("ds_read2_b32 %0, %3 offset0:0 offset1:%4\n"
                      "ds_read2_b32 %1, %3 offset0:1 offset1:%5\n"
                      "ds_read2_b32 %2, %3 offset0:2 offset1:%6"
                      : "=&v"(v[3 * d]), "=&v"(v[3 * d + 1]), "=&v"(v[3 * d + 2])
-                     : "v"(b0), "n"(G::CHB / 4), "n"(G::CHB / 4 + 1), "n"(G::CHB / 4 + 2)
+                     : "v"(b0), "n"(G::CHS / 4), "n"(G::CHS / 4 + 1), "n"(G::CHS / 4 + 2)
                      : "memory");
     };
     auto issue_taps = [&](auto qc, floatx2(&v)[9]) {
@@ -405,34 +419,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_
     WSTAMP(5);
 }
 
-template <int CIN, int COUT, int NCB, int H, int W, int STRIDE>
+template <int CIN, int COUT, int NCB, int H, int W, int STRIDE, int NBUF>
 void launch_wave(const DwPwArgs &a, hipStream_t s) {
-    using G = WaveGeom<CIN, NCB, W, STRIDE>;
+    using G = WaveGeom<CIN, NCB, H, W, STRIDE, NBUF>;
     static bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_wave_kernel<CIN, COUT, NCB, H, W, STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dwpw_wave_kernel<CIN, COUT, NCB, H, W, STRIDE, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   G::LDS_BYTES);
         return true;
     }();
     (void)once;
-    const int tpi = (a.Ho * a.Wo + 63) / 64;
+    constexpr int tpi = (G::HOWO + 63) / 64;
 #ifdef WAVE_STAMP
-    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.relu, reinterpret_cast<long long *>(a.tmp)};
+    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.zeros, a.relu, reinterpret_cast<long long *>(a.tmp)};
 #else
-    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.relu};
+    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.zeros, a.relu};
 #endif
-    hipLaunchKernelGGL((dwpw_wave_kernel<CIN, COUT, NCB, H, W, STRIDE>), dim3((unsigned)(a.B * tpi), COUT / (32 * NCB)), dim3(64), G::LDS_BYTES, s, w);
+    hipLaunchKernelGGL((dwpw_wave_kernel<CIN, COUT, NCB, H, W, STRIDE, NBUF>), dim3((unsigned)(a.B * tpi), COUT / (32 * NCB)), dim3(64), G::LDS_BYTES, s, w);
 }
 
 }  // namespace
 
-// true: launched.  Shapes covered: the five 128 -> 128 blocks at 40x40 of a 640x640 input
+size_t dwpw_wave_zero_bytes() { return (size_t)1 << 20; }  // covers ((CPC - 1) * H * W + W) * 4 + 16 for every shape below
+
+// true: launched.  Shapes covered (640x640 detector input): the five 128 -> 128 blocks at 40x40, 64 -> 64 at 80x80, 256 -> 256 at 20x20
 bool launch_dwpw_wave(const DwPwArgs &a, hipStream_t s) {
     static const bool on = !(frt_tuning_env("FRT_DWPW_WAVE") && frt_tuning_env("FRT_DWPW_WAVE")[0] == '0');
-    if (!on || !a.wdp || !a.wpf || a.add || !a.wd) return false;
+    if (!on || !a.wdp || !a.wpf || !a.zeros || a.add || !a.wd) return false;
     if (a.W != a.Wo * a.stride || (a.stride == 1 ? a.H != a.Ho : a.H != 2 * a.Ho)) return false;
     if ((long)a.B * a.Cin * a.H * a.W * 4 >= (1L << 31)) return false;
-    if (a.stride == 1 && a.Cin == 128 && a.Cout == 128 && a.W == 40 && a.H == 40) {
-        launch_wave<128, 128, 4, 40, 40, 1>(a, s);
+    static const int which = frt_tuning_env("FRT_DWPW_WAVE_SHAPES") ? atoi(frt_tuning_env("FRT_DWPW_WAVE_SHAPES")) : 7;  // bit per shape (A/B measurements)
+    if (a.stride == 1 && a.Cin == 128 && a.Cout == 128 && a.W == 40 && a.H == 40 && (which & 1)) {
+        static const int v = frt_tuning_env("FRT_DWPW_WAVE_V") ? atoi(frt_tuning_env("FRT_DWPW_WAVE_V")) : 0;
+        if (v == 1) launch_wave<128, 128, 2, 40, 40, 1, 3>(a, s);
+        else if (v == 2) launch_wave<128, 128, 2, 40, 40, 1, 4>(a, s);
+        else if (v == 3) launch_wave<128, 128, 4, 40, 40, 1, 3>(a, s);
+        else launch_wave<128, 128, 4, 40, 40, 1, 4>(a, s);
+        return true;
+    }
+    if (a.stride == 1 && a.Cin == 64 && a.Cout == 64 && a.W == 80 && a.H == 80 && (which & 2)) {
+        static const int v = frt_tuning_env("FRT_DWPW_WAVE_V") ? atoi(frt_tuning_env("FRT_DWPW_WAVE_V")) : 0;
+        if (v == 1) launch_wave<64, 64, 1, 80, 80, 1, 3>(a, s);
+        else launch_wave<64, 64, 2, 80, 80, 1, 3>(a, s);
+        return true;
+    }
+    if (a.stride == 1 && a.Cin == 256 && a.Cout == 256 && a.W == 20 && a.H == 20 && (which & 4)) {
+        launch_wave<256, 256, 2, 20, 20, 1, 4>(a, s);  // four waves per pixel tile, 64 output channels each (only 224 tiles at 32 frames)
         return true;
     }
     return false;

@@ -45,7 +45,7 @@ static float h2f(uint16_t u) {
 }
 
 int main(int argc, char **argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 32, C = 128, H = 40, W = 40, Cout = 128;
+    const int B = argc > 1 ? atoi(argv[1]) : 32, C = argc > 2 ? atoi(argv[2]) : 128, H = argc > 3 ? atoi(argv[3]) : 40, W = H, Cout = C;
     const long n = (long)B * C * H * W;
     std::vector<float> in(n), wd(C * 9), bd(C), wp((size_t)C * Cout), bp(Cout);
     srand(1);
@@ -84,6 +84,8 @@ int main(int argc, char **argv) {
     DwPwArgs a{};
     a.in = d_in; a.out = d_out; a.wd = d_wd; a.bd = d_bd; a.wp = d_wp; a.bp = d_bp; a.B = B; a.Cin = C; a.H = H; a.W = W; a.Cout = Cout; a.Ho = H; a.Wo = W;
     a.stride = 1; a.relu = 1; a.wdp = d_wdp; a.wpf = d_wpf;
+    float *d_zero; CK(hipMalloc(&d_zero, dwpw_wave_zero_bytes())); CK(hipMemset(d_zero, 0, dwpw_wave_zero_bytes()));
+    a.zeros = d_zero;
     long long *d_st; CK(hipMalloc(&d_st, 64 * 8)); CK(hipMemset(d_st, 0, 64 * 8));
     a.tmp = reinterpret_cast<float *>(d_st);
     hipLaunchKernelGGL(ref_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_in, d_wd, d_bd, d_wp, d_bp, d_ref, B, C, H, W, Cout);
@@ -102,7 +104,7 @@ int main(int argc, char **argv) {
     if (first >= 0) printf("; first at b=%ld co=%ld y=%ld x=%ld: got %g want %g", first / ((long)Cout * H * W), (first / (H * W)) % Cout, (first / W) % H, first % W, out[first], ref[first]);
     printf("\n");
     if (bad) {
-        long byl[64] = {0}, byc[128] = {0};
+        long byl[64] = {0}, byc[256] = {0};
         for (long i = 0; i < n; ++i) {
             const double d = fabs((double)out[i] - ref[i]);
             if (!(d <= 1e-4 * (1 + fabs(ref[i])))) { ++byl[(i % (H * W)) % 64]; ++byc[(i / (H * W)) % Cout]; }
@@ -110,7 +112,7 @@ int main(int argc, char **argv) {
         printf("bad by lane (pixel %% 64):");
         for (int i = 0; i < 64; ++i) printf(" %ld", byl[i]);
         printf("\nbad by output channel:");
-        for (int i = 0; i < 128; ++i) printf(" %ld", byc[i]);
+        for (int i = 0; i < Cout; ++i) printf(" %ld", byc[i]);
         printf("\n");
     }
 #ifdef WAVE_STAMP
