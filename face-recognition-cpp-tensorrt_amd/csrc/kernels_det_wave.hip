@@ -112,7 +112,6 @@ struct WaveArgs {  // (the few fields of DwPwArgs this kernel reads: scalar regi
     const float *bp, *wdp;
     const half_t *wpf;
     const float *zeros;  // >= ((CPC - 1) * H * W + W) * 4 + 16 bytes of zeros: the source of input rows outside the image
-    int relu;
 #ifdef WAVE_STAMP
     long long *stamps;
 #endif
@@ -150,26 +149,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_
         lval[i] = q < G::CPC * G::SL && sl >= 1;
         voff[i] = lval[i] ? (unsigned)((k * HW + (sl - 1) * 4) * 4) : 0u;
     }
-    const char *inb = reinterpret_cast<const char *>(a.in + (long)b * CIN * HW);
-    const char *zer = reinterpret_cast<const char *>(a.zeros);
-    int rowoff[G::ROWS];  // byte offset of LDS row j's image row inside a channel plane, or -1
+    // one running source pointer per LDS row (uniform), advanced by a chunk of channels per DMA round; rows outside the image stay on the zeros
+    const char *rsrc[G::ROWS];
+    unsigned rstep[G::ROWS];
+    {
+        const char *inb = reinterpret_cast<const char *>(a.in + (long)b * CIN * HW);
+        const char *zer = reinterpret_cast<const char *>(a.zeros);
 #pragma unroll
-    for (int j = 0; j < G::ROWS; ++j) {
-        const int iy = y_first * STRIDE - 1 + j;
-        rowoff[j] = (iy >= 0 && iy < H) ? iy * W * 4 : -1;
+        for (int j = 0; j < G::ROWS; ++j) {
+            const int iy = y_first * STRIDE - 1 + j;
+            const bool in = iy >= 0 && iy < H;
+            rsrc[j] = in ? inb + iy * W * 4 : zer;
+            rstep[j] = in ? (unsigned)(G::CPC * HW * 4) : 0u;
+        }
     }
-    auto dma_chunk = [&](auto cc) {
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    auto dma_chunk = [&](auto cc) {  // (chunks are requested in order: the pointers advance)
         constexpr int c = decltype(cc)::value;
 #pragma unroll
         for (int i = 0; i < G::NDR; ++i)
             if (lval[i]) {
+                const unsigned vo = voff[i];
 #pragma unroll
                 for (int j = 0; j < G::ROWS; ++j) {
-                    const char *base = rowoff[j] >= 0 ? inb + ((long)c * G::CPC * HW * 4 + rowoff[j]) : zer;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + voff[i]),
-                                                     (__attribute__((address_space(3))) void *)(lds + (c % G::NBUF) * G::CHUNKB + j * G::ROWB + i * 1024), 16, 0, 0);
+                    const char *src = rsrc[j];
+                    const unsigned dst = lds0 + (c % G::NBUF) * G::CHUNKB + j * G::ROWB + i * 1024;
+                    // (asm: scalar base + 32-bit lane offset; the builtin took a 64-bit vector add and six scalar instructions per DMA)
+                    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(src), "s"(dst) : "memory");
                 }
             }
+#pragma unroll
+        for (int j = 0; j < G::ROWS; ++j) rsrc[j] += rstep[j];
     };
 
     // ---- stencil role: lane = output pixel p0 + lane (clamped for the tail of an image's last tile; those lanes are not stored)
@@ -364,8 +374,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
             floatx2 o = pr ? ob : oa;
-            o[0] = fmaxf(o[0], 0.f);
-            o[1] = fmaxf(o[1], 0.f);
+            asm("v_max_f32 %0, 0, %0" : "+v"(o[0]));  // (fmaxf() costs a second, canonicalising v_max per value)
+            asm("v_max_f32 %0, 0, %0" : "+v"(o[1]));
             const half2v h = __builtin_convertvector(o, half2v);
             float l0 = (float)h[0], l1 = (float)h[1];
             asm("v_sub_f32 %0, %1, %0" : "+v"(l0) : "v"(o[0]));  // (asm: the compiler would fuse the two subtractions into v_pk_add_f32)
@@ -400,20 +410,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(48))) void dwpw_
     static_for<0, 4 * MF_STEP>([&](auto mc) { mfma_n(std::integral_constant<int, G::NG - 1>{}, mc); });
     WSTAMP(4);
 
-    // ---- epilogue: lane (r, hi) of tile t owns pixel p0 + 32 t + r and channels 32 cb + (e & 3) + 8 (e >> 2) + 4 hi
+    // ---- epilogue: lane (r, hi) of tile t owns pixel p0 + 32 t + r and channels 32 cb + (e & 3) + 8 (e >> 2) + 4 hi; conv_dw blocks end in ReLU
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int pix = p0 + 32 * t + r;
         if (pix >= HoWo) continue;
-        float *ob = a.out + (long)b * COUT * HoWo + pix;
+        float *ob = a.out + ((long)b * COUT + cob * 32 + 4 * hi) * HoWo + pix;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = (cob + cb) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
                 float v = acc[t][cb][e] + bias4[cb][e >> 2][e & 3];
-                if (a.relu) v = fmaxf(v, 0.f);
-                ob[(long)co * HoWo] = v;
+                asm("v_max_f32 %0, 0, %0" : "+v"(v));
+                ob[(long)(cb * 32 + (e & 3) + 8 * (e >> 2)) * HoWo] = v;
             }
     }
     WSTAMP(5);
@@ -430,9 +439,9 @@ void launch_wave(const DwPwArgs &a, hipStream_t s) {
     (void)once;
     constexpr int tpi = (G::HOWO + 63) / 64;
 #ifdef WAVE_STAMP
-    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.zeros, a.relu, reinterpret_cast<long long *>(a.tmp)};
+    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.zeros, reinterpret_cast<long long *>(a.tmp)};
 #else
-    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.zeros, a.relu};
+    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.zeros};
 #endif
     hipLaunchKernelGGL((dwpw_wave_kernel<CIN, COUT, NCB, H, W, STRIDE, NBUF>), dim3((unsigned)(a.B * tpi), COUT / (32 * NCB)), dim3(64), G::LDS_BYTES, s, w);
 }
@@ -444,25 +453,24 @@ size_t dwpw_wave_zero_bytes() { return (size_t)1 << 20; }  // covers ((CPC - 1) 
 // true: launched.  Shapes covered (640x640 detector input): the five 128 -> 128 blocks at 40x40, 64 -> 64 at 80x80, 256 -> 256 at 20x20
 bool launch_dwpw_wave(const DwPwArgs &a, hipStream_t s) {
     static const bool on = !(frt_tuning_env("FRT_DWPW_WAVE") && frt_tuning_env("FRT_DWPW_WAVE")[0] == '0');
-    if (!on || !a.wdp || !a.wpf || !a.zeros || a.add || !a.wd) return false;
+    if (!on || !a.wdp || !a.wpf || !a.zeros || a.add || !a.wd || !a.relu) return false;
     if (a.W != a.Wo * a.stride || (a.stride == 1 ? a.H != a.Ho : a.H != 2 * a.Ho)) return false;
     if ((long)a.B * a.Cin * a.H * a.W * 4 >= (1L << 31)) return false;
     static const int which = frt_tuning_env("FRT_DWPW_WAVE_SHAPES") ? atoi(frt_tuning_env("FRT_DWPW_WAVE_SHAPES")) : 7;  // bit per shape (A/B measurements)
-    if (a.stride == 1 && a.Cin == 128 && a.Cout == 128 && a.W == 40 && a.H == 40 && (which & 1)) {
-        static const int v = frt_tuning_env("FRT_DWPW_WAVE_V") ? atoi(frt_tuning_env("FRT_DWPW_WAVE_V")) : 0;
-        if (v == 1) launch_wave<128, 128, 2, 40, 40, 1, 3>(a, s);
-        else if (v == 2) launch_wave<128, 128, 2, 40, 40, 1, 4>(a, s);
-        else if (v == 3) launch_wave<128, 128, 4, 40, 40, 1, 3>(a, s);
-        else launch_wave<128, 128, 4, 40, 40, 1, 4>(a, s);
+    static const bool any_batch = frt_tuning_env("FRT_DWPW_WAVE_ANYB") != nullptr;
+    // Batch thresholds: a wave is ~ 13 / 8 / 17 us long whatever the batch (one wave = 64 pixels x every input channel), the workgroup-tiled
+    // kernel finishes a few frames sooner.  Measured per launch, old / this kernel (us):  128 @ 40x40: 11.6 / 14 at 4 frames, 14.7 / 16 at 8,
+    // 24.4 / 18 at 16, 39 / 20 at 32;  64 @ 80x80: 10.1 / 10 at 1, 12.9 / 11 at 4, 20.3 / 14 at 8, 56 / 36 at 32;  256 @ 20x20: 19 / 21 at 4,
+    // 25.5 / 24 at 8, 27.8 / 25 at 16, 36 / 22 at 32 (profiles/r04t_dwpw_wave.txt)
+    if (a.stride == 1 && a.Cin == 128 && a.Cout == 128 && a.W == 40 && a.H == 40 && (which & 1) && (a.B >= 12 || any_batch)) {
+        launch_wave<128, 128, 4, 40, 40, 1, 3>(a, s);
         return true;
     }
-    if (a.stride == 1 && a.Cin == 64 && a.Cout == 64 && a.W == 80 && a.H == 80 && (which & 2)) {
-        static const int v = frt_tuning_env("FRT_DWPW_WAVE_V") ? atoi(frt_tuning_env("FRT_DWPW_WAVE_V")) : 0;
-        if (v == 1) launch_wave<64, 64, 1, 80, 80, 1, 3>(a, s);
-        else launch_wave<64, 64, 2, 80, 80, 1, 3>(a, s);
+    if (a.stride == 1 && a.Cin == 64 && a.Cout == 64 && a.W == 80 && a.H == 80 && (which & 2) && (a.B >= 3 || any_batch)) {
+        launch_wave<64, 64, 2, 80, 80, 1, 3>(a, s);
         return true;
     }
-    if (a.stride == 1 && a.Cin == 256 && a.Cout == 256 && a.W == 20 && a.H == 20 && (which & 4)) {
+    if (a.stride == 1 && a.Cin == 256 && a.Cout == 256 && a.W == 20 && a.H == 20 && (which & 4) && (a.B >= 12 || any_batch)) {
         launch_wave<256, 256, 2, 20, 20, 1, 4>(a, s);  // four waves per pixel tile, 64 output channels each (only 224 tiles at 32 frames)
         return true;
     }

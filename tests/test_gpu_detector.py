@@ -130,3 +130,24 @@ def test_box_census(frt, blobs, geo, frames, max_differing):
     assert r["boxes"] >= frames * 3 and r["frames_with_different_box_count"] == 0, r
     assert r["coordinates_differing"] <= max_differing and r["max_abs_diff_px"] <= 2, r
     assert r["max_abs_score_diff"] < 1e-5, r
+
+
+def test_batch_size_classes_of_the_conv_dw_kernels_agree_bit_for_bit(frt, synth, blobs):
+    """Round 4: at 640x640 the 64->64 (80x80), 128->128 (40x40) and 256->256 (20x20) conv_dw blocks run on dwpw_wave_kernel from 3 / 12 / 12 frames per
+    call upwards and on dwpw_mfma_kernel below (kernels_det_wave.hip: same arithmetic operation for operation).  16 frames in one call must give
+    the head outputs of the same frames in calls of 2, bit for bit - and the oracle's within the usual tolerance."""
+    from oracle import nets
+    path, sd = blobs("det")
+    fr = np.concatenate([synth.make_frames(4, 640, 640), synth.make_frames(4, 640, 640)[:, ::-1], synth.make_frames(4, 640, 640)[:, :, ::-1],
+                         synth.make_frames(4, 640, 640)[:, ::-1, ::-1]])
+    x = np.ascontiguousarray((fr.astype(np.float32) - np.array([104, 117, 123], np.float32)).transpose(0, 3, 1, 2))
+    big = frt.RetinaFace(path, 640, 640, (3, 640, 640), 16, 4)
+    loc16, conf16 = big.doInference(x)
+    big.close()
+    small = frt.RetinaFace(path, 640, 640, (3, 640, 640), 2, 4)
+    for i in range(0, 16, 2):
+        loc2, conf2 = small.doInference(x[i:i + 2])
+        assert np.array_equal(loc2, loc16[i:i + 2]) and np.array_equal(conf2, conf16[i:i + 2]), i
+    small.close()
+    oloc, oconf = nets.retinaface_forward(sd, x[12:14])
+    assert np.abs(loc16[12:14] - oloc).max() < LOC_TOL and np.abs(conf16[12:14] - oconf).max() < CONF_TOL

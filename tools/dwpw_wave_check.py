@@ -31,7 +31,7 @@ lib = os.path.join(ROOT, "face-recognition-cpp-tensorrt_amd", "libfrt_tuning.so"
 res = {}
 for B in (3, 32):
     for mode in ("0", "1"):
-        env = dict(os.environ, FRT_LIB=lib, FRT_DWPW_WAVE=mode)
+        env = dict(os.environ, FRT_LIB=lib, FRT_DWPW_WAVE=mode, FRT_DWPW_WAVE_ANYB="1")  # (ANYB: also below the batch thresholds)
         out = os.path.join(tmp, "o%s_%d.npz" % (mode, B))
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child", out, str(B)], env=env, check=True)
         res[mode] = np.load(out)
