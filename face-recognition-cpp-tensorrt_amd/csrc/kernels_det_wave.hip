@@ -7,14 +7,16 @@
 // 85 % of the launch left when all memory traffic is removed.  Here
 //   * lane = pixel, the loop runs over channels: the depthwise weights of a channel are wave-uniform, i.e. SGPR operands of
 //     v_pk_fma_f32 (two channels per instruction), and there is no per-element address arithmetic at all;
-//   * the input rows a wave needs (the rows its 64 pixels touch + one above and below) come in by LDS-DMA (global_load_lds_dwordx4), one
-//     instruction per channel: lane = (row, 16-byte slot) of a row-padded LDS image [row][4 zero floats | W floats].  The zero slot and
-//     the rows outside the image are never written (exec-masked lanes; the region is zeroed once), so every border case is a plain
-//     ds_read_b32 with an immediate offset - no selects;
+//   * the input rows a wave needs (the rows its 64 pixels touch + one above and below) come in by LDS-DMA (global_load_lds_dwordx4) in chunks
+//     of 8 channels: LDS image [row][channel][16-byte slot] with one zero slot in front of every channel row, one DMA instruction per 64
+//     (channel, slot) positions of a row.  The zero slots are never written (exec-masked lanes; the region is zeroed once) and rows outside
+//     the image are fetched from a buffer of zeros, so every border case is a plain ds_read2_b32 with immediate offsets - no selects;
 //   * the MFMA B operand never goes through LDS: after 16 channels a lane holds their 16 depthwise outputs for ITS pixel, as fp16 hi / lo
 //     pairs; lanes 0-31 are pixel tile A, lanes 32-63 tile B, and v_permlane32_swap_b32 (gfx950) turns "channels 0-7 | channels 8-15 of my
 //     pixel" into the two tiles' (pixel, k = 8*hi + j) fragments: 8 swaps per 16 channels;
-//   * no barrier anywhere: the LDS region is wave-private and ordered by s_waitcnt vmcnt.
+//   * no barrier anywhere: the LDS region is wave-private and ordered by s_waitcnt vmcnt (+ a step of distance: see WaveGeom::younger);
+//   * depthwise weights and tap registers live in inline asm with FIXED scalar registers: what the compiler does to in-flight asm results and to
+//     lgkmcnt is told where it happened, below.
 // Arithmetic is the old kernel's operation for operation (same fma chain per pixel, same RNE split, same MFMA order), so the output is
 // bit-identical to dwpw_mfma_kernel<..., SPLIT = true> - checked by tools/dwpw_wave_check.py and by the detector tests, which run unchanged.
 #include <cstdlib>
@@ -446,6 +448,113 @@ void launch_wave(const DwPwArgs &a, hipStream_t s) {
     hipLaunchKernelGGL((dwpw_wave_kernel<CIN, COUT, NCB, H, W, STRIDE, NBUF>), dim3((unsigned)(a.B * tpi), COUT / (32 * NCB)), dim3(64), G::LDS_BYTES, s, w);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The same lane = pixel formulation for the wide, shallow blocks (160x160 and up, <= 32 input channels), where a wave's halo'd LDS image
+// would be tens of KB for a handful of channels: the taps come straight from global memory instead - nine buffer loads per channel whose
+// per-lane offsets are computed once (a tap outside the image has an out-of-range offset: the buffer returns 0, no selects), the channel is
+// the scalar offset.  There are thousands of waves on these maps, so occupancy (not a software pipeline) hides the load latency; everything
+// is left to the compiler.  MEASURED at 32 frames (FRT_DWPW_PIX, tuning build): 32 -> 32 at 160x160 75.7 us against 90.0 for dwpw_row4_kernel,
+// but 16 -> 32 / stride 2 120.6 against 110.7 and 32 -> 64 / stride 2 57.6 against 43.1 (nine dword loads per channel and pixel: the texture
+// path, not HBM, bounds it).  Not bit-identical to the scalar row4 kernel (|d| 2e-5 on the head outputs, the oracle's tolerance holds).  Left
+// OFF: 14 us of a 3.1 ms step do not pay for moving the box census.
+template <int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(256) void dwpw_pix_kernel(WaveArgs a, int B, int H, int W) {
+    constexpr int NCB = COUT / 32, NG = CIN / 16;
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int Ho = H / STRIDE, Wo = W / STRIDE, HW = H * W, HoWo = Ho * Wo;
+    const long total = (long)B * HoWo;
+    const long p0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (p0 >= total) return;
+    const long pl = min(p0 + lane, total - 1);
+    const int b = (int)(pl / HoWo), pp = (int)(pl - (long)b * HoWo), oy = pp / Wo, ox = pp - oy * Wo;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, (int)((long)B * CIN * HW * 4), 0x00020000);
+    int vo[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = oy * STRIDE - 1 + t / 3, ix = ox * STRIDE - 1 + t % 3;
+        vo[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? (int)((((long)b * CIN * H + iy) * W + ix) * 4) : (int)0x80000000;
+    }
+    const __attribute__((address_space(4))) float *wd = reinterpret_cast<const __attribute__((address_space(4))) float *>(reinterpret_cast<uintptr_t>(a.wdp));
+    const half_t *wf = a.wpf + (long)lane * 8;
+    floatx16 acc[2][NCB];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][cb][e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        half8 ah[NCB], al[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            ah[cb] = *reinterpret_cast<const half8 *>(wf + ((long)(g * NCB + cb) * 2) * 512);
+            al[cb] = *reinterpret_cast<const half8 *>(wf + ((long)(g * NCB + cb) * 2 + 1) * 512);
+        }
+        unsigned hp[8], lp[8];
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+            const int q = g * 8 + pr;
+            const int so = 2 * q * HW * 4;
+            floatx2 o = {wd[q * 20 + 18], wd[q * 20 + 19]};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const floatx2 v = {__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[t], so, 0)),
+                                   __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[t], so + HW * 4, 0))};
+                o = __builtin_elementwise_fma(v, floatx2{wd[q * 20 + 2 * t], wd[q * 20 + 2 * t + 1]}, o);
+            }
+            o[0] = fmaxf(o[0], 0.f);
+            o[1] = fmaxf(o[1], 0.f);
+            const half2v h = __builtin_convertvector(o, half2v);
+            const floatx2 back = __builtin_convertvector(h, floatx2);
+            const half2v l = __builtin_convertvector(o - back, half2v);
+            hp[pr] = __builtin_bit_cast(unsigned, h);
+            lp[pr] = __builtin_bit_cast(unsigned, l);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint2v sh = __builtin_amdgcn_permlane32_swap(hp[i], hp[4 + i], false, false);
+            const uint2v sl = __builtin_amdgcn_permlane32_swap(lp[i], lp[4 + i], false, false);
+            hp[i] = sh[0];
+            hp[4 + i] = sh[1];
+            lp[i] = sl[0];
+            lp[4 + i] = sl[1];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const half8 bh = __builtin_bit_cast(half8, uint4v{hp[4 * t], hp[4 * t + 1], hp[4 * t + 2], hp[4 * t + 3]});
+            const half8 bl = __builtin_bit_cast(half8, uint4v{lp[4 * t], lp[4 * t + 1], lp[4 * t + 2], lp[4 * t + 3]});
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                acc[t][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bh, acc[t][cb], 0, 0, 0);
+                acc[t][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl, acc[t][cb], 0, 0, 0);
+                acc[t][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh, acc[t][cb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long px = p0 + 32 * t + r;
+        if (px >= total) continue;
+        const int b2 = (int)(px / HoWo), p2 = (int)(px - (long)b2 * HoWo);
+        float *ob = a.out + ((long)b2 * COUT + 4 * hi) * HoWo + p2;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = cb * 32 + (e & 3) + 8 * (e >> 2);
+                ob[(long)co * HoWo] = fmaxf(acc[t][cb][e] + a.bp[co + 4 * hi], 0.f);
+            }
+    }
+}
+
+template <int CIN, int COUT, int STRIDE>
+void launch_pix(const DwPwArgs &a, hipStream_t s) {
+    const long tiles = ((long)a.B * a.Ho * a.Wo + 63) / 64;
+    const WaveArgs w{a.in, a.out, a.bp, a.wdp, a.wpf, a.zeros};
+    hipLaunchKernelGGL((dwpw_pix_kernel<CIN, COUT, STRIDE>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, w, a.B, a.H, a.W);
+}
+
 }  // namespace
 
 size_t dwpw_wave_zero_bytes() { return (size_t)1 << 20; }  // covers ((CPC - 1) * H * W + W) * 4 + 16 for every shape below
@@ -472,6 +581,19 @@ bool launch_dwpw_wave(const DwPwArgs &a, hipStream_t s) {
     }
     if (a.stride == 1 && a.Cin == 256 && a.Cout == 256 && a.W == 20 && a.H == 20 && (which & 4) && (a.B >= 12 || any_batch)) {
         launch_wave<256, 256, 2, 20, 20, 1, 4>(a, s);  // four waves per pixel tile, 64 output channels each (only 224 tiles at 32 frames)
+        return true;
+    }
+    static const int pix = frt_tuning_env("FRT_DWPW_PIX") ? atoi(frt_tuning_env("FRT_DWPW_PIX")) : 0;  // (experiment: default off until measured)
+    if ((pix & 1) && a.stride == 1 && a.Cin == 32 && a.Cout == 32) {
+        launch_pix<32, 32, 1>(a, s);
+        return true;
+    }
+    if ((pix & 2) && a.stride == 2 && a.Cin == 16 && a.Cout == 32) {
+        launch_pix<16, 32, 2>(a, s);
+        return true;
+    }
+    if ((pix & 4) && a.stride == 2 && a.Cin == 32 && a.Cout == 64) {
+        launch_pix<32, 64, 2>(a, s);
         return true;
     }
     return false;

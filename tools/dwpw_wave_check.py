@@ -27,11 +27,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.exit(0)
 
 tmp = tempfile.mkdtemp()
+# optional: another tuning switch and its two values, e.g.  FRT_DWPW_PIX 0 7
+SWITCH, OFF, ON = (sys.argv[1:4] + ["FRT_DWPW_WAVE", "0", "1"][len(sys.argv[1:4]):]) if len(sys.argv) > 1 else ("FRT_DWPW_WAVE", "0", "1")
 lib = os.path.join(ROOT, "face-recognition-cpp-tensorrt_amd", "libfrt_tuning.so")
 res = {}
 for B in (3, 32):
     for mode in ("0", "1"):
-        env = dict(os.environ, FRT_LIB=lib, FRT_DWPW_WAVE=mode, FRT_DWPW_WAVE_ANYB="1")  # (ANYB: also below the batch thresholds)
+        env = dict(os.environ, FRT_LIB=lib, FRT_DWPW_WAVE_ANYB="1")  # (ANYB: also below the batch thresholds)
+        env[SWITCH] = ON if mode == "1" else OFF
         out = os.path.join(tmp, "o%s_%d.npz" % (mode, B))
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child", out, str(B)], env=env, check=True)
         res[mode] = np.load(out)
