@@ -111,6 +111,10 @@ __global__ __launch_bounds__(256, 1) void conv_ks_kernel(ConvMfmaArgs p) {
         load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW == 2 ? 60 : 24) : "memory");
+    // The patch is wave-private: no barrier follows.  Measured in kernels_det_wave.hip (round 4): a ds_read issued right behind the vmcnt
+    // wait of an LDS-DMA can still see the old LDS contents; 128 cycles were enough there.  The K loop's first read sits ~ 50 instructions
+    // further down and every test has passed without this sleep, but "the compiler happened to put enough in between" is not an ordering.
+    asm volatile("s_sleep 2" ::: "memory");
     KS_STAMP(2);
 
     // ---- epilogue operands of the tiles this wave finishes (they land under the K loop)
