@@ -81,7 +81,19 @@ for nf in 1 4 16 32; do NF=$nf bash tools/layer_table.sh "A=1"; done > "$OUT/${T
 python tools/ks_check.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/${TAG}_medium_batch_parity.txt"
 python tools/prof_match_small.py 2>/dev/null | grep queries > "$OUT/${TAG}_match_small.txt"
 # 4. the microbenchmarks DESIGN.md quotes (sources in tools/ubench/*.hip)
-for P in clock_probe occ_probe mfma_f32_order; do
+for P in clock_probe occ_probe mfma_f32_order mfma_pk_overlap; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -w -o /tmp/$P "$ROOT/tools/ubench/$P.hip" 2>/dev/null && timeout 120 /tmp/$P > "$OUT/${TAG}_$P.txt" 2>&1
 done
+# 5. round 4: the detector alone (kernel trace of tools/prof_det.py at 32 and 4 frames), dwpw_wave_kernel against dwpw_mfma_kernel bit for bit
+#    (tuning build), and the stand-alone harness of the wave kernel on its three shapes
+cd /tmp
+for B in 32 4; do
+  rm -rf /tmp/prof_det && mkdir -p /tmp/prof_det
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_det -o st -- python "$ROOT/tools/prof_det.py" $B 5 > /dev/null 2>&1
+  cp "$(find /tmp/prof_det -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_det_kernel_stats_b$B.csv" 2>/dev/null
+done
+cd "$ROOT"
+python tools/dwpw_wave_check.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/${TAG}_dwpw_wave_check.txt"
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFRT_TUNING -w -Iface-recognition-cpp-tensorrt_amd/csrc -o /tmp/dwpw_wave_bench tools/ubench/dwpw_wave_bench.hip 2>/dev/null &&
+  for A in "32" "2" "32 64 80" "2 64 80" "32 256 20" "2 256 20"; do timeout 60 /tmp/dwpw_wave_bench $A; done > "$OUT/${TAG}_dwpw_wave_bench.txt" 2>&1
 ls -la "$OUT"
