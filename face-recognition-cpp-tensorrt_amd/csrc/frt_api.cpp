@@ -415,12 +415,23 @@ void frt_detector::build(const frt::Blob &b) {
                 {
                     const std::vector<uint16_t> ph = pack_pw_split(w2, l.cin, l.cout);
                     if (!ph.empty()) o.dw.wph = reinterpret_cast<const half_t *>(arena.upload(ph));
-                    if (!ph.empty() && l.cout % 32 == 0) {  // the operands of dwpw_wave_kernel (kernels_det_wave.hip)
+                    if (l.cin % 2 == 0) {  // depthwise weights of channel pairs (kernels_det_wave.hip, kernels_det_stem.hip)
                         std::vector<float> wp2((size_t)l.cin * 10, 0.f);  // [Cin/2][10][2]: taps 0-8, bias; the channel pair interleaved
                         for (int ci = 0; ci < l.cin; ++ci) {
                             for (int t = 0; t < 9; ++t) wp2[(size_t)(ci / 2) * 20 + 2 * t + (ci & 1)] = w[(size_t)ci * 9 + t];
                             wp2[(size_t)(ci / 2) * 20 + 18 + (ci & 1)] = bias[ci];
                         }
+                        o.dw.wdp = arena.upload(wp2);
+                        if (l.cin <= 16) {
+                            std::vector<float> wt((size_t)l.cin * 10, 0.f);
+                            for (int ci = 0; ci < l.cin; ++ci) {
+                                for (int t = 0; t < 9; ++t) wt[((size_t)t * (l.cin / 2) + ci / 2) * 2 + (ci & 1)] = w[(size_t)ci * 9 + t];
+                                wt[((size_t)9 * (l.cin / 2) + ci / 2) * 2 + (ci & 1)] = bias[ci];
+                            }
+                            o.dw.wdt = arena.upload(wt);
+                        }
+                    }
+                    if (!ph.empty() && l.cout % 32 == 0) {  // the other operands of dwpw_wave_kernel
                         std::vector<uint16_t> pf(ph.size());
                         const int ng = l.cin / 16, ncb = l.cout / 32;
                         for (int gq = 0; gq < ng; ++gq)
@@ -435,7 +446,6 @@ void frt_detector::build(const frt::Blob &b) {
                             HIPCHK(hipMemset(d_wave_zeros, 0, dwpw_wave_zero_bytes()));
                         }
                         o.dw.zeros = d_wave_zeros;
-                        o.dw.wdp = arena.upload(wp2);
                         o.dw.wpf = reinterpret_cast<const half_t *>(arena.upload(pf));
                     }
                 }
@@ -450,6 +460,14 @@ void frt_detector::build(const frt::Blob &b) {
         fh[si] = ch;
         fw[si] = cw;
         ++si;
+    }
+    // the first three layers as one kernel (kernels_det_stem.hip): their weights gathered into one buffer
+    if (ops.size() >= 3 && ops[0].type == 1 && ops[0].n == 1 && ops[1].type == 0 && ops[2].type == 0 && ops[1].dw.wdt && ops[2].dw.wdt &&
+        ops[1].dw.Cin == 8 && ops[1].dw.Cout == 16 && ops[2].dw.Cin == 16 && ops[2].dw.Cout == 32) {
+        float *stem = arena.alloc<float>(det_stem_weight_floats());
+        det_stem_pack(ops[0].c3[0], ops[1].dw, ops[2].dw, stem, nullptr);
+        HIPCHK(hipStreamSynchronize(nullptr));
+        ops[1].dw.stem = stem;
     }
     for (int k = 0; k < 3; ++k)
         if (fh[k] != g.fh[k] || fw[k] != g.fw[k]) raise(FRT_ERR_INVALID, "detector: feature-map size mismatch");
@@ -558,6 +576,46 @@ void frt_detector::forward_frames(const uint8_t *frames_dev, int n, size_t row_s
     if (g.frame_h == g.in_h && g.frame_w == g.in_w && !ops.empty() && ops[0].type == 1 && ops[0].n == 1) {
         Conv3Args c = ops[0].c3[0];
         c.B = n;
+        if (ops.size() >= 3 && ops[1].type == 0 && ops[2].type == 0) {  // first conv + the first two conv_dw blocks in one kernel
+#ifdef FRT_TUNING
+            if (getenv("FRT_DET_STEM_CHECK")) {  // debugging aid: the three layers one by one against the fused kernel, element for element
+                const size_t cnt = (size_t)n * ops[2].dw.Cout * ops[2].dw.Ho * ops[2].dw.Wo;
+                std::vector<float> ref(cnt), got(cnt);
+                (void)launch_det_conv1_u8(frames_dev, row_stride, frame_stride, c, s);
+                ops[1].dw.B = n; ops[2].dw.B = n;
+                launch_dwpw(ops[1].dw, s);
+                launch_dwpw(ops[2].dw, s);
+                HIPCHK(hipStreamSynchronize(s));
+                HIPCHK(hipMemcpy(ref.data(), ops[2].dw.out, cnt * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemset(ops[2].dw.out, 0xff, cnt * 4));
+                const bool ran = launch_det_stem(frames_dev, row_stride, frame_stride, c, ops[1].dw, ops[2].dw, s);
+                HIPCHK(hipStreamSynchronize(s));
+                HIPCHK(hipMemcpy(got.data(), ops[2].dw.out, cnt * 4, hipMemcpyDeviceToHost));
+                size_t bad = 0, first = cnt;
+                double maxd = 0;
+                for (size_t i = 0; i < cnt; ++i) {
+                    const double d = std::fabs((double)ref[i] - (double)got[i]);
+                    if (!(d == 0)) { if (first == cnt) first = i; ++bad; }
+                    if (d > maxd || d != d) maxd = d;
+                }
+                const int hw = ops[2].dw.Ho * ops[2].dw.Wo;
+                fprintf(stderr, "[stem check] ran %d, %zu of %zu differ, max |d| %g", (int)ran, bad, cnt, maxd);
+                if (first < cnt) fprintf(stderr, "; first at b=%zu c=%zu y=%zu x=%zu: got %g want %g", first / ((size_t)32 * hw), (first / hw) % 32, (first % hw) / ops[2].dw.Wo, first % ops[2].dw.Wo, got[first], ref[first]);
+                fprintf(stderr, "\n");
+                size_t by_c[32] = {0};
+                for (size_t i = 0; i < cnt; ++i) if (ref[i] != got[i]) ++by_c[(i / hw) % 32];
+                fprintf(stderr, "[stem check] differing by channel:");
+                for (int k = 0; k < 32; ++k) fprintf(stderr, " %zu", by_c[k]);
+                fprintf(stderr, "\n");
+            }
+#endif
+            bool stem;
+            {
+                ProfScope ps(2, "det_stem", (double)n * g.frame_h * g.frame_w * 3, s);
+                stem = launch_det_stem(frames_dev, row_stride, frame_stride, c, ops[1].dw, ops[2].dw, s);
+            }
+            if (stem) return forward(n, s, 3);
+        }
         bool fused;
         {
             ProfScope ps(2, "det_preprocess", (double)n * g.frame_h * g.frame_w * 3, s);  // fused into the first conv
@@ -2521,7 +2579,14 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
         // streams also measured 1 % slower
         p->copy_prio = prio_hi;
         auto mk = [&](hipStream_t *st) { HIPCHK(hipStreamCreateWithPriority(st, hipStreamDefault, prio_hi)); };
-        mk(&p->det_stream);
+        {
+            // FRT_PIPELINE_DET_PRIO=lo / normal: the detector's stream below the recogniser's (A/B: does the hardware then give the recogniser -
+            // the longer stage - the CUs first and let the detector fill its gaps?)
+            const char *dp = getenv("FRT_PIPELINE_DET_PRIO");
+            if (dp && dp[0] == 'l') HIPCHK(hipStreamCreateWithPriority(&p->det_stream, hipStreamDefault, prio_lo));
+            else if (dp && dp[0] == 'n') HIPCHK(hipStreamCreateWithPriority(&p->det_stream, hipStreamDefault, 0));
+            else mk(&p->det_stream);
+        }
         mk(&p->emb_stream);
         mk(&p->emb_stream2);
         {

@@ -142,6 +142,8 @@ struct DwPwArgs {
     const half_t *wph;      // pointwise weights as fp16 hi/lo split [Cout][Cin/16][hi16 | lo16] (Cin % 16 == 0); null: fp32 MFMA path
     const float *wdp;       // depthwise weights of channel pairs [Cin/2][10][2] (kernels_det_wave.hip); null: that kernel does not apply
     const half_t *wpf;      // the split pointwise weights in fragment order [Cin/16][Cout/32][hi|lo][64][8] (kernels_det_wave.hip)
+    const float *wdt;       // the same depthwise weights tap-major [10][Cin/2][2] (tap 9 = bias; kernels_det_stem.hip); Cin <= 16 only
+    const float *stem;      // 8 -> 16 block only: the gathered weights of the fused stem kernel (det_stem_pack, kernels_det_stem.hip); null: not fused
     const float *zeros;     // dwpw_wave_zero_bytes() of zeros (kernels_det_wave.hip: the source of input rows outside the image)
 };
 size_t dwpw_wave_zero_bytes();
@@ -162,6 +164,10 @@ struct Conv3Args {
 };
 bool det_mfma_enabled();       // env FRT_DET_MFMA=0 switches the detector back to the scalar kernels (A/B measurements)
 void launch_conv3x3(const Conv3Args &a, hipStream_t s);
+// the detector's first three layers in one kernel (kernels_det_stem.hip); false: not applicable, run them one by one
+size_t det_stem_weight_floats();
+void det_stem_pack(const Conv3Args &c, const DwPwArgs &d1, const DwPwArgs &d2, float *dst, hipStream_t s);
+bool launch_det_stem(const uint8_t *frames, size_t row_stride, size_t frame_stride, const Conv3Args &c, const DwPwArgs &d1, const DwPwArgs &d2, hipStream_t s);
 // first detector conv fed by the u8 frames directly (only valid when the letterbox is the identity); false: not applicable
 bool launch_det_conv1_u8(const uint8_t *frames, size_t row_stride, size_t frame_stride, const Conv3Args &a, hipStream_t s);
 // (A fused "stem" kernel - first conv + the two conv_dw blocks behind it with the intermediates in LDS - was tried and removed:

@@ -312,11 +312,16 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
         // 8 scalar loads the fp32 path spends on 8 k-steps), splits them, and three fp16 MFMAs replace eight fp32 ones
         const float *xs = a.in + (long)b * a.Cin * HW + p + (long)(8 * hi) * HW;
         const int ngroups = a.Cin / 16;
-        float bxs[8], nbx[8];
+        // activations FOUR groups ahead (32 registers), weights (L2 hits) one: with one group in flight a wave paid the HBM latency once per 16
+        // channels, and few waves fit a CU (round 4: lateral 64->64 at 80x80 61 -> see profiles/r04v_laterals.txt)
+        constexpr int DA = 4;
+        float bx[DA][8];
         half8 ah[CBW], al[CBW], nah[CBW], nal[CBW];
-        auto load_g = [&](int g, float (&bxv)[8], half8 (&dh)[CBW], half8 (&dl)[CBW]) {
+        auto load_x = [&](int g, float (&bxv)[8]) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) bxv[e] = (ok && g < ngroups) ? xs[(long)(16 * g + e) * HW] : 0.f;
+        };
+        auto load_w = [&](int g, half8 (&dh)[CBW], half8 (&dl)[CBW]) {
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) {
                 const int co = co_base + cb * 32 + r;
@@ -330,29 +335,35 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
                 }
             }
         };
-        load_g(0, bxs, ah, al);
-        for (int g = 0; g < ngroups; ++g) {
-            if (g + 1 < ngroups) load_g(g + 1, nbx, nah, nal);
-            half8 bh, bl;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const half_t xh = (half_t)bxs[e];
-                bh[e] = xh;
-                bl[e] = (half_t)(bxs[e] - (float)xh);
-            }
+        for (int i = 0; i < DA; ++i) load_x(i, bx[i]);
+        load_w(0, ah, al);
+        for (int g0 = 0; g0 < ngroups; g0 += DA) {
 #pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) {
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bh, acc[cb], 0, 0, 0);
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl, acc[cb], 0, 0, 0);
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh, acc[cb], 0, 0, 0);
-            }
-            if (g + 1 < ngroups) {
+            for (int i = 0; i < DA; ++i) {
+                const int g = g0 + i;
+                if (g >= ngroups) break;
+                if (g + 1 < ngroups) load_w(g + 1, nah, nal);
+                half8 bh, bl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bxs[e] = nbx[e];
+                for (int e = 0; e < 8; ++e) {
+                    const half_t xh = (half_t)bx[i][e];
+                    bh[e] = xh;
+                    bl[e] = (half_t)(bx[i][e] - (float)xh);
+                }
+                if (g + DA < ngroups) load_x(g + DA, bx[i]);
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb) {
-                    ah[cb] = nah[cb];
-                    al[cb] = nal[cb];
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bh, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl, acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh, acc[cb], 0, 0, 0);
+                }
+                if (g + 1 < ngroups) {
+#pragma unroll
+                    for (int cb = 0; cb < CBW; ++cb) {
+                        ah[cb] = nah[cb];
+                        al[cb] = nal[cb];
+                    }
                 }
             }
         }
@@ -401,15 +412,27 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
         addb = a.add + (long)b * a.Cout * add_cs + ah * a.add_w + awd;
     }
     float *ob = a.out + (long)b * a.Cout * HW + p;
+    // every load of the epilogue before its first store (the output may alias the add source for all the compiler knows: left alone it
+    // serialises load -> store -> load)
+    float bias_v[CBW][16], add_v[CBW][16];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            const bool cok = co < a.Cout;
+            bias_v[cb][e] = cok ? a.bp[co] : 0.f;
+            add_v[cb][e] = (cok && addb) ? addb[co * add_cs] : 0.f;
+        }
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
             if (co < a.Cout) {
-                float v = acc[cb][e] + a.bp[co];
+                float v = acc[cb][e] + bias_v[cb][e];
                 if (a.relu) v = fmaxf(v, 0.f);
-                if (addb) v += addb[co * add_cs];
+                if (addb) v += add_v[cb][e];
                 ob[(long)co * HW] = v;
             }
         }
