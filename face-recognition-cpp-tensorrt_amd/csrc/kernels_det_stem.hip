@@ -75,6 +75,65 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
     {
         const uint8_t *fb = a.frames + (size_t)b * a.frame_stride;
         const float mean[3] = {104.f, 117.f, 123.f};
+        if constexpr (INTERIOR) {
+            // the nine raw loads of the NEXT position are in flight under this position's arithmetic (one pass = one HBM / L2 round trip otherwise:
+            // six per wave, with little more than one wave per SIMD to hide them)
+            uint32_t raw[9], nxt[9];
+            auto ldraw = [&](int idx, uint32_t (&d)[9]) {
+                const int id = min(idx, R1 * R1 - 1), cy = id / R1, cx = id - cy * R1;
+                const uint8_t *row = fb + (size_t)((r1y0 + cy) * 2 - 1) * a.row_stride + (size_t)(r1x0 + cx) * 6;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    __builtin_memcpy(&d[3 * kh], row + kh * a.row_stride - 3, 4);
+                    __builtin_memcpy(&d[3 * kh + 1], row + kh * a.row_stride + 1, 4);
+                    d[3 * kh + 2] = row[kh * a.row_stride + 5];
+                }
+            };
+            ldraw(lane, raw);
+#pragma unroll 1
+            for (int idx = lane; idx < R1 * R1; idx += 64) {
+                int z;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+                const auto w = uni(a.w1) + z;
+                const auto bias = uni(a.b1) + z;
+                ldraw(idx + 64, nxt);
+                float v[3][9];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const uint32_t d0 = raw[3 * kh], d1 = raw[3 * kh + 1], d2 = raw[3 * kh + 2];
+                    const uint32_t by[9] = {d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, d0 >> 24, d1 & 255u, (d1 >> 8) & 255u, (d1 >> 16) & 255u, d1 >> 24, d2};
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int ci = 0; ci < 3; ++ci) v[ci][kh * 3 + kw] = (float)by[kw * 3 + ci] - mean[ci];
+                }
+                floatx2 acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = floatx2{0.f, 0.f};
+                constexpr int D = 2;
+                floatx2 wc[D + 1][4];
+                static_for<0, D>([&](auto jc) { ld_pairs<4>(w, decltype(jc)::value, wc[decltype(jc)::value]); });
+                static_for<0, 27>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i + D < 27) ld_pairs<4>(w, i + D, wc[(i + D) % (D + 1)]);
+                    const float x = v[i / 9][i % 9];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_elementwise_fma(floatx2{x, x}, wc[i % (D + 1)][c], acc[c]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                floatx4 o0, o1;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float ov = fmaxf(acc[c >> 1][c & 1] + bias[c], 0.f);
+                    if (c < 4) o0[c] = ov;
+                    else o1[c - 4] = ov;
+                }
+                *reinterpret_cast<floatx4 *>(&c1[idx][0]) = o0;
+                *reinterpret_cast<floatx4 *>(&c1[idx][4]) = o1;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) raw[k] = nxt[k];
+            }
+        } else
 #pragma unroll 1
         for (int idx = lane; idx < R1 * R1; idx += 64) {
             // (an opaque zero: without it the 224 scalar weight loads are hoisted out of the loop and spilled - 569 SGPR spills)
@@ -124,14 +183,15 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
                             }
                         }
                 }
-                floatx2 wc[2][4];
-                ld_pairs<4>(w, 0, wc[0]);
+                constexpr int D = INTERIOR ? 3 : 1;  // chunks of scalar weights in flight ahead of the one in use (scalar registers permitting)
+                floatx2 wc[D + 1][4];
+                static_for<0, D>([&](auto jc) { ld_pairs<4>(w, decltype(jc)::value, wc[decltype(jc)::value]); });
                 static_for<0, 27>([&](auto ic) {  // chunk i = (ci, tap): the eight output channels' weights of one input value
                     constexpr int i = decltype(ic)::value;
-                    if constexpr (i + 1 < 27) ld_pairs<4>(w, i + 1, wc[(i + 1) & 1]);
+                    if constexpr (i + D < 27) ld_pairs<4>(w, i + D, wc[(i + D) % (D + 1)]);
                     const float x = v[i / 9][i % 9];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_elementwise_fma(floatx2{x, x}, wc[i & 1][c], acc[c]);
+                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_elementwise_fma(floatx2{x, x}, wc[i % (D + 1)][c], acc[c]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
@@ -159,18 +219,19 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
             const bool inside = INTERIOR || (r2y0 + by >= 0 && r2y0 + by < a.H1 && r2x0 + bx >= 0 && r2x0 + bx < a.W1);
             floatx2 dd[4];  // depthwise outputs, channel pairs; weights tap-major [tap | bias][pair][2]
             {
-                floatx2 wc[2][4];
+                constexpr int D = INTERIOR ? 3 : 1;
+                floatx2 wc[D + 1][4];
                 ld_pairs<4>(wdt, 9, dd);
-                ld_pairs<4>(wdt, 0, wc[0]);
+                static_for<0, D>([&](auto jc) { ld_pairs<4>(wdt, decltype(jc)::value, wc[decltype(jc)::value]); });
                 static_for<0, 9>([&](auto tc) {
                     constexpr int tt = decltype(tc)::value;
-                    if constexpr (tt + 1 < 9) ld_pairs<4>(wdt, tt + 1, wc[(tt + 1) & 1]);
+                    if constexpr (tt + D < 9) ld_pairs<4>(wdt, tt + D, wc[(tt + D) % (D + 1)]);
                     const float *tp = &c1[(by + tt / 3) * R1 + bx + tt % 3][0];
                     const floatx4 t0 = *reinterpret_cast<const floatx4 *>(tp), t1 = *reinterpret_cast<const floatx4 *>(tp + 4);
-                    dd[0] = __builtin_elementwise_fma(floatx2{t0[0], t0[1]}, wc[tt & 1][0], dd[0]);
-                    dd[1] = __builtin_elementwise_fma(floatx2{t0[2], t0[3]}, wc[tt & 1][1], dd[1]);
-                    dd[2] = __builtin_elementwise_fma(floatx2{t1[0], t1[1]}, wc[tt & 1][2], dd[2]);
-                    dd[3] = __builtin_elementwise_fma(floatx2{t1[2], t1[3]}, wc[tt & 1][3], dd[3]);
+                    dd[0] = __builtin_elementwise_fma(floatx2{t0[0], t0[1]}, wc[tt % (D + 1)][0], dd[0]);
+                    dd[1] = __builtin_elementwise_fma(floatx2{t0[2], t0[3]}, wc[tt % (D + 1)][1], dd[1]);
+                    dd[2] = __builtin_elementwise_fma(floatx2{t1[0], t1[1]}, wc[tt % (D + 1)][2], dd[2]);
+                    dd[3] = __builtin_elementwise_fma(floatx2{t1[2], t1[3]}, wc[tt % (D + 1)][3], dd[3]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
@@ -261,18 +322,30 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
     }
 }
 
+// Two launches: the interior tiles (everything but the outermost ring of 8x8 tiles) and the ring.  As one kernel with a run-time branch the
+// register allocation was the border path's (93 scalar spills in the interior loops).
+template <bool INTERIOR>
 __global__ __launch_bounds__(64) void det_stem_kernel(StemArgs a) {
     __shared__ __attribute__((aligned(16))) float c1[R1 * R1][8];
     __shared__ __attribute__((aligned(16))) float b1s[R2 * R2][16];
     const int tiles_x = a.W2 >> 3, tiles_y = a.H2 >> 3;
-    int t = blockIdx.x;
-    const int b = t / (tiles_x * tiles_y);
-    t -= b * tiles_x * tiles_y;
-    const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    const int Y0 = ty * 8, X0 = tx * 8;  // output tile origin (H2 x W2 map)
-    const int r1y0 = 2 * Y0 - 2, r1x0 = 2 * X0 - 2;
-    if (r1y0 >= 1 && r1x0 >= 1 && r1y0 + R1 - 1 < a.H1 && r1x0 + R1 - 1 < a.W1) stem_body<true>(a, c1, b1s, b, Y0, X0);
-    else stem_body<false>(a, c1, b1s, b, Y0, X0);
+    int t = blockIdx.x, b, ty, tx;
+    if (INTERIOR) {
+        const int ix = tiles_x - 2, per = ix * (tiles_y - 2);
+        b = t / per;
+        t -= b * per;
+        ty = t / ix;
+        tx = t - ty * ix + 1;
+        ty += 1;
+    } else {  // the ring: top row, bottom row, then the left / right columns of the rows in between
+        const int per = 2 * tiles_x + 2 * (tiles_y - 2);
+        b = t / per;
+        t -= b * per;
+        if (t < tiles_x) { ty = 0; tx = t; }
+        else if (t < 2 * tiles_x) { ty = tiles_y - 1; tx = t - tiles_x; }
+        else { t -= 2 * tiles_x; ty = 1 + (t >> 1); tx = (t & 1) ? tiles_x - 1 : 0; }
+    }
+    stem_body<INTERIOR>(a, c1, b1s, b, ty * 8, tx * 8);
 }
 
 }  // namespace
@@ -295,9 +368,12 @@ bool launch_det_stem(const uint8_t *frames, size_t row_stride, size_t frame_stri
     if (c.Cin != 3 || c.Cout != 8 || c.stride != 2 || !c.relu || c.out_ctotal != 8 || c.out_coff != 0) return false;
     if (!d1.wd || d1.add || d1.Cin != 8 || d1.Cout != 16 || d1.stride != 1 || !d1.relu || d1.H != c.Ho || d1.W != c.Wo) return false;
     if (!d2.wd || d2.add || d2.Cin != 16 || d2.Cout != 32 || d2.stride != 2 || !d2.relu || d2.H != d1.Ho || d2.W != d1.Wo) return false;
-    if ((d2.Ho & 7) || (d2.Wo & 7) || d2.H != 2 * d2.Ho || d2.W != 2 * d2.Wo || d1.in != c.out || d2.in != d1.out) return false;
+    if ((c.W & 1) || (c.H & 1) || (d2.Ho & 7) || (d2.Wo & 7) || d2.H != 2 * d2.Ho || d2.W != 2 * d2.Wo || d1.in != c.out || d2.in != d1.out) return false;
     const float *w = d1.stem;
     StemArgs a{frames, row_stride, frame_stride, w + OFF_W1, w + OFF_B1, w + OFF_WDT1, w + OFF_WP1, w + OFF_BP1, w + OFF_WDT2, w + OFF_WP2, w + OFF_BP2, d2.out, c.B, c.H, c.W, c.Ho, c.Wo, d2.Ho, d2.Wo};
-    hipLaunchKernelGGL(det_stem_kernel, dim3((unsigned)(c.B * (d2.Ho >> 3) * (d2.Wo >> 3))), dim3(64), 0, s, a);
+    const int tx = d2.Wo >> 3, ty = d2.Ho >> 3;
+    if (tx < 3 || ty < 3) return false;
+    hipLaunchKernelGGL(det_stem_kernel<true>, dim3((unsigned)(c.B * (tx - 2) * (ty - 2))), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(det_stem_kernel<false>, dim3((unsigned)(c.B * (2 * tx + 2 * (ty - 2)))), dim3(64), 0, s, a);
     return true;
 }
