@@ -67,7 +67,8 @@ __device__ __forceinline__ void ld_pairs(const P w, int chunk, floatx2 (&dst)[NP
 // channel pairs they deliver are the operands of v_pk_fma_f32 (weights: scalar pairs, host-packed [pair][tap][2] for the depthwise parts).
 template <bool INTERIOR>
 __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], float (*b1s)[16], int b, int Y0, int X0) {
-    const int lane = threadIdx.x;
+    constexpr int NT = 192;  // three waves per tile split the positions of P1 and P2 (measured at 32 frames, interior + ring: one wave 134 + 68 us, two 106 + 50, four 97 + 45, three 94 + 43: more waves per LDS byte against emptier passes); wave 0 alone runs P3
+    const int lane = threadIdx.x;  // (position index in P1 / P2; < 64: the P3 lane)
     const int r2y0 = 2 * Y0 - 1, r2x0 = 2 * X0 - 1;  // block 1 region origin (H1 x W1 map)
     const int r1y0 = r2y0 - 1, r1x0 = r2x0 - 1;      // first conv region origin
 
@@ -91,12 +92,12 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
             };
             ldraw(lane, raw);
 #pragma unroll 1
-            for (int idx = lane; idx < R1 * R1; idx += 64) {
+            for (int idx = lane; idx < R1 * R1; idx += NT) {
                 int z;
                 asm volatile("s_mov_b32 %0, 0" : "=s"(z));
                 const auto w = uni(a.w1) + z;
                 const auto bias = uni(a.b1) + z;
-                ldraw(idx + 64, nxt);
+                ldraw(idx + NT, nxt);
                 float v[3][9];
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
@@ -135,7 +136,7 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
             }
         } else
 #pragma unroll 1
-        for (int idx = lane; idx < R1 * R1; idx += 64) {
+        for (int idx = lane; idx < R1 * R1; idx += NT) {
             // (an opaque zero: without it the 224 scalar weight loads are hoisted out of the loop and spilled - 569 SGPR spills)
             int z;
             asm volatile("s_mov_b32 %0, 0" : "=s"(z));
@@ -211,7 +212,7 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
     // ---- P2: conv_dw 8 -> 16 (dwpw_row4_kernel<16>'s arithmetic) at the R2 x R2 positions
     {
 #pragma unroll 1
-        for (int idx = lane; idx < R2 * R2; idx += 64) {
+        for (int idx = lane; idx < R2 * R2; idx += NT) {
             int z;
             asm volatile("s_mov_b32 %0, 0" : "=s"(z));
             const auto wdt = uni(a.wdt1) + z, wp = uni(a.wp1) + z, bp = uni(a.bp1) + z;
@@ -265,6 +266,7 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
     __syncthreads();
 
     // ---- P3: conv_dw 16 -> 32 at stride 2; lane = output pixel (py, px) of the tile
+    if (lane >= 64) return;
     const int py = lane >> 3, px = lane & 7;
     const int r = lane & 31, hi = lane >> 5;
     floatx2 d2[8];
@@ -325,7 +327,7 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
 // Two launches: the interior tiles (everything but the outermost ring of 8x8 tiles) and the ring.  As one kernel with a run-time branch the
 // register allocation was the border path's (93 scalar spills in the interior loops).
 template <bool INTERIOR>
-__global__ __launch_bounds__(64) void det_stem_kernel(StemArgs a) {
+__global__ __launch_bounds__(192) void det_stem_kernel(StemArgs a) {
     __shared__ __attribute__((aligned(16))) float c1[R1 * R1][8];
     __shared__ __attribute__((aligned(16))) float b1s[R2 * R2][16];
     const int tiles_x = a.W2 >> 3, tiles_y = a.H2 >> 3;
@@ -363,7 +365,7 @@ void det_stem_pack(const Conv3Args &c, const DwPwArgs &d1, const DwPwArgs &d2, f
 // d1.stem: the buffer det_stem_pack() filled
 bool launch_det_stem(const uint8_t *frames, size_t row_stride, size_t frame_stride, const Conv3Args &c, const DwPwArgs &d1, const DwPwArgs &d2, hipStream_t s) {
     static const bool on = !(frt_tuning_env("FRT_DET_STEM") && frt_tuning_env("FRT_DET_STEM")[0] == '0');
-    static const int min_b = frt_tuning_env("FRT_DET_STEM_MINB") ? atoi(frt_tuning_env("FRT_DET_STEM_MINB")) : 12;  // (4 frames: 50 us against 43 for the three kernels)
+    static const int min_b = frt_tuning_env("FRT_DET_STEM_MINB") ? atoi(frt_tuning_env("FRT_DET_STEM_MINB")) : 2;  // (us, this / the three kernels: 1 frame 27 / 27.5, 2: 29 / 31, 4: 41 / 42.5, 8: 54 / 72, 32: 137 / 266)
     if (!on || !det_mfma_enabled() || !d1.stem || c.B < min_b) return false;
     if (c.Cin != 3 || c.Cout != 8 || c.stride != 2 || !c.relu || c.out_ctotal != 8 || c.out_coff != 0) return false;
     if (!d1.wd || d1.add || d1.Cin != 8 || d1.Cout != 16 || d1.stride != 1 || !d1.relu || d1.H != c.Ho || d1.W != c.Wo) return false;
@@ -373,7 +375,7 @@ bool launch_det_stem(const uint8_t *frames, size_t row_stride, size_t frame_stri
     StemArgs a{frames, row_stride, frame_stride, w + OFF_W1, w + OFF_B1, w + OFF_WDT1, w + OFF_WP1, w + OFF_BP1, w + OFF_WDT2, w + OFF_WP2, w + OFF_BP2, d2.out, c.B, c.H, c.W, c.Ho, c.Wo, d2.Ho, d2.Wo};
     const int tx = d2.Wo >> 3, ty = d2.Ho >> 3;
     if (tx < 3 || ty < 3) return false;
-    hipLaunchKernelGGL(det_stem_kernel<true>, dim3((unsigned)(c.B * (tx - 2) * (ty - 2))), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(det_stem_kernel<false>, dim3((unsigned)(c.B * (2 * tx + 2 * (ty - 2)))), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(det_stem_kernel<true>, dim3((unsigned)(c.B * (tx - 2) * (ty - 2))), dim3(192), 0, s, a);
+    hipLaunchKernelGGL(det_stem_kernel<false>, dim3((unsigned)(c.B * (2 * tx + 2 * (ty - 2)))), dim3(192), 0, s, a);
     return true;
 }
