@@ -94,6 +94,7 @@ for B in 32 4; do
 done
 cd "$ROOT"
 python tools/dwpw_wave_check.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/${TAG}_dwpw_wave_check.txt"
+FRT_LIB=$ROOT/face-recognition-cpp-tensorrt_amd/libfrt_tuning.so FRT_DET_STEM_CHECK=1 python tools/stem_check_run.py 2>&1 | grep "stem check" > "$OUT/${TAG}_stem_check.txt"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFRT_TUNING -w -Iface-recognition-cpp-tensorrt_amd/csrc -o /tmp/dwpw_wave_bench tools/ubench/dwpw_wave_bench.hip 2>/dev/null &&
   for A in "32" "2" "32 64 80" "2 64 80" "32 256 20" "2 256 20"; do FRT_DWPW_WAVE_ANYB=1 timeout 60 /tmp/dwpw_wave_bench $A; done > "$OUT/${TAG}_dwpw_wave_bench.txt" 2>&1
 ls -la "$OUT"
