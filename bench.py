@@ -743,7 +743,9 @@ def main():
                              "achieved_TBps": round(det_bytes / (stage_ms["detector"] * 1e-3) / 1e12, 3) if stage_ms["detector"] > 0 else None,
                              "frac_hbm": frac(det_bytes, stage_ms["detector"], PEAK_HBM_BPS),
                              "frac_fp32_matrix": frac(det_flop, stage_ms["detector"], PEAK_FP32_MATRIX_TFLOPS * 1e12),
-                             "note": "fp32 NCHW activations, every tensor written once and read once (27.45 M elements per 640x640 frame, DESIGN 3)"},
+                             "note": "ALGORITHMIC bytes: fp32 NCHW activations, every tensor of the layer-by-layer network written once and read once (27.45 M "
+                                     "elements per 640x640 frame, DESIGN 3); since round 4 the fused stem kernel never writes two of them (-0.63 GB per 32 "
+                                     "frames), so frac_hbm prices the work done, not the traffic on the bus"},
                 "recogniser": {"bound": "mfma", "ms": round(stage_ms["recogniser"], 4), "flop": rec_flop,
                                "achieved_TFLOPs": round(rec_flop / (stage_ms["recogniser"] * 1e-3) / 1e12, 1) if stage_ms["recogniser"] > 0 else None,
                                "frac_mfma": frac(rec_flop, stage_ms["recogniser"], PEAK_FP16_MFMA_TFLOPS * 1e12),

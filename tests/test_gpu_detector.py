@@ -151,3 +151,23 @@ def test_batch_size_classes_of_the_conv_dw_kernels_agree_bit_for_bit(frt, synth,
     small.close()
     oloc, oconf = nets.retinaface_forward(sd, x[12:14])
     assert np.abs(loc16[12:14] - oloc).max() < LOC_TOL and np.abs(conf16[12:14] - oconf).max() < CONF_TOL
+
+
+@pytest.mark.parametrize("hw", [(256, 320), (192, 192), (320, 448)])
+def test_fused_stem_equals_the_staged_path_on_other_identity_geometries(frt, synth, blobs, hw):
+    """Round 4: from two frames per call whose size equals the network input, the first conv and the first two conv_dw blocks run as ONE kernel
+    (kernels_det_stem.hip: 8x8 output tiles, an interior and a ring launch).  Same arithmetic as the three kernels: four frames through findFaceBatch
+    must give exactly what preprocess -> doInference -> postprocessing gives frame by frame (separate preprocess kernel, generic first conv,
+    stand-alone conv_dw kernels) - on non-square maps and on maps whose ring is most of the tiles."""
+    h, w = hw
+    path, _ = blobs("det")
+    det = frt.RetinaFace(path, w, h, (3, h, w), 4, 8, 0.4, 0.02)
+    frames = synth.make_frames(4, h, w)
+    fused = det.findFaceBatch(frames)
+    for i in range(4):
+        loc, conf = det.doInference(det.preprocess(frames[i])[None])
+        staged = det.postprocessing(loc[0], conf[0])
+        assert len(fused[i]) == len(staged) > 0
+        for k in ("x1", "y1", "x2", "y2", "score"):
+            assert np.array_equal(fused[i][k], staged[k]), (hw, i, k)
+    det.close()
