@@ -13,7 +13,7 @@
 // Arithmetic: every chain is the stand-alone kernels' chain (det_conv1_u8_kernel, dwpw_row4_kernel<16>, dwpw_mfma_kernel<4, 1, 16, 1, 2>'s fp32
 // MFMA path: same operand order, same fma order) - the output is bit-identical: tuning build, FRT_DET_STEM_CHECK=1 python tools/stem_check_run.py
 // runs the three kernels and this one on the same frames and compares the 32-channel tensor element for element; in the GPU suite
-// tests/test_gpu_detector.py::test_batch_of_32_equals_frame_by_frame (one frame per call takes the three kernels, 32 frames this one).
+// tests/test_gpu_detector.py::test_batch_of_32_equals_frame_by_frame (32 frames in one call against one frame per call) and test_fused_stem_equals_the_staged_path_on_other_identity_geometries (against the three kernels).
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -326,28 +326,32 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
 
 // Two launches: the interior tiles (everything but the outermost ring of 8x8 tiles) and the ring.  As one kernel with a run-time branch the
 // register allocation was the border path's (93 scalar spills in the interior loops).
-template <bool INTERIOR>
-__global__ __launch_bounds__(192) void det_stem_kernel(StemArgs a) {
+// ONE launch, interior tiles first, then the ring: blockIdx.x < n_interior selects.  (As two launches the register allocation of the interior loops
+// is cleaner - 9 scalar spills against 99 - but the ring's few, slow workgroups then run alone: 94 + 43 us against 133 at 32 frames, 23 + 18
+// against 33 at 4, 14 + 13 against 16.5 at one.)
+__global__ __launch_bounds__(192) void det_stem_kernel(StemArgs a, int n_interior) {
     __shared__ __attribute__((aligned(16))) float c1[R1 * R1][8];
     __shared__ __attribute__((aligned(16))) float b1s[R2 * R2][16];
     const int tiles_x = a.W2 >> 3, tiles_y = a.H2 >> 3;
     int t = blockIdx.x, b, ty, tx;
-    if (INTERIOR) {
+    if (t < n_interior) {
         const int ix = tiles_x - 2, per = ix * (tiles_y - 2);
         b = t / per;
         t -= b * per;
         ty = t / ix;
         tx = t - ty * ix + 1;
         ty += 1;
+        stem_body<true>(a, c1, b1s, b, ty * 8, tx * 8);
     } else {  // the ring: top row, bottom row, then the left / right columns of the rows in between
+        t -= n_interior;
         const int per = 2 * tiles_x + 2 * (tiles_y - 2);
         b = t / per;
         t -= b * per;
         if (t < tiles_x) { ty = 0; tx = t; }
         else if (t < 2 * tiles_x) { ty = tiles_y - 1; tx = t - tiles_x; }
         else { t -= 2 * tiles_x; ty = 1 + (t >> 1); tx = (t & 1) ? tiles_x - 1 : 0; }
+        stem_body<false>(a, c1, b1s, b, ty * 8, tx * 8);
     }
-    stem_body<INTERIOR>(a, c1, b1s, b, ty * 8, tx * 8);
 }
 
 }  // namespace
@@ -365,7 +369,7 @@ void det_stem_pack(const Conv3Args &c, const DwPwArgs &d1, const DwPwArgs &d2, f
 // d1.stem: the buffer det_stem_pack() filled
 bool launch_det_stem(const uint8_t *frames, size_t row_stride, size_t frame_stride, const Conv3Args &c, const DwPwArgs &d1, const DwPwArgs &d2, hipStream_t s) {
     static const bool on = !(frt_tuning_env("FRT_DET_STEM") && frt_tuning_env("FRT_DET_STEM")[0] == '0');
-    static const int min_b = frt_tuning_env("FRT_DET_STEM_MINB") ? atoi(frt_tuning_env("FRT_DET_STEM_MINB")) : 2;  // (us, this / the three kernels: 1 frame 27 / 27.5, 2: 29 / 31, 4: 41 / 42.5, 8: 54 / 72, 32: 137 / 266)
+    static const int min_b = frt_tuning_env("FRT_DET_STEM_MINB") ? atoi(frt_tuning_env("FRT_DET_STEM_MINB")) : 1;  // (us, this / the three kernels: 1 frame 16.5 / 27.5, 2: 20 / 31, 4: 33 / 42.5, 8: 48 / 72, 32: 133 / 266)
     if (!on || !det_mfma_enabled() || !d1.stem || c.B < min_b) return false;
     if (c.Cin != 3 || c.Cout != 8 || c.stride != 2 || !c.relu || c.out_ctotal != 8 || c.out_coff != 0) return false;
     if (!d1.wd || d1.add || d1.Cin != 8 || d1.Cout != 16 || d1.stride != 1 || !d1.relu || d1.H != c.Ho || d1.W != c.Wo) return false;
@@ -375,7 +379,7 @@ bool launch_det_stem(const uint8_t *frames, size_t row_stride, size_t frame_stri
     StemArgs a{frames, row_stride, frame_stride, w + OFF_W1, w + OFF_B1, w + OFF_WDT1, w + OFF_WP1, w + OFF_BP1, w + OFF_WDT2, w + OFF_WP2, w + OFF_BP2, d2.out, c.B, c.H, c.W, c.Ho, c.Wo, d2.Ho, d2.Wo};
     const int tx = d2.Wo >> 3, ty = d2.Ho >> 3;
     if (tx < 3 || ty < 3) return false;
-    hipLaunchKernelGGL(det_stem_kernel<true>, dim3((unsigned)(c.B * (tx - 2) * (ty - 2))), dim3(192), 0, s, a);
-    hipLaunchKernelGGL(det_stem_kernel<false>, dim3((unsigned)(c.B * (2 * tx + 2 * (ty - 2)))), dim3(192), 0, s, a);
+    const int n_int = c.B * (tx - 2) * (ty - 2), n_ring = c.B * (2 * tx + 2 * (ty - 2));
+    hipLaunchKernelGGL(det_stem_kernel, dim3((unsigned)(n_int + n_ring)), dim3(192), 0, s, a, n_int);
     return true;
 }
