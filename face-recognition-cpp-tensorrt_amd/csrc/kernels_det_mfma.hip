@@ -23,6 +23,7 @@
 // Pixel mapping: 8x16 2-D tiles where the map is wide (halo re-read 1.4x instead of 3x), linear order over (b, y, x) on the
 // small maps (no tile-shape waste at 40x40 / 20x20).  Logical tiles are assigned so that every XCD's L2 sees a contiguous
 // range (neighbouring tiles share halo rows).
+#include <algorithm>
 #include <cstdlib>
 
 #include "frt_kernels.h"
@@ -287,11 +288,16 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
 // ---------------------------------------------------------------- plain 1x1 conv, one wave = 32 pixels x CBW*32 output channels
 template <int CBW, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_groups) {
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave id
+    // Persistent waves (round 4): a wave lives ~ 4 us here, 70 % of it in s_waitcnt, and the counters put 1.5 waves per CU in flight on average
+    // (profiles/r04x_det_pmc.txt).  The grid is now what fits the chip at once and every wave walks its share of the (pixel group, channel
+    // group) items; with the scalar-base addressing (240 -> 180 / 168 -> 104 registers) that is 61 -> 59 us for the 64-channel lateral at
+    // 80x80 and 23 -> 18.5 us for the other two at 32 frames, 13 -> 11.6 us at 4 - the wide one is still not understood (1.9 TB/s, clean
+    // 128-byte accesses).
     const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
     const int n_cgroups = (a.Cout + CBW * 32 - 1) / (CBW * 32);
+    const int n_items = n_pix_groups * n_cgroups;
+    for (int gw = blockIdx.x * 4 + (threadIdx.x >> 6); gw < n_items; gw += gridDim.x * 4) {
     const int pg = gw / n_cgroups, cg = gw - pg * n_cgroups;
-    if (pg >= n_pix_groups) return;
     const int HW = a.H * a.W;  // == Ho*Wo (stride 1)
     const long g = (long)pg * 32 + r;
     const bool ok = g < (long)a.B * HW;
@@ -310,16 +316,20 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
     if constexpr (SPLIT) {
         // fp16 hi/lo split (see dwpw_mfma_kernel): per 16 input channels a lane fetches its 8 channel values of the pixel (the same
         // 8 scalar loads the fp32 path spends on 8 k-steps), splits them, and three fp16 MFMAs replace eight fp32 ones
-        const float *xs = a.in + (long)b * a.Cin * HW + p + (long)(8 * hi) * HW;
         const int ngroups = a.Cin / 16;
         // activations FOUR groups ahead (32 registers), weights (L2 hits) one: with one group in flight a wave paid the HBM latency once per 16
         // channels, and few waves fit a CU (round 4: lateral 64->64 at 80x80 61 -> see profiles/r04v_laterals.txt)
         constexpr int DA = 4;
         float bx[DA][8];
         half8 ah[CBW], al[CBW], nah[CBW], nal[CBW];
+        // addresses as (uniform 64-bit base) + (32-bit lane offset): the scalar-base form of global_load.  As per-lane 64-bit pointers the
+        // compiler kept one register pair per load in flight and the kernel sat at 240 VGPRs = two waves per SIMD
+        const char *xin_c = reinterpret_cast<const char *>(a.in);
+        const unsigned xs_off = (unsigned)((((long)b * a.Cin + 8 * hi) * HW + p) * 4);
         auto load_x = [&](int g, float (&bxv)[8]) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bxv[e] = (ok && g < ngroups) ? xs[(long)(16 * g + e) * HW] : 0.f;
+            for (int e = 0; e < 8; ++e)
+                bxv[e] = (ok && g < ngroups) ? *reinterpret_cast<const float *>(xin_c + (size_t)(16 * g + e) * HW * 4 + (size_t)xs_off) : 0.f;
         };
         auto load_w = [&](int g, half8 (&dh)[CBW], half8 (&dl)[CBW]) {
 #pragma unroll
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
     }
     }
 
-    if (!ok) return;
+    if (!ok) continue;
     const int oy = p / a.W, ox = p - oy * a.W;
     const float *addb = nullptr;
     long add_cs = 0;
@@ -411,31 +421,35 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
         add_cs = (long)a.add_h * a.add_w;
         addb = a.add + (long)b * a.Cout * add_cs + ah * a.add_w + awd;
     }
-    float *ob = a.out + (long)b * a.Cout * HW + p;
-    // every load of the epilogue before its first store (the output may alias the add source for all the compiler knows: left alone it
-    // serialises load -> store -> load)
-    float bias_v[CBW][16], add_v[CBW][16];
+    // (addresses again as uniform base + 32-bit lane offset; every load of the epilogue before its first store: the output may alias the add
+    //  source for all the compiler knows, left alone it serialises load -> store -> load)
+    char *out_c = reinterpret_cast<char *>(a.out);
+    const char *add_c = reinterpret_cast<const char *>(a.add), *bp_c = reinterpret_cast<const char *>(a.bp);
+    const int co_l = co_base + 4 * hi;  // this lane's first channel; + cb * 32 + (e & 3) + 8 * (e >> 2)
+    const unsigned out_off = (unsigned)((((long)b * a.Cout + co_l) * HW + p) * 4);
+    const unsigned add_off = addb ? (unsigned)(((addb - a.add) + (long)co_l * add_cs) * 4) : 0u;
 #pragma unroll
-    for (int cb = 0; cb < CBW; ++cb)
+    for (int cb = 0; cb < CBW; ++cb) {  // (one 32-channel block at a time: 32 live values instead of 64)
+        float bias_v[16], add_v[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-            const bool cok = co < a.Cout;
-            bias_v[cb][e] = cok ? a.bp[co] : 0.f;
-            add_v[cb][e] = (cok && addb) ? addb[co * add_cs] : 0.f;
+            const int cu = cb * 32 + (e & 3) + 8 * (e >> 2);  // uniform part of the channel
+            const bool cok = co_l + cu < a.Cout;
+            bias_v[e] = cok ? *reinterpret_cast<const float *>(bp_c + (size_t)cu * 4 + (size_t)(unsigned)(co_l * 4)) : 0.f;
+            add_v[e] = (cok && addb) ? *reinterpret_cast<const float *>(add_c + (size_t)cu * add_cs * 4 + (size_t)add_off) : 0.f;
         }
 #pragma unroll
-    for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-            if (co < a.Cout) {
-                float v = acc[cb][e] + bias_v[cb][e];
+            const int cu = cb * 32 + (e & 3) + 8 * (e >> 2);
+            if (co_l + cu < a.Cout) {
+                float v = acc[cb][e] + bias_v[e];
                 if (a.relu) v = fmaxf(v, 0.f);
-                if (addb) v += add_v[cb][e];
-                ob[(long)co * HW] = v;
+                if (addb) v += add_v[e];
+                *reinterpret_cast<float *>(out_c + (size_t)cu * HW * 4 + (size_t)out_off) = v;
             }
         }
+    }
+    }  // persistent item loop
 }
 
 template <int NPW, int NCW, int KC, int CBW, bool MODE2D>
@@ -487,7 +501,9 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
         const int cbw = wide ? 2 : 1;
         const int n_cgroups = (a.Cout + cbw * 32 - 1) / (cbw * 32);
         const long waves = (long)n_pix_groups * n_cgroups;
-        const unsigned grid = (unsigned)((waves + 3) / 4);
+        // (persistent: two 256-thread workgroups per CU for the wide variant (180 registers), four for the narrow one (104))
+        const unsigned cap = wide ? 2 * 256 : 4 * 256;
+        const unsigned grid = (unsigned)std::min<long>((waves + 3) / 4, cap);
         static const bool split = !(frt_tuning_env("FRT_DET_PW_SPLIT") && frt_tuning_env("FRT_DET_PW_SPLIT")[0] == '0');
         if (split && a.wph && a.Cin % 16 == 0) {
             if (wide) hipLaunchKernelGGL((pw_mfma_kernel<2, true>), dim3(grid), dim3(256), 0, s, a, n_pix_groups);
