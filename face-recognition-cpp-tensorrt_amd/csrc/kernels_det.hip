@@ -158,12 +158,13 @@ template <int CT, int NS = 2>
 __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
     constexpr int REC = 12 + CT;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int co0 = blockIdx.y * CT;  // (grid.y > 1: a frame or two, narrower channel tiles = more waves; the depthwise part is recomputed per tile)
     for (int i = threadIdx.x; i < a.Cin * REC; i += 256) {
         const int ci = i / REC, r = i - ci * REC;
         float v = 0.f;
         if (r < 9) v = a.wd[ci * 9 + r];
         else if (r == 9) v = a.bd[ci];
-        else if (r >= 12) v = a.wp[(long)ci * a.Cout + (r - 12)];
+        else if (r >= 12) v = a.wp[(long)ci * a.Cout + co0 + (r - 12)];
         wsm[i] = v;
     }
     __syncthreads();
@@ -249,13 +250,13 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
             }
         }
     }
-    float *ob = a.out + (long)b * a.Cout * HW + oh * a.W + ow0;
+    float *ob = a.out + ((long)b * a.Cout + co0) * HW + oh * a.W + ow0;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         floatx4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float v = acc[q][c] + a.bp[c];
+            float v = acc[q][c] + a.bp[co0 + c];
             if (a.relu) v = fmaxf(v, 0.f);
             o[q] = v;
         }
@@ -332,6 +333,77 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Multi mm) {
             for (int c = 0; c < CT; ++c) acc[c] = fmaf(v[t], w[t * a.Cout + c], acc[c]);
     }
     // channel tiles at or beyond `split` belong to the second output tensor (two convs that share their input, run as one)
+    float *ob = (a.out2 && co0 >= a.split) ? a.out2 + ((long)b * a.out2_ctotal + a.out2_coff + co0 - a.split) * HoWo + p
+                                           : a.out + ((long)b * a.out_ctotal + a.out_coff + co0) * HoWo + p;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        float v = acc[c] + a.b[co0 + c];
+        if (a.relu) v = fmaxf(v, 0.f);
+        ob[(long)c * HoWo] = v;
+    }
+}
+
+// ---------------------------------------------------------------- the same conv for a frame or two: weights through LDS, UNR channels' taps in flight
+// conv3x3_kernel fetches its 144 weights per input channel through the scalar cache, in register-sized batches that wait on each other: at
+// 32 frames other waves hide that, at one frame (8 400 pixels on three levels = 1 wave per SIMD) it IS the kernel: 22 us for 39 MFLOP.  Here the
+// workgroup copies its (level, channel tile)'s weights to LDS once ([Cin * 9][CT], 9 KB), reads them back as broadcast ds_read_b128 and keeps
+// the taps of UNR input channels in flight.  Same products in the same order (ci outer, tap inner, one fmaf each): bit-identical results.
+template <int CT, int UNR>
+__global__ __launch_bounds__(256) void conv3x3_ldsw_kernel(Conv3Multi mm) {
+    const Conv3Args &a = mm.p[blockIdx.z];
+    const int HoWo = a.Ho * a.Wo;
+    const long total = (long)a.B * HoWo;
+    if ((long)blockIdx.x * 256 >= total || (int)blockIdx.y * CT >= a.Cout) return;  // (uniform over the workgroup)
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int co0 = blockIdx.y * CT;
+    for (int i = threadIdx.x; i < a.Cin * 9 * (CT / 4); i += 256) {
+        const int row = i / (CT / 4), c4 = i - row * (CT / 4);
+        *reinterpret_cast<floatx4 *>(wsm + row * CT + c4 * 4) = *reinterpret_cast<const floatx4 *>(a.w + (long)row * a.Cout + co0 + c4 * 4);
+    }
+    __syncthreads();
+    const long gp = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gp >= total) return;
+    const int b = (int)(gp / HoWo), p = (int)(gp - (long)b * HoWo);
+    const int oh = p / a.Wo, ow = p - oh * a.Wo;
+    const int HW = a.H * a.W;
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+    const int ih0 = oh * a.stride - 1, iw0 = ow * a.stride - 1;
+    int off[9];
+    bool ok[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ih = ih0 + kh, iw = iw0 + kw;
+            ok[kh * 3 + kw] = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            off[kh * 3 + kw] = ok[kh * 3 + kw] ? ih * a.W + iw : 0;
+        }
+    const float *inb = a.in + (long)b * a.Cin * HW;
+    for (int ci = 0; ci < a.Cin; ci += UNR) {
+        float v[UNR][9];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const float *x = inb + (long)(ci + u) * HW;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[u][t] = ok[t] ? x[off[t]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const float *w = wsm + (ci + u) * 9 * CT;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c4 = 0; c4 < CT; c4 += 4) {
+                    const floatx4 ww = *reinterpret_cast<const floatx4 *>(w + t * CT + c4);
+                    acc[c4] = fmaf(v[u][t], ww[0], acc[c4]);
+                    acc[c4 + 1] = fmaf(v[u][t], ww[1], acc[c4 + 1]);
+                    acc[c4 + 2] = fmaf(v[u][t], ww[2], acc[c4 + 2]);
+                    acc[c4 + 3] = fmaf(v[u][t], ww[3], acc[c4 + 3]);
+                }
+        }
+    }
     float *ob = (a.out2 && co0 >= a.split) ? a.out2 + ((long)b * a.out2_ctotal + a.out2_coff + co0 - a.split) * HoWo + p
                                            : a.out + ((long)b * a.out_ctotal + a.out_coff + co0) * HoWo + p;
 #pragma unroll
@@ -517,9 +589,15 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
         // (ring depth measured on the 8 -> 16 block: 98 / 97 / 99 us with 1 / 2 / 3 channels in flight - the kernel waits on memory 60 % of
         //  its wave cycles but not for lack of bytes in flight; default = the shallow ring, 176 registers)
         static const int ns16 = frt_tuning_env("FRT_ROW4_NS") ? atoi(frt_tuning_env("FRT_ROW4_NS")) : 2;
+        static const bool split32 = !(frt_tuning_env("FRT_ROW4_SPLIT32") && frt_tuning_env("FRT_ROW4_SPLIT32")[0] == '0');
         if (a.Cout == 16 && ns16 == 4) hipLaunchKernelGGL((dwpw_row4_kernel<16, 4>), grid, dim3(256), lds, s, a);
         else if (a.Cout == 16 && ns16 == 3) hipLaunchKernelGGL((dwpw_row4_kernel<16, 3>), grid, dim3(256), lds, s, a);
         else if (a.Cout == 16) hipLaunchKernelGGL((dwpw_row4_kernel<16, 2>), grid, dim3(256), lds, s, a);
+        // 32 -> 32 at a frame or two (25 workgroups per frame, one wave per SIMD, 29 us whatever the ring depth): the output channels split over
+        // grid.y, depthwise part recomputed per tile - 20.9 us at 1 frame with four 8-channel tiles, 24.9 against 29.8 at 4 frames with two 16-channel
+        // tiles; from 8 frames the full tile wins (31 us).  Same chain per output: bit-identical.
+        else if (a.Cout == 32 && split32 && grid.x <= 64) hipLaunchKernelGGL((dwpw_row4_kernel<8, 2>), dim3(grid.x, 4), dim3(256), (size_t)a.Cin * 20 * sizeof(float), s, a);
+        else if (a.Cout == 32 && split32 && grid.x <= 128) hipLaunchKernelGGL((dwpw_row4_kernel<16, 4>), dim3(grid.x, 2), dim3(256), (size_t)a.Cin * 28 * sizeof(float), s, a);
         else hipLaunchKernelGGL((dwpw_row4_kernel<32, 2>), grid, dim3(256), lds, s, a);
         return;
     }
@@ -562,6 +640,16 @@ void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s) {
     for (int i = n; i < 3; ++i) mm.p[i] = a[0];
     const unsigned gx = (unsigned)((max_total + 255) / 256);
     const bool two_out = a[0].out2 != nullptr;  // the split must fall on a channel-tile boundary: 16-channel tiles
+    // a few frames: the LDS-weight variant (bit-identical).  Measured per launch, conv3x3_kernel<16> / this: 22.4 / 10.7 us at 1 frame (8-channel
+    // tiles, all 16 input channels' taps in flight), 23.4 / 16.0 at 4 frames (16-channel tiles), equal at 8, 43 / 60 at 32
+    static const int ldsw = frt_tuning_env("FRT_C3_LDSW") ? atoi(frt_tuning_env("FRT_C3_LDSW")) : 1;  // 0: off, 2: at every batch size
+    bool ldsw_ok = ldsw && cout % 16 == 0 && (ldsw == 2 || gx <= 128);
+    for (int i = 0; i < n; ++i) ldsw_ok = ldsw_ok && a[i].Cin == 16 && a[i].Cout == cout && !(reinterpret_cast<uintptr_t>(a[i].w) & 15);
+    if (ldsw_ok) {
+        if (gx <= 32) hipLaunchKernelGGL((conv3x3_ldsw_kernel<8, 16>), dim3(gx, cout / 8, n), dim3(256), (size_t)16 * 9 * 8 * sizeof(float), s, mm);
+        else hipLaunchKernelGGL((conv3x3_ldsw_kernel<16, 4>), dim3(gx, cout / 16, n), dim3(256), (size_t)16 * 9 * 16 * sizeof(float), s, mm);
+        return;
+    }
     if (cout % 32 == 0 && max_total >= 256L * 256 && !(two_out && a[0].split % 32))
         hipLaunchKernelGGL((conv3x3_kernel<32>), dim3(gx, cout / 32, n), dim3(256), 0, s, mm);
     else if (cout % 16 == 0)

@@ -135,7 +135,7 @@ def test_box_census(frt, blobs, geo, frames, max_differing):
 def test_batch_size_classes_of_the_conv_dw_kernels_agree_bit_for_bit(frt, synth, blobs):
     """Round 4: at 640x640 the 64->64 (80x80), 128->128 (40x40) and 256->256 (20x20) conv_dw blocks run on dwpw_wave_kernel from 3 / 12 / 12 frames per
     call upwards and on dwpw_mfma_kernel below (kernels_det_wave.hip: same arithmetic operation for operation).  16 frames in one call must give
-    the head outputs of the same frames in calls of 2, bit for bit - and the oracle's within the usual tolerance."""
+    the head outputs of the same frames in calls of 1, 2 and 4, bit for bit - and the oracle's within the usual tolerance."""
     from oracle import nets
     path, sd = blobs("det")
     fr = np.concatenate([synth.make_frames(4, 640, 640), synth.make_frames(4, 640, 640)[:, ::-1], synth.make_frames(4, 640, 640)[:, :, ::-1],
@@ -149,6 +149,14 @@ def test_batch_size_classes_of_the_conv_dw_kernels_agree_bit_for_bit(frt, synth,
         loc2, conf2 = small.doInference(x[i:i + 2])
         assert np.array_equal(loc2, loc16[i:i + 2]) and np.array_equal(conf2, conf16[i:i + 2]), i
     small.close()
+    # the 32 -> 32 block and the 16-channel SSH convs have their own kernels for 1, 2 - 5 and more frames per call (kernels_det.hip: output-channel
+    # tiles over grid.y, weights through LDS): calls of 1 and of 4 frames as well
+    for nb in (1, 4):
+        det = frt.RetinaFace(path, 640, 640, (3, 640, 640), nb, 4)
+        for i in range(0, 8, nb):
+            locn, confn = det.doInference(x[i:i + nb])
+            assert np.array_equal(locn, loc16[i:i + nb]) and np.array_equal(confn, conf16[i:i + nb]), (nb, i)
+        det.close()
     oloc, oconf = nets.retinaface_forward(sd, x[12:14])
     assert np.abs(loc16[12:14] - oloc).max() < LOC_TOL and np.abs(conf16[12:14] - oconf).max() < CONF_TOL
 
