@@ -264,6 +264,89 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- fused conv_dw block for a frame or two: thread = pixel, branch-free taps
+// dwpw_row4_kernel at one frame of 160x160 is 25 workgroups - one wave on a tenth of the SIMDs, each issuing its 6 400 instructions alone
+// (29 us); dwpw_kernel has the threads but its nine exec-masked loads per channel compile to nine branches (15 us, 26 per frame from two
+// frames on).  Here the taps are BUFFER loads - a tap outside the image gets an offset past the buffer's size and reads as 0, no branch, no
+// select - the input channel is the scalar offset, UNR channels' taps (9 * UNR loads) are in flight ahead of the channel group being
+// consumed, and the output channels are split into CT-wide tiles over grid.y (depthwise part recomputed per tile: the chip is empty anyway).
+// Same chain per output as the other two kernels (dw bias, nine fmaf, ReLU; then one fmaf per input channel in channel order): bit-identical.
+template <int CT, int UNR>
+__global__ __launch_bounds__(256) void dwpw_pixs_kernel(DwPwArgs a) {
+    constexpr int REC = 12 + CT;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int co0 = blockIdx.y * CT;
+    for (int i = threadIdx.x; i < a.Cin * REC; i += 256) {
+        const int ci = i / REC, r = i - ci * REC;
+        float v = 0.f;
+        if (r < 9) v = a.wd[ci * 9 + r];
+        else if (r == 9) v = a.bd[ci];
+        else if (r >= 12) v = a.wp[(long)ci * a.Cout + co0 + (r - 12)];
+        wsm[i] = v;
+    }
+    __syncthreads();
+    const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
+    const long total = (long)a.B * HoWo;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gq = g < total ? g : total - 1;  // (the last workgroup's spare threads redo the last pixel and do not store)
+    const int b = (int)(gq / HoWo), p = (int)(gq - (long)b * HoWo);
+    const int oh = p / a.Wo, ow = p - oh * a.Wo;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, (int)((long)a.B * a.Cin * HW * 4), 0x00020000);
+    int vo[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ih = oh * a.stride - 1 + t / 3, iw = ow * a.stride - 1 + t % 3;
+        vo[t] = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? (int)((((long)b * a.Cin * a.H + ih) * a.W + iw) * 4) : (int)0x80000000;
+    }
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+    float v[2][UNR][9];
+    auto fetch = [&](int ci0, int slot) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[slot][u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[t], (ci0 + u) * HW * 4, 0));
+    };
+    auto consume = [&](int ci0, int slot) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const float *rec = wsm + (ci0 + u) * REC;
+            const floatx4 w0 = *reinterpret_cast<const floatx4 *>(rec);
+            const floatx4 w1 = *reinterpret_cast<const floatx4 *>(rec + 4);
+            const floatx4 w2 = *reinterpret_cast<const floatx4 *>(rec + 8);
+            const float wt[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0]};
+            float sacc = w2[1];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sacc = fmaf(v[slot][u][t], wt[t], sacc);
+            const float d = fmaxf(sacc, 0.f);
+#pragma unroll
+            for (int c4 = 0; c4 < CT; c4 += 4) {
+                const floatx4 w = *reinterpret_cast<const floatx4 *>(rec + 12 + c4);
+                acc[c4] = fmaf(d, w[0], acc[c4]);
+                acc[c4 + 1] = fmaf(d, w[1], acc[c4 + 1]);
+                acc[c4 + 2] = fmaf(d, w[2], acc[c4 + 2]);
+                acc[c4 + 3] = fmaf(d, w[3], acc[c4 + 3]);
+            }
+        }
+    };
+    fetch(0, 0);
+    for (int ci = 0; ci < a.Cin; ci += 2 * UNR) {  // (Cin % (2 * UNR) == 0: checked by the launcher)
+        fetch(ci + UNR, 1);
+        consume(ci, 0);
+        if (ci + 2 * UNR < a.Cin) fetch(ci + 2 * UNR, 0);
+        consume(ci + UNR, 1);
+    }
+    if (g >= total) return;
+    float *ob = a.out + ((long)b * a.Cout + co0) * HoWo + p;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        float o = acc[c] + a.bp[co0 + c];
+        if (a.relu) o = fmaxf(o, 0.f);
+        ob[(long)c * HoWo] = o;
+    }
+}
+
 // ---------------------------------------------------------------- depthwise 3x3 + bias + ReLU (split path), thread = (b, c, pixel)
 __global__ __launch_bounds__(256) void dw_kernel(DwPwArgs a) {
     const int HoWo = a.Ho * a.Wo;
@@ -582,6 +665,15 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
     const long blocks = (total + 255) / 256;
     // stride-1 blocks whose one channel tile covers every output channel: four pixels of a row per thread
     static const bool row4 = !(frt_tuning_env("FRT_DWPW_ROW4") && frt_tuning_env("FRT_DWPW_ROW4")[0] == '0');
+    // the 32 -> 32 block at a few frames per call: thread = pixel with branch-free taps.  Measured per launch (us), dwpw_row4_kernel / this:
+    // 29.3 / 12.7 at 1 frame and 29.3 / 17.4 at 2 (two 16-channel tiles over grid.y), 29.8 / 21.3 at 4 (one tile); 31 / 40 at 8 (nine dword
+    // loads per pixel and channel: the texture path saturates at ~ 9 lanes per CU and clock)
+    static const bool pixs = !(frt_tuning_env("FRT_DWPW_PIXS") && frt_tuning_env("FRT_DWPW_PIXS")[0] == '0');
+    if (pixs && !a.add && a.Cout == 32 && a.Cin == 32 && blocks <= 512 && (long)a.B * a.Cin * a.H * a.W * 4 < (1L << 31)) {
+        if (blocks <= 256) hipLaunchKernelGGL((dwpw_pixs_kernel<16, 4>), dim3((unsigned)blocks, 2), dim3(256), (size_t)a.Cin * 28 * sizeof(float), s, a);
+        else hipLaunchKernelGGL((dwpw_pixs_kernel<32, 2>), dim3((unsigned)blocks, 1), dim3(256), (size_t)a.Cin * 44 * sizeof(float), s, a);
+        return;
+    }
     if (row4 && a.stride == 1 && !a.add && a.H == a.Ho && a.W == a.Wo && a.W % 4 == 0 && (a.Cout == 16 || a.Cout == 32) && a.Cin <= 64) {
         const long threads = (long)a.B * a.H * (a.W / 4);
         const dim3 grid((unsigned)((threads + 255) / 256));
@@ -589,15 +681,9 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
         // (ring depth measured on the 8 -> 16 block: 98 / 97 / 99 us with 1 / 2 / 3 channels in flight - the kernel waits on memory 60 % of
         //  its wave cycles but not for lack of bytes in flight; default = the shallow ring, 176 registers)
         static const int ns16 = frt_tuning_env("FRT_ROW4_NS") ? atoi(frt_tuning_env("FRT_ROW4_NS")) : 2;
-        static const bool split32 = !(frt_tuning_env("FRT_ROW4_SPLIT32") && frt_tuning_env("FRT_ROW4_SPLIT32")[0] == '0');
         if (a.Cout == 16 && ns16 == 4) hipLaunchKernelGGL((dwpw_row4_kernel<16, 4>), grid, dim3(256), lds, s, a);
         else if (a.Cout == 16 && ns16 == 3) hipLaunchKernelGGL((dwpw_row4_kernel<16, 3>), grid, dim3(256), lds, s, a);
         else if (a.Cout == 16) hipLaunchKernelGGL((dwpw_row4_kernel<16, 2>), grid, dim3(256), lds, s, a);
-        // 32 -> 32 at a frame or two (25 workgroups per frame, one wave per SIMD, 29 us whatever the ring depth): the output channels split over
-        // grid.y, depthwise part recomputed per tile - 20.9 us at 1 frame with four 8-channel tiles, 24.9 against 29.8 at 4 frames with two 16-channel
-        // tiles; from 8 frames the full tile wins (31 us).  Same chain per output: bit-identical.
-        else if (a.Cout == 32 && split32 && grid.x <= 64) hipLaunchKernelGGL((dwpw_row4_kernel<8, 2>), dim3(grid.x, 4), dim3(256), (size_t)a.Cin * 20 * sizeof(float), s, a);
-        else if (a.Cout == 32 && split32 && grid.x <= 128) hipLaunchKernelGGL((dwpw_row4_kernel<16, 4>), dim3(grid.x, 2), dim3(256), (size_t)a.Cin * 28 * sizeof(float), s, a);
         else hipLaunchKernelGGL((dwpw_row4_kernel<32, 2>), grid, dim3(256), lds, s, a);
         return;
     }

@@ -69,7 +69,12 @@ __device__ __forceinline__ int xcd_logical_tile(int nblocks) {
 // SPLIT: the pointwise product runs on the fp16 matrix cores at fp32 accuracy (x = hi + lo, three v_mfma_f32_32x32x16_f16 per 16
 // channels = 96 matrix-pipe clocks against 512 for v_mfma_f32_32x32x2f32; same idea and error analysis as kernels_det_conv3h.hip):
 // the depthwise stage stores its output split into LDS rows [pixel][KC hi | KC lo | pad], weights come pre-split from the host.
-template <int NPW, int NCW, int KC, int CBW, int STRIDE, bool MODE2D, bool SPLIT = false>
+//
+// PRE > 0 (SPLIT only; a frame or two per call, where a workgroup is alone on its CU and its lifetime is the chain "loads of chunk c + 1 ->
+// depthwise -> LDS -> barrier" once per chunk): the taps AND the depthwise weights of PRE chunks are in flight ahead of the chunk whose
+// depthwise part is being computed - unconditional loads from clamped addresses, the zero padding applied by selects when the chunk is
+// consumed.  Same values, same operations in the same order: bit-identical to PRE = 0.
+template <int NPW, int NCW, int KC, int CBW, int STRIDE, bool MODE2D, bool SPLIT = false, int PRE = 0>
 __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, int tiles_x, int tiles_y) {
     constexpr int T = 64 * NPW * NCW;       // threads
     constexpr int TP = 32 * NPW;            // pixels per workgroup tile
@@ -169,6 +174,72 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
         }
     };
 
+    // PRE > 0: the same chunk in two halves - loads now, arithmetic PRE chunks later
+    struct Taps {
+        floatx4 m0[3], m1[STRIDE == 2 ? 3 : 1], w0, w1, w2;
+        float lft[3], rgt[STRIDE == 1 ? 3 : 1];
+    };
+    const int loff = left_ok ? 1 : 0, roffr = right_ok ? 4 : 3;
+    auto dw_load = [&](int c0, Taps (&tp)[ITEMS]) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int ch = c0 + it * CH_PASS + chl;
+            const float *x = inb + (long)ch * HW;
+            tp[it].w0 = *reinterpret_cast<const floatx4 *>(wsm + ch * 12);
+            tp[it].w1 = *reinterpret_cast<const floatx4 *>(wsm + ch * 12 + 4);
+            tp[it].w2 = *reinterpret_cast<const floatx4 *>(wsm + ch * 12 + 8);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                tp[it].m0[k] = *reinterpret_cast<const floatx4 *>(x + roff[k]);
+                tp[it].lft[k] = x[rok[k] ? roff[k] - loff : 0];
+                if (STRIDE == 1) tp[it].rgt[k] = x[roff[k] + roffr];
+                else tp[it].m1[k] = *reinterpret_cast<const floatx4 *>(x + roff[k] + 4);
+            }
+        }
+    };
+    auto dw_compute = [&](int c0, const Taps (&tp)[ITEMS], float *dst) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int cl = it * CH_PASS + chl;
+            const floatx4 w0 = tp[it].w0, w1 = tp[it].w1, w2 = tp[it].w2;
+            const float wt[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0]};
+            const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            floatx4 o = {w2[1], w2[1], w2[1], w2[1]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (STRIDE == 1) {
+                    float v[6];
+                    const floatx4 m = rok[k] ? tp[it].m0[k] : zero4;
+                    v[0] = (rok[k] && left_ok) ? tp[it].lft[k] : 0.f;
+                    v[5] = (rok[k] && right_ok) ? tp[it].rgt[k] : 0.f;
+                    v[1] = m[0]; v[2] = m[1]; v[3] = m[2]; v[4] = m[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = fmaf(v[j + 2], wt[3 * k + 2], fmaf(v[j + 1], wt[3 * k + 1], fmaf(v[j], wt[3 * k], o[j])));
+                } else {
+                    float v[9];
+                    const floatx4 m0 = rok[k] ? tp[it].m0[k] : zero4;
+                    const floatx4 m1 = rok[k] ? tp[it].m1[k] : zero4;
+                    v[0] = (rok[k] && left_ok) ? tp[it].lft[k] : 0.f;
+                    v[1] = m0[0]; v[2] = m0[1]; v[3] = m0[2]; v[4] = m0[3];
+                    v[5] = m1[0]; v[6] = m1[1]; v[7] = m1[2]; v[8] = m1[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = fmaf(v[2 * j + 2], wt[3 * k + 2], fmaf(v[2 * j + 1], wt[3 * k + 1], fmaf(v[2 * j], wt[3 * k], o[j])));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+            half_t *hd = reinterpret_cast<half_t *>(dst);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const half_t xh = (half_t)o[j];
+                hd[(seg * 4 + j) * ROWH + cl] = xh;
+                hd[(seg * 4 + j) * ROWH + KC + cl] = (half_t)(o[j] - (float)xh);
+            }
+        }
+    };
+
     // ---- MFMA role: 32 pixels (wp) x CBW blocks of 32 output channels (wc)
     floatx16 acc[CBW];
 #pragma unroll
@@ -196,6 +267,50 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
                 }
         };
         auto hb = [&](int c) { return reinterpret_cast<float *>(hbuf + (c & 1) * TP * ROWH); };
+        if constexpr (PRE > 0) {
+            static_assert(PRE % 2 == 0, "the LDS double buffer's slot must be a compile-time value");
+            Taps ring[PRE][ITEMS];
+#pragma unroll
+            for (int k = 0; k < PRE; ++k)
+                if (k < nchunk) dw_load(k * KC, ring[k]);
+            load_weights_h(0, ah, al);
+            dw_compute(0, ring[0], hb(0));
+            if (PRE < nchunk) dw_load(PRE * KC, ring[0]);
+            __syncthreads();
+            for (int c0 = 0; c0 < nchunk; c0 += PRE) {  // (nchunk % PRE == 0: the launcher's condition)
+#pragma unroll
+                for (int d = 0; d < PRE; ++d) {
+                    const int c = c0 + d;
+                    const half_t *cur = hbuf + (d & 1) * TP * ROWH + (wp * 32 + r) * ROWH + 8 * hi;
+                    if (c + 1 < nchunk) {
+                        load_weights_h((c + 1) * KC, ahn, aln);
+                        dw_compute((c + 1) * KC, ring[(d + 1) % PRE], hb(d + 1));
+                        if (c + 1 + PRE < nchunk) dw_load((c + 1 + PRE) * KC, ring[(d + 1) % PRE]);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) {
+                        const half8 bh = *reinterpret_cast<const half8 *>(cur + kk * 16);
+                        const half8 bl = *reinterpret_cast<const half8 *>(cur + KC + kk * 16);
+#pragma unroll
+                        for (int cb = 0; cb < CBW; ++cb) {
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][cb], bh, acc[cb], 0, 0, 0);
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][cb], bl, acc[cb], 0, 0, 0);
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk][cb], bh, acc[cb], 0, 0, 0);
+                        }
+                    }
+                    if (c + 1 < nchunk) {
+#pragma unroll
+                        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                            for (int cb = 0; cb < CBW; ++cb) {
+                                ah[kk][cb] = ahn[kk][cb];
+                                al[kk][cb] = aln[kk][cb];
+                            }
+                    }
+                    __syncthreads();
+                }
+            }
+        } else {
         load_weights_h(0, ah, al);
         depthwise_chunk(0, hb(0));
         __syncthreads();
@@ -226,6 +341,7 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
                     }
             }
             __syncthreads();
+        }
         }
     } else {
     float areg[KS][CBW], anext[KS][CBW];
@@ -473,6 +589,27 @@ void launch_fused(const DwPwArgs &a, hipStream_t s) {
     if constexpr (KC == 32) {  // (the 16-channel block with 128-pixel tiles measured slower split: 113 vs 108 us, scattered 2-byte LDS stores)
         if (split && a.wph) {  // pointwise product on the fp16 matrix cores (hi/lo split, fp32-class accuracy)
             const size_t ldsh = (size_t)2 * TP * (2 * KC + 8) * sizeof(half_t);
+            // a frame or two (every workgroup alone on its CU): PRE chunks' loads in flight.  Measured per launch at one frame: see DESIGN 3.9
+            static const int pre = frt_tuning_env("FRT_DWPW_PRE") ? atoi(frt_tuning_env("FRT_DWPW_PRE")) : 1;
+            if constexpr (!MODE2D && NPW <= 2) {
+                const int nchunk = a.Cin / KC;
+                if (pre && nblocks * cgroups <= (pre == 2 ? 100000 : 256) && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0) {
+                    if (nchunk % 4 == 0) {
+                        if (a.stride == 1)
+                            hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 1, MODE2D, true, 4>), grid, dim3(64 * NPW * NCW), ldsh, s, a, tiles_x, tiles_y);
+                        else
+                            hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 2, MODE2D, true, 4>), grid, dim3(64 * NPW * NCW), ldsh, s, a, tiles_x, tiles_y);
+                        return;
+                    }
+                    if (nchunk % 2 == 0) {
+                        if (a.stride == 1)
+                            hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 1, MODE2D, true, 2>), grid, dim3(64 * NPW * NCW), ldsh, s, a, tiles_x, tiles_y);
+                        else
+                            hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 2, MODE2D, true, 2>), grid, dim3(64 * NPW * NCW), ldsh, s, a, tiles_x, tiles_y);
+                        return;
+                    }
+                }
+            }
             if (a.stride == 1)
                 hipLaunchKernelGGL((dwpw_mfma_kernel<NPW, NCW, KC, CBW, 1, MODE2D, true>), grid, dim3(64 * NPW * NCW), ldsh, s, a, tiles_x, tiles_y);
             else
