@@ -87,7 +87,7 @@ done
 # 5. round 4: the detector alone (kernel trace of tools/prof_det.py at 32 and 4 frames), dwpw_wave_kernel against dwpw_mfma_kernel bit for bit
 #    (tuning build), and the stand-alone harness of the wave kernel on its three shapes
 cd /tmp
-for B in 32 4; do
+for B in 32 4 1; do
   rm -rf /tmp/prof_det && mkdir -p /tmp/prof_det
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_det -o st -- python "$ROOT/tools/prof_det.py" $B 5 > /dev/null 2>&1
   cp "$(find /tmp/prof_det -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_det_kernel_stats_b$B.csv" 2>/dev/null
