@@ -300,7 +300,7 @@ def main():
     # streams onto GPU_MAX_HW_QUEUES (default 4) in-order hardware queues per priority class.  Alone, the pipeline is 1.2 % faster on the
     # default (39.05 k against 38.5 - 38.7 k faces/s with 6 / 8 / 12 queues, one box); with RCCL in the process and the per-step record
     # gather running on its own stream (N > 1) four queues put that stream's copies and collective in front of pipeline work: 35.25 k
-    # against 38.4 - 38.6 k with 6 / 8 / 12 (same box, alternating runs, profiles/r03l_hw_queues.txt).  So: 8 whenever a communicator exists.
+    # against 38.4 - 38.6 k with 6 / 8 / 12 (same box, alternating runs, profiles/r03/r03l_hw_queues.txt).  So: 8 whenever a communicator exists.
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("FRT_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

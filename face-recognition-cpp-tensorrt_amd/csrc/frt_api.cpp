@@ -65,7 +65,7 @@ struct Arena {
 //      GPU latency, which the 50 ms busy-poll of round 3 did;
 //   3. then hipEventSynchronize / hipStreamSynchronize (interrupt wait) - an idle pipeline costs nothing.
 // Why not (3) at once: in the 20-step benchmark region (one wait every 3 ms) the interrupt wake-up was observed 20 - 30 ms late about once in
-// four processes - the GPU finished all three batches in flight while the host slept (profiles/r03v_step_times.txt; polling: 12 of 12
+// four processes - the GPU finished all three batches in flight while the host slept (profiles/r03/r03v_step_times.txt; polling: 12 of 12
 // processes within 1 %, r03w_step_times.txt).  A throughput driver that owns its core may raise the spin (bench.py sets 50 000 and says so).
 static std::atomic<long> g_wait_spin_us{-1};
 static long wait_spin_us() {
@@ -2807,7 +2807,7 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
     // A synchronous call that finds nothing else in flight (the reference's request / reply shape: one frame, one caller) has nothing to
     // overlap with: upload, detector, recogniser, match and download go down ONE stream - no stream-to-stream event hand-overs on its
-    // critical path (5 of them otherwise; one 4-face call 1.02 -> 0.94 ms, profiles/r03u_sync_overlap.txt).  Calls that arrive while
+    // critical path (5 of them otherwise; one 4-face call 1.02 -> 0.94 ms, profiles/r03/r03u_sync_overlap.txt).  Calls that arrive while
     // another is in flight take the stage streams as before (and are ordered behind this one through ev_serial).
     bool lone = synchronous && p->overlap;
     for (int i = 0; lone && i < frt_pipeline::NBUF; ++i)

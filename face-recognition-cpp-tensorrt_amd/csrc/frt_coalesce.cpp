@@ -2,7 +2,7 @@
 //
 // The reference serves one frame per request (src/app.cpp:293-352: findFace -> forward -> featureMatching -> getOutputs) from a Crow
 // server started with .multithreaded() (src/app.cpp:367).  Through the drop-in shells that call sequence costs 1.35 ms per frame and
-// reaches 5.9 k faces/s with 8 request threads (profiles/r03zf_dropin_bench.json) where frt_pipeline_submit / wait sustains 39 k: one
+// reaches 5.9 k faces/s with 8 request threads (profiles/r03/r03zf_dropin_bench.json) where frt_pipeline_submit / wait sustains 39 k: one
 // frame is 4 faces, and a 4-face pass leaves the chip idle.  This object gathers the frames of requests that are in the building at
 // the same time into ONE frt_pipeline_submit:
 //   * a caller copies its frame into the next slot of the open batch's pinned staging buffer (the callers' memcpys run in parallel)

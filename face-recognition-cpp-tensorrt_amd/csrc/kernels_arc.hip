@@ -956,7 +956,7 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
     single = a.Cin == 64;
     const int co_tiles = pair ? 1 : a.Cout / 128;
     static const bool small_ok = !(frt_tuning_env("FRT_CONV_SMALL_BATCH") && frt_tuning_env("FRT_CONV_SMALL_BATCH")[0] == '0');
-    constexpr int kWant = 224;  // workgroups that count as "fills the 256 CUs" (128 / 64 measured at 16 / 32 / 64 faces: 0.89 / 1.20 / 1.68 ms per pass become 0.89 / 1.28 / 1.87 and 1.10 / 1.56 / 1.88, profiles/r03r_kwant.txt)
+    constexpr int kWant = 224;  // workgroups that count as "fills the 256 CUs" (128 / 64 measured at 16 / 32 / 64 faces: 0.89 / 1.20 / 1.68 ms per pass become 0.89 / 1.28 / 1.87 and 1.10 / 1.56 / 1.88, profiles/r03/r03r_kwant.txt)
     auto tiles_for = [](int px) { return px <= 32 ? 1 : (px <= 64 ? 2 : (px <= 128 ? 4 : (px <= 224 ? 7 : 0))); };
     auto slots_of = [&](int r, int ni) { return (ni * (r + 2) * (a.W + 2) * 9 + 255) / 256; };
     auto fits = [&](int r, int ni, int t) {  // LDS budget of the instantiation that serves t tiles (see launch_conv_mfma)
@@ -995,7 +995,7 @@ bool patch_geometry(const ConvMfmaArgs &a, int &R, int &n_img, int &pps, bool &s
                 // of a medium batch, in the padded enumeration, with at most 1/7 of the rows wasted - 14x14 in strips of 4 rows puts 24 - 48
                 // faces at ONE round of two-tile workgroups where two-row strips take two rounds of one-tile workgroups, each of which
                 // streams the same 590 KB of weights (pass of 28 / 32 / 40 / 48 / 55 faces: 1.15 / 1.22 / 1.54 / 1.60 / 1.84 -> 1.08 / 1.12 / 1.42 / 1.49 /
-                // 1.57 ms, profiles/r03z_ragged.txt)
+                // 1.57 ms, profiles/r03/r03z_ragged.txt)
                 if (!ragged_ok || !small_ok || (n_str * d - a.H) * 7 > a.H || tiles_for(d * (a.W + 2)) != 2 || d * (a.W + 2) > 64) continue;
                 if (a.B * n_str * co_tiles < kWant) continue;  // (never the last resort: the divisor strips cover that)
             }
@@ -1162,7 +1162,7 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
                 return launch_patch_t<10, 1, 5, false, 0, false, 7, 1, 3, true>(a, R, n_img, s);
             // (Round 3, built, measured and parked in tools/experiments/conv_patch2_two_cout_blocks_per_wave.hip: a wave owning TWO cout
             //  blocks x half the pixel tiles, so that a B fragment read from LDS feeds two MFMAs - half the LDS bytes per MFMA at 256
-            //  registers, parity tests green.  40.9 -> 43.2 us per launch, pipelined step 3.274 -> 3.348 ms (profiles/r03g_patch2_*):
+            //  registers, parity tests green.  40.9 -> 43.2 us per launch, pipelined step 3.274 -> 3.348 ms (profiles/r03/r03g_patch2_*):
             //  the 4 + 3 split of 7 tiles puts 8 MFMA slots per kk step on the critical SIMDs, and the K loop was never LDS-bound - it
             //  runs at 0.94 of the rate the part sustains for its instruction mix.)
             return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
@@ -1176,7 +1176,7 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             return launch_patch_t<10, 1, 5, false, 0, false, 4, 1>(a, R, n_img, s);
         // (Round 3, measured and not kept: a 9-deep weight ring for these short-strip variants - 1 or 2 accumulator tiles leave the
         //  registers for it.  4 / 16 / 32 faces: 12.4 -> 12.0, 14.0 -> 13.5, 18.7 -> 18.9 us per launch, batch-1 call 1.286 -> 1.280 ms
-        //  (profiles/r03f_small_batch_wr.txt): a small-batch launch is prologue + four chunk hand-overs + epilogue + dispatch, not
+        //  (profiles/r03/r03f_small_batch_wr.txt): a small-batch launch is prologue + four chunk hand-overs + epilogue + dispatch, not
         //  weight latency.)
         case CV_P_NT2:
 #ifdef FRT_ABLATE

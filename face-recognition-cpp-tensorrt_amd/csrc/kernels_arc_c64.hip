@@ -244,7 +244,7 @@ __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strip
 
 // Round 3, measured and removed: a variant in which a wave owns BOTH 32-cout blocks (288 weight registers) and half of the strip's
 // pixel tiles, so that every B fragment read from LDS feeds two MFMAs (half the LDS traffic per MFMA, the bound named above).  Correct,
-// no spills in the PReLU / BN forms - and slower (profiles/r03b_embed_ab.txt, one box, rocprofv3 averages at 128 faces): the three PReLU
+// no spills in the PReLU / BN forms - and slower (profiles/r03/r03b_embed_ab.txt, one box, rocprofv3 averages at 128 faces): the three PReLU
 // layers 92.2 -> 108.3 us per launch (the 56x56 ones 48.8 -> 57.8), the shortcut-add form 57.4 -> 79.6 us.  At 464 - 512 registers per
 // lane the A operands of half the MFMAs come out of the accumulator file, and the kernel can no longer share a SIMD with another
 // wave.  The kernel above stays.

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void conv_small_kernel(ConvMfmaArgs p, con
 }
 
 // How much work may go this way: workgroups x (chunk, tap) pairs of a launch; beyond it the strip kernels' weight reuse wins.  Measured per
-// layer at 1 / 4 / 8 / 16 / 32 faces (profiles/r03p_small_layers.txt, r03p_small_ab*.txt): stride-1 layers break even at ~ 14 000 (14x14x256
+// layer at 1 / 4 / 8 / 16 / 32 faces (profiles/r03/r03p_small_layers.txt, r03p_small_ab*.txt): stride-1 layers break even at ~ 14 000 (14x14x256
 // for 8 faces: 392 x 36; 28x28x128 and 56x56x64 for 4 faces are level from 7 000 on); the stride-2 layers - 33 - 44 us in the strip
 // kernel however small the batch - win at 30 000 (16 faces: 25 - 27 us) and lose at 60 000 (32 faces, 14 -> 7: 47 against 43).
 long small_work_limit(int stride) {
@@ -264,13 +264,13 @@ bool launch_conv_small(const ConvMfmaArgs &a, hipStream_t s) {
     // of round trips, and a second pixel tile doubles the gathers.  Also not
     // kept: the pixel operand fetched as whole 128-byte chunks of 8 pixels per load (8 cache lines per instruction instead of the gather's
     // 32) and transposed into MFMA fragments through a wave-private LDS tile, with 1 / 2 / 4 tiles per workgroup: bit-identical results,
-    // 430 / 659 us (1 face), 504 / 716 us (4 faces), 16 - 32 faces 1.3 - 3.1 ms per pass (profiles/r03x_small_lds.txt).)
+    // 430 / 659 us (1 face), 504 / 716 us (4 faces), 16 - 32 faces 1.3 - 3.1 ms per pass (profiles/r03/r03x_small_lds.txt).)
     static const int nc_env = frt_tuning_env("FRT_CONV_SMALL_NC") ? atoi(frt_tuning_env("FRT_CONV_SMALL_NC")) : 0;
     const int wgs = (M + 31) / 32 * (a.Cout / 32);
     int nc = wgs > 256 && a.Cout % 64 == 0 ? 2 : 1;  // more one-block units than CUs: two cout blocks per workgroup share the pixel fragments
     if (nc_env == 1 || (nc_env == 2 && a.Cout % 64 == 0)) nc = nc_env;
     // (four cout blocks per workgroup, ring of 2: 8 / 12 / 16 / 32 faces 0.86 / 1.00 / 1.04 / 1.61 ms per pass against 0.73 / 0.86 / 0.91 / 1.19 -
-    //  from ~ 10 faces on the strip kernels win, profiles/r03z_small_nc4.txt)
+    //  from ~ 10 faces on the strip kernels win, profiles/r03/r03z_small_nc4.txt)
     if (nc == 2) {
         if (scf) launch_small_t<true, 4, 2, 3>(a, wfrag, taps, M, s);
         else launch_small_t<false, 4, 2, 3>(a, wfrag, taps, M, s);

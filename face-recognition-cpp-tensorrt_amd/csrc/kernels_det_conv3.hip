@@ -292,7 +292,7 @@ bool launch_conv3x3_mfma(const Conv3Args *a, int n, hipStream_t s) {
     const int cin = a[0].Cin, cout = a[0].Cout;
     const int kc = cin == 16 ? 16 : 32;
     // 16 -> 16 convs: 8 MFMAs per step cannot hide a step's fixed costs (measured 51 us against 31 us for the scalar kernel)
-    // (With the few tiles of ONE frame it is the other way round - 10 us against 23, profiles/r03q_det_b1_switches.txt - but switching by
+    // (With the few tiles of ONE frame it is the other way round - 10 us against 23, profiles/r03/r03q_det_b1_switches.txt - but switching by
     //  batch size would give a frame other last bits in its scores alone than in a batch: tests/test_gpu_detector.py holds the detector to
     //  bit-identical outputs whatever the batch.)
     if (cin == 16 && !frt_tuning_env("FRT_C3_FORCE16")) return false;

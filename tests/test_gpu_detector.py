@@ -115,7 +115,7 @@ def test_batch_of_32_equals_frame_by_frame(frt, synth, blobs):
 @pytest.mark.parametrize("geo,frames,max_differing", [("640x640->640x640", 256, 0), ("640x480->320x288", 256, 1)])
 def test_box_census(frt, blobs, geo, frames, max_differing):
     """The box-flip census (tools/box_census.py) as a test: findFace on the GPU against the fp32 oracle +
-    oracle/postproc.c on 256 synthetic frames per geometry, 1 024 boxes / 4 096 coordinates each.  Expected (profiles/r02_box_census.json,
+    oracle/postproc.c on 256 synthetic frames per geometry, 1 024 boxes / 4 096 coordinates each.  Expected (profiles/r02/r02_box_census.json,
     512 frames): no differing coordinate at 640x640, ONE at 320x288 (an `int` truncation of a float that differs in its last bits,
     src/retinaface.cpp:171-187) - never a different box count, never more than one detector-input pixel."""
     import importlib.util

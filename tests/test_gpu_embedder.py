@@ -177,7 +177,7 @@ def test_dynamic_range_of_the_fp16_activation_storage(frt, synth, tmp_path, whic
     """Round-2 VERDICT robustness item 7a.  All other parity evidence sits on weights that keep activations O(1).  tools/dynamic_range_sweep.py
     rescales the network WITHOUT changing the function it computes so that the residual stream (tensors Y / Z / SC, fp16) or the
     conv1 -> conv2 activation (tensor T, fp16, plus the fp16 weights around it) sits 10^-3 ... 10^3 away from that; measured
-    (profiles/r03a_dynamic_range.json): 1 - cos stays at 3e-6 ... 1.5e-5 over that whole range for IR-50 and IR-SE-50, degrades silently
+    (profiles/r03/r03a_dynamic_range.json): 1 - cos stays at 3e-6 ... 1.5e-5 over that whole range for IR-50 and IR-SE-50, degrades silently
     below (branch scale 1e-4: 4.8e-4) and turns non-finite - visibly - at 1e4.  The tolerance is north_star's 1e-4."""
     import importlib.util
 

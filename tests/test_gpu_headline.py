@@ -28,7 +28,7 @@ def check_faces(res, emb, f, K, oboxes, oemb, slots):
         r, ob = res[f * K + j], oboxes[j]
         assert r["valid"] and r["frame"] == f
         d = [abs(int(r[c]) - int(ob[c])) for c in ("x1", "y1", "x2", "y2")]
-        assert max(d) <= 1, (f, j, r, ob)  # census-backed bound, see DESIGN.md section 4 / profiles/r02_box_census.json
+        assert max(d) <= 1, (f, j, r, ob)  # census-backed bound, see DESIGN.md section 4 / profiles/r02/r02_box_census.json
         same_box = max(d) == 0
         exact += same_box
         cos = float((emb[f * K + j] * oemb[j]).sum())

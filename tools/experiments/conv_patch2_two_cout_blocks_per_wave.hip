@@ -1,9 +1,9 @@
 // PARKED EXPERIMENT (round 3) - not part of libfrt.so.  Built, parity-green (tests/test_gpu_embedder.py, tests/test_gpu_headline.py with this
 // kernel serving the 34 dominant launches), measured slower than conv_patch_kernel: 40.9 -> 43.2 us per launch, pipelined step 3.274 -> 3.348 ms
-// (profiles/r03g_patch2_embed_ab.txt, profiles/r03g_patch2_bench_ab.txt).  Kept as source for the record; to rebuild it, add it to
+// (profiles/r03/r03g_patch2_embed_ab.txt, profiles/r03/r03g_patch2_bench_ab.txt).  Kept as source for the record; to rebuild it, add it to
 // csrc/Makefile's NAMES, declare conv_patch2_applies / launch_conv_patch2 in frt_kernels.h and call them from launch_conv_mfma's CV_P_255 case.
 // A balanced second form (tiles 0-2 / 4-6 x both cout blocks + the middle tile shared, one block per pixel half: 7 MFMA slots per kk step on
-// every wave, 4 B-fragment reads instead of 7) measured 40.8 -> 42.2 us per launch, step 3.185 -> 3.241 ms (profiles/r03n_patch2_balanced_ab.txt)
+// every wave, 4 B-fragment reads instead of 7) measured 40.8 -> 42.2 us per launch, step 3.185 -> 3.241 ms (profiles/r03/r03n_patch2_balanced_ab.txt)
 // and was dropped with one parity test still failing: DESIGN 3.15.
 //
 // ArcFace IR-50: the dominant 3x3 stride-1 convolutions (Cout % 128 == 0, strips of up to 224 pixel slots: 26 x 256 -> 256 at 14x14,

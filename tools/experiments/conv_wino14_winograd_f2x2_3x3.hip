@@ -1,6 +1,6 @@
 // PARKED EXPERIMENT (round 3) - not part of libfrt.so.  Winograd F(2x2, 3x3) for the 26 256 -> 256 convolutions at 14x14, built, parity-correct on
 // the first run (128- and 64-face passes against the fp32 oracle: 1 - cos 5.2e-6 where the direct kernels give 2.9e-6, IR-SE 2.0e-6 / 1.7e-6),
-// and SLOWER than the direct strip kernel: 68.7 us per launch against 41.6 (profiles/r03z_wino_first.txt, r03z_wino_ablations.txt).  Where the
+// and SLOWER than the direct strip kernel: 68.7 us per launch against 41.6 (profiles/r03/r03z_wino_first.txt, r03z_wino_ablations.txt).  Where the
 // time goes (ablations, us per launch): everything 68.7; without the input transform 62.4; without the output fold 61.0; without the MFMAs and
 // their fragment reads 52.0; without the weight loads 65.8; with transform, fold and MFMAs all off 35.7 - the skeleton alone (1 MB of
 // transformed weights per workgroup through one CU's memory path ~ 13 us, two patch loads, 32 barriers, an epilogue of scattered 8-byte
