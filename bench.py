@@ -6,7 +6,13 @@
 
 One "step" = one pass of the whole hot path over one batch of 32 synthetic 640x640 frames: letterbox/normalise ->
 RetinaFace-mnet0.25 -> decode + NMS (K = 4 faces per frame) -> bicubic crop -> ArcFace IR-50 (fp16 MFMA convs, fp32 accumulate) ->
-cosine top-1 against a 1M x 512 fp32 gallery (fp32 MFMA).  Nothing is cached between steps and no stage is skipped.
+cosine top-1 against a 1M x 512 fp32 gallery.  Nothing is cached between steps and no stage is skipped.
+
+THE MATCH STAGE IS NOT SURVEY 8(d)'s 2.048 GB fp32 scan: it is an int8-SCREENED coarse scan (0.51 GB shadow gallery, fp16 MFMA products of
+exactly widened int8 rows) + an EXACT fp32 re-rank of every 32-row block the rigorous error bound cannot exclude.  Its results
+are bit-identical to the exact scan's (tests/test_gpu_match.py), its cost depends on the queries: the default workload's queries match
+nothing in the gallery ("miss": ~ 11 candidate blocks per query); `match_legs` in the line carries the same step with the queries planted
+in the gallery ("hit") and with the screening switched off ("worst_case" = the exact fp32 scan of 8(d), frt_matcher_set_screening(m, 0)).
 
 TIMED REGION: u8 frames in PINNED HOST memory -> per-face (box, top-1 index, similarity) records back in host memory,
 through frt_pipeline_submit / frt_pipeline_wait with three batches in flight (H2D of 39 MB per step on the copy stream, D2H of the
@@ -24,7 +30,8 @@ barrier / max-over-ranks bookkeeping.
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      dominant kernel family = the ArcFace 3x3 implicit-GEMM convs; achieved = algorithmic FLOPs of those launches /
                 their HIP-event time, measured live on the stream they run on during one step of the timed region; peak = 2.5 PFLOP/s
-                dense fp16 MFMA (MI355X_MICROARCH.md).
+                dense fp16 MFMA (MI355X_MICROARCH.md); sustained_peak = what THIS device sustains on the kernel's instruction mix under its
+                power limit, measured in this process right after the timed region (frt_probe_sustained_mfma).
   cpu_baseline  the oracle (reference-faithful CPU restatement, oracle/) timed on this box's host cores over bounded samples of
                 the same workload, rank 0 at N = 1 only: the full CPU pipeline and the reference's HOST-side work alone
                 (pre/post-processing + O(F*N) argmax), each with all cores and with one thread.
@@ -271,6 +278,8 @@ def main():
                                                                  "keeps this many of its small batches in the stage pipeline at once")
     ap.add_argument("--sharded-gallery", action="store_true",
                     help="BASELINE configs[4]: gallery row-sharded over the ranks and stored as fp16; RCCL all-gather of embeddings and of the top-1 winners")
+    ap.add_argument("--exact-match", action="store_true", help="match stage = the exact fp32 scan of the whole gallery on every call "
+                                                               "(frt_matcher_set_screening(m, 0): SURVEY 8(d)'s 2.048 GB per call) instead of the screened top-1")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step RCCL all-gather of the result records")
     ap.add_argument("--topk", type=int, default=5, help="--sharded-gallery: length of the per-query lists every rank answers with (1..16)")
     ap.add_argument("--dump-final", default=None, help="--sharded-gallery: write the last step's gathered fp16 queries and merged top-k lists (npz) "
@@ -354,6 +363,10 @@ def main():
         rec.setGallery(gallery)  # bulk initKnownEmbeds + addEmbedding x N through the streaming loader (pinned chunks, async copies)
         rec.initMatMul()
     gallery_load_s = time.perf_counter() - t_load
+    if args.exact_match:
+        rec.matmul.setScreening(False)
+    _sb, _rows = rec.matmul.scanBytes(), max(int(frt.lib.frt_matcher_num_rows(rec.matmul._h)), 1)
+    scan_mode = "int8" if _sb == 512 * _rows else ("fp16" if (_sb == 1024 * _rows and not args.sharded_gallery) else "exact")
     pipe = frt.Pipeline(det, rec, B, match=not args.sharded_gallery)  # sharded gallery: the pipeline produces embeddings, match + merge follow below
     # The caller's stream (NOT torch's default stream: that is the legacy NULL stream, and every operation on it - an event record, a
     # collective's stream hand-over - is a barrier against all blocking streams, including the pipeline's stage streams: measured 7.9
@@ -730,10 +743,9 @@ def main():
             rec_flop = wk.get("embed_network", 0.0)
             n_rows = int(frt.lib.frt_matcher_num_rows(rec.matmul._h))
             # bytes per element of the per-call scan: int8 shadow (fp32-stored galleries, round 4), fp16 shadow / fp16-stored shard, or the fp32 rows
-            i8 = (not args.sharded_gallery and n_rows >= 32768 and os.environ.get("FRT_MATCH_I8") != "0" and os.environ.get("FRT_MATCH_FAST") != "0"
-                  and os.environ.get("FRT_MATCH_SCREEN") != "0")
-            scan_bpe = 1 if i8 else (2 if (n_rows >= 32768 or args.sharded_gallery) else 4)
-            scan_b = scan_bpe * 512.0 * n_rows
+            scan_b = float(rec.matmul.scanBytes())   # what ONE top-1 call reads: the int8 / fp16 shadow when screened, the stored rows otherwise
+            scan_bpe = int(round(scan_b / (512.0 * max(n_rows, 1))))
+            i8 = scan_bpe == 1
             mt_ms = st.get("match_top1", 0) + st.get("match_topk", 0)
 
             def frac(x, ms, peak):
@@ -763,6 +775,109 @@ def main():
                            "serial_sum_ms": round(sum(stage_ms.values()), 4), "step_ms": round(step_ms, 4),
                            "note": "max(serial stage time) / pipelined step time: 1.0 = the step costs what its slowest stage costs alone "
                                    "(stage times: HIP events around each stage in 3 extra serial steps on this rank)"}
+
+    # ---- the match stage under other query populations, the sustained matrix-core rate, and the strong-scaling shape (N = 1 side legs)
+    match_legs = None
+    proxy = None
+    if rank == 0 and not use_dist and not args.no_extras and not args.sharded_gallery and not args.resident:
+        def serial_match_ms():
+            frt.profile_enable(2)
+            for i in range(3):
+                pipe.run_dev(d_frames[i & 1].data_ptr(), B, d_res[0].data_ptr(), None)
+            torch.cuda.synchronize()
+            lb, mm, _w = frt.profile_collect()
+            frt.profile_enable(0)
+            return sum(m for l, m in zip(lb, mm) if l in ("match_top1", "match_topk")) / 3.0
+
+        def step_rate(n):
+            run(3)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            run(n)
+            torch.cuda.synchronize()
+            d = time.perf_counter() - ta
+            return round(faces_per_step * n / d, 1), round(1e3 * d / n, 4)
+
+        n_leg = max(args.steps, 50)
+        n_rows = int(frt.lib.frt_matcher_num_rows(rec.matmul._h))
+        match_legs = {"note": "the same pipelined step (%d steps each, untimed by the contract) with other match-stage conditions; match_stage_ms = HIP events around "
+                              "the stage in 3 serial steps; answers are identical in all three modes by construction (tests/test_gpu_match.py)" % n_leg}
+        if scan_mode != "exact":
+            f, m = step_rate(n_leg)
+            match_legs["miss"] = {"faces_per_sec": f, "ms_per_step": m, "match_stage_ms": round(serial_match_ms(), 4), "scan_bytes": rec.matmul.scanBytes(),
+                                  "what": "the default workload: embeddings of synthetic faces against an i.i.d. gallery - no query matches, every query keeps ~ 11 candidate blocks for the exact re-rank"}
+            # worst case: no screening at all = SURVEY 8(d)'s match (4 * 512 * N bytes per call, fp32 MFMA, fused first maximum)
+            rec.matmul.setScreening(False)
+            f, m = step_rate(n_leg)
+            wc_ms = serial_match_ms()
+            wb = rec.matmul.scanBytes()
+            match_legs["worst_case"] = {"faces_per_sec": f, "ms_per_step": m, "match_stage_ms": round(wc_ms, 4), "scan_bytes": wb,
+                                        "achieved_TBps": round(wb / (wc_ms * 1e-3) / 1e12, 3) if wc_ms > 0 else None,
+                                        "frac_hbm": round(wb / (wc_ms * 1e-3) / PEAK_HBM_BPS, 4) if wc_ms > 0 else None,
+                                        "frac_fp32_matrix": round(2.0 * 512 * n_rows * F / (wc_ms * 1e-3) / (PEAK_FP32_MATRIX_TFLOPS * 1e12), 4) if wc_ms > 0 else None,
+                                        "what": "frt_matcher_set_screening(m, 0): the exact fp32 scan of the whole gallery on every call (src/matmul.h:7-16 + the "
+                                                "first maximum of src/arcface.cpp:203-217 fused) - what any query population costs at most"}
+            rec.matmul.setScreening(True)
+            # hit: plant this workload's own embeddings in the gallery (every query then has its row, similarity 1)
+            embs = []
+            for hb in h_np:
+                _r, e = pipe.run(hb, want_embeds=True)
+                embs.append(np.array(e[:F], np.float32))
+            emb = np.concatenate(embs)
+            ok = np.isfinite(emb).all(axis=1) & (np.linalg.norm(emb, axis=1) > 0.5)
+            rows = np.random.default_rng(11).choice(n_rows, size=len(emb), replace=False)
+            g2 = np.array(gallery, np.float32, copy=True)
+            g2[rows[ok]] = emb[ok]
+            rec.setGallery(g2)
+            rec.initMatMul()
+            f, m = step_rate(n_leg)
+            hit_ms = serial_match_ms()
+            res_hit = h_views[(n_leg - 1) % 4]
+            planted = {int(r) for r in rows[ok]}
+            found = int(sum(1 for x in res_hit[res_hit["valid"] != 0]["match_idx"] if int(x) in planted))
+            match_legs["hit"] = {"faces_per_sec": f, "ms_per_step": m, "match_stage_ms": round(hit_ms, 4), "scan_bytes": rec.matmul.scanBytes(),
+                                 "queries_answered_with_a_planted_row": found, "queries": int((res_hit["valid"] != 0).sum()),
+                                 "what": "the gallery with this workload's %d embeddings planted at random rows: every query has its own row (similarity 1), the "
+                                         "screening keeps one candidate block per query" % int(ok.sum())}
+            rec.setGallery(gallery)   # back to the workload's gallery
+            rec.initMatMul()
+            del g2
+        # ---- BASELINE configs[3] as written, per-rank shape at 8 GPUs: ONE 32-frame batch split 8 ways = 4 frames per step on this GPU
+        nb = max(B // 8, 1)
+        for i in range(6):
+            pipe.run_dev(d_frames[i & 1].data_ptr(), nb, d_res[i % NRING].data_ptr(), None)
+        torch.cuda.synchronize()
+        n_px = max(args.steps, 100) * 3
+        tp = time.perf_counter()
+        for i in range(n_px):
+            pipe.run_dev(d_frames[i & 1].data_ptr(), nb, d_res[i % NRING].data_ptr(), None)
+        torch.cuda.synchronize()
+        ms4 = 1e3 * (time.perf_counter() - tp) / n_px
+        ms32 = extras.get("hbm_resident", {}).get("ms_per_step")
+        if "steady_state" in extras and not ms32:
+            ms32 = extras["steady_state"]["ms_per_step"]
+        if not ms32:
+            ms32 = 1e3 * dt / args.steps
+        proxy = {"frames_per_step": nb, "ms_per_%d_frame_step" % nb: round(ms4, 4), "ms_per_%d_frame_step" % B: round(ms32, 4),
+                 "projected_x_at_8": round(ms32 / ms4, 3) if nb * 8 == B else None,
+                 "note": "single-GPU proxy for north_star's strong-scaling sentence (one %d-frame batch split over 8 GPUs, gallery replicated, no data-path "
+                         "collective): a rank's step is %d frames; projected speed-up at 8 GPUs = (ms per %d-frame step on one GPU, HBM-resident) / (ms per "
+                         "%d-frame step, HBM-resident, %d steps back to back with the stages of consecutive calls overlapping)" % (B, nb, B, nb, n_px)}
+    if roofline is not None and rank == 0 and not args.no_extras:
+        # what THIS device sustains on the dominant kernel's K-loop instruction mix (back-to-back fp16 MFMAs on random operands + one ds_read_b128 per MFMA
+        # + the weight-fragment global loads) under its power limit: the denominator the 2.5 PFLOP/s nominal peak is not on this part (DESIGN A.1, A.15)
+        try:
+            sp = {"mfma_only": round(frt.probe_sustained_mfma(local_rank, 0, 0.15), 1), "mfma_lds": round(frt.probe_sustained_mfma(local_rank, 1, 0.15), 1),
+                  "mfma_lds_vmem": round(frt.probe_sustained_mfma(local_rank, 2, 0.3), 1)}
+            roofline["sustained_peak"] = {"value": sp["mfma_lds_vmem"], "unit": "TFLOP/s", "frac_of_nominal": round(sp["mfma_lds_vmem"] / PEAK_FP16_MFMA_TFLOPS, 4),
+                                          "achieved_over_sustained": round(roofline["achieved"] / sp["mfma_lds_vmem"], 4) if sp["mfma_lds_vmem"] > 0 else None,
+                                          "by_mix_TFLOPs": sp,
+                                          "note": "frt_probe_sustained_mfma in this process right after the timed region: one wave per SIMD on every CU, back-to-back "
+                                                  "v_mfma_f32_32x32x16_f16 on random fp16 operands (mfma_only), + one ds_read_b128 per MFMA (mfma_lds), + 4 global "
+                                                  "16-byte loads per 28 MFMAs (mfma_lds_vmem = the dominant kernel's K-loop mix); ~ 0.15 - 0.3 s each; the package "
+                                                  "is power-limited (1.4 kW), so the nominal 2.5 PFLOP/s is not reachable with real operands"}
+        except Exception as e:  # noqa: BLE001  (a measurement aid must never cost the line)
+            roofline["sustained_peak"] = {"value": None, "error": str(e)}
 
     # how many ranks really took part (counted over the process group, not read from the environment)
     n_ranks = 1
@@ -795,7 +910,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
-            "dtype": "f16 MFMA recogniser convs (fp32 accumulate) + fp32-accurate detector (fp32 MFMA, fp16 hi/lo-split MFMA for the 64-channel 3x3 convs) + f32 MFMA match",
+            "dtype": "f16 MFMA recogniser convs (fp32 accumulate) + fp32-accurate detector (fp32 MFMA, fp16 hi/lo-split MFMA for the 64-channel 3x3 convs) + "
+                     + {"exact": "exact f32 MFMA match (full scan of the stored rows)",
+                        "fp16": "fp16-screened coarse scan (fp16 MFMA) + exact f32 re-rank match (bit-identical to the exact f32 scan)",
+                        "int8": "int8-screened coarse scan (fp16 MFMA on exactly widened int8 rows) + exact f32 re-rank match (bit-identical to the exact f32 scan)"}[scan_mode],
             "data": "synthetic",
             "config": {"workload": "%s; %dx%d frames (640x640 detector input) batch=%d frames/GPU, K=%d faces/frame, %dx512 %s gallery, "
                                    "RetinaFace-mnet0.25 + ArcFace %s" % (boundary, FW, FH, B, K, args.gallery,
@@ -810,6 +928,12 @@ def main():
             "cpu_baseline": None,
         }
         out.update(extras)
+        if match_legs:
+            out["match_legs"] = match_legs
+            if "worst_case" in match_legs:
+                out["match_worst_case"] = match_legs["worst_case"]
+        if proxy:
+            out["strong_scaling_proxy"] = proxy
         if overlap_eff:
             out["overlap_efficiency"] = overlap_eff
         if smi and smi.samples:

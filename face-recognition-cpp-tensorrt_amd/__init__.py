@@ -65,7 +65,11 @@ ABI = {
     "frt_matcher_destroy": (None, [_vp]),
     "frt_matcher_init": (_i, [_vp, _vp, _i, _i]),
     "frt_matcher_set_row_offset": (_i, [_vp, _i]),
+    "frt_probe_sustained_mfma": (_i, [_i, _i, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]),
     "frt_matcher_set_storage": (_i, [_vp, _i]),
+    "frt_matcher_set_screening": (_i, [_vp, _i]),
+    "frt_matcher_scan_bytes": (ctypes.c_size_t, [_vp]),
+    "frt_matcher_generation": (ctypes.c_uint, [_vp]),
     "frt_matcher_gallery_begin": (_i, [_vp, _i, _i]),
     "frt_matcher_gallery_append": (_i, [_vp, _vp, _i]),
     "frt_matcher_gallery_commit": (_i, [_vp]),
@@ -164,6 +168,14 @@ def set_wait_spin_us(us):
     return int(lib.frt_set_wait_spin_us(int(us)))
 
 
+def probe_sustained_mfma(device=0, mix=2, seconds=0.25):
+    """TFLOP/s the device sustains on back-to-back fp16 MFMAs with random operands (mix 0), + one LDS read per MFMA (1), + the dominant conv
+    kernel's global loads (2): frt_probe_sustained_mfma."""
+    out = ctypes.c_double(0.0)
+    _check(lib.frt_probe_sustained_mfma(int(device), int(mix), float(seconds), ctypes.byref(out)))
+    return float(out.value)
+
+
 def write_weights(path, state, kind):
     return weights_io.write_blob(path, state, kind)
 
@@ -187,6 +199,14 @@ class MatMul:
     def setStorage(self, fp16):
         """Rows of the NEXT init / galleryBegin are stored as fp16 on the device (BASELINE config 5) when ``fp16`` is true."""
         _check(lib.frt_matcher_set_storage(self._h, 1 if fp16 else 0))
+
+    def setScreening(self, on):
+        """``False``: every top-1 call takes the exact fp32 scan of the whole gallery (same answers, the path's worst case)."""
+        _check(lib.frt_matcher_set_screening(self._h, 1 if on else 0))
+
+    def scanBytes(self):
+        """Gallery bytes one top-1 call reads in the current mode (shadow copy when screened, stored rows otherwise)."""
+        return int(lib.frt_matcher_scan_bytes(self._h))
 
     # streaming load == initKnownEmbeds / addEmbedding x n / initMatMul (src/db.cpp:316-346)
     def galleryBegin(self, rowCapacity, numCol=512):

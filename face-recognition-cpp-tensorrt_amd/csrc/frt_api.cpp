@@ -912,7 +912,7 @@ void frt_embedder::build(const frt::Blob &b) {
         HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_se_error), sizeof(int), hipHostMallocMapped));
         *h_se_error = 0;
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_se_error), h_se_error, 0));
-        const char *sf = getenv("FRT_SE_FUSED");
+        const char *sf = frt_tuning_env("FRT_SE_FUSED");  // (tuning build; the product's switch is frt_embedder_set_se_fused)
         se_fused = !(sf && sf[0] == '0');
     }
     fc_partial = arena.alloc<float>((size_t)FC_SPLITS * F * 512);
@@ -1098,6 +1098,7 @@ struct frt_matcher {
     bool want16 = false;       // storage mode of the NEXT init / gallery_begin (frt_matcher_set_storage)
     float gmax_norm = 0.f;
     bool screen = false;
+    bool screen_on = true;     // frt_matcher_set_screening: false = every top-1 call takes the exact fp32 scan (the shadow gallery stays resident)
     ScreenScratch scr{};
     void free_screen_scratch() {
         for (void *p : {(void *)scr.q16, (void *)scr.tilemax, (void *)scr.tile_flags, (void *)scr.tile_list, (void *)scr.segmax, (void *)scr.wgmax, scr.pairs,
@@ -1244,7 +1245,7 @@ struct frt_matcher {
         if (old32) (void)hipFree(old32);  // (hipFree waits for the device: stages of earlier pipeline calls have finished with it)
         if (old16) (void)hipFree(old16);
         blocks = match_top1_blocks(N, 0);
-        const char *scr_env = getenv("FRT_MATCH_SCREEN");
+        const char *scr_env = frt_tuning_env("FRT_MATCH_SCREEN");  // (tuning build only; the product's switch is frt_matcher_set_screening)
         screen = N >= 32768 && match_screen_supported(D) && !(scr_env && scr_env[0] == '0');
         gmax_norm = 0.f;
         if (N > 0 && (screen || store16)) {  // fp16 shadow copy (fp32 storage) + the largest row norm (rounding bound of the screening pass)
@@ -1252,7 +1253,7 @@ struct frt_matcher {
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_bits), sizeof(int)));
             // fp32-stored galleries of 512 columns are screened through an INT8 shadow (half the bytes of the per-call scan; kernels_match.hip);
             // FRT_MATCH_I8=0 / FRT_MATCH_FAST=0 keep the fp16 shadow (A/B measurements, the round-2 tile-list path)
-            const char *i8_env = getenv("FRT_MATCH_I8"), *fast_env = getenv("FRT_MATCH_FAST");
+            const char *i8_env = frt_tuning_env("FRT_MATCH_I8"), *fast_env = frt_tuning_env("FRT_MATCH_FAST");
             const bool use_i8 = screen && !store16 && D == 512 && !(i8_env && i8_env[0] == '0') && !(fast_env && fast_env[0] == '0');
             int *d_ebits = nullptr;
             if (store16) {
@@ -1311,7 +1312,7 @@ struct frt_matcher {
             scr.count = scr.tile_flags + tiles;                                                           // one contiguous range to clear per call
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.tile_list), tiles * sizeof(int)));
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.segmax), (size_t)cap * 16 * sizeof(float)));
-            const char *fe = getenv("FRT_MATCH_FAST");  // "0": the round-2 tile-list re-rank (diagnostics)
+            const char *fe = frt_tuning_env("FRT_MATCH_FAST");  // "0": the round-2 tile-list re-rank (diagnostics, tuning build)
             if (!(fe && fe[0] == '0')) {
                 scr.pair_cap = std::max(cap * 64, 8192);  // (a multiple of the 16 sub-lists)
                 HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.wgmax), (size_t)256 * cap * sizeof(float)));
@@ -1327,7 +1328,7 @@ struct frt_matcher {
     void top1_dev(const float *queries_dev, int F, int32_t *idx_dev, float *sim_dev, hipStream_t s) {
         ProfScope ps(2, "match_top1", 2.0 * D * (double)N * F, s);
         // the partial scratch is [blocks][F]
-        if (screen) {  // (d_gallery == nullptr with fp16 storage: the exact re-rank then reads the stored fp16 rows)
+        if (screen && screen_on) {  // (d_gallery == nullptr with fp16 storage: the exact re-rank then reads the stored fp16 rows)
             ScreenScratch w = scr;
             w.g8 = d_g8;
             w.g8_scale = d_g8_scale;
@@ -1772,6 +1773,54 @@ int frt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int frt_probe_sustained_mfma(int device, int mix, double seconds, double *tflops_out) {
+    return guarded([&] {
+        if (!tflops_out || mix < 0 || mix > 2 || !(seconds > 0.0) || seconds > 10.0) raise(FRT_ERR_INVALID, "frt_probe_sustained_mfma: bad argument");
+        use_device(device);
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        const int n_wg = prop.multiProcessorCount;
+        std::vector<uint16_t> h(8192 * 8);
+        uint32_t x = 0x2545F491u;
+        for (auto &v : h) {  // random fp16 values in (-1, 1): sign, exponent 8..14, random mantissa (real operand toggling, no inf / nan)
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            v = (uint16_t)(((x >> 3) & 0x8000u) | ((8u + (x >> 20) % 7u) << 10) | (x & 0x3ffu));
+        }
+        void *src = nullptr;
+        float *out = nullptr;
+        hipStream_t st = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIPCHK(hipMalloc(&src, h.size() * 2));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&out), (size_t)n_wg * 256 * sizeof(float)));
+        HIPCHK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        const int iters = 2000;                 // ~ 1.2 - 1.6 ms per launch: long enough for the clock to settle at its power-managed value
+        (void)launch_mfma_probe(mix, n_wg, iters, src, out, st);   // code load + first touch off the clock
+        HIPCHK(hipStreamSynchronize(st));
+        double flop = 0.0, ms_total = 0.0;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
+        do {
+            HIPCHK(hipEventRecord(e0, st));
+            double f = 0.0;
+            for (int i = 0; i < 8; ++i) f += launch_mfma_probe(mix, n_wg, iters, src, out, st);
+            HIPCHK(hipEventRecord(e1, st));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            flop += f;
+            ms_total += ms;
+        } while (std::chrono::steady_clock::now() < t_end);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(st);
+        (void)hipFree(src);
+        (void)hipFree(out);
+        *tflops_out = flop / (ms_total * 1e-3) / 1e12;
+    });
 }
 
 int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int in_c, int in_h, int in_w, int max_batch, int max_faces,
@@ -2260,6 +2309,28 @@ int frt_matcher_set_storage(frt_matcher *m, int fp16) {
         std::lock_guard<std::mutex> lk(m->mu);
         m->want16 = fp16 != 0;
     });
+}
+
+int frt_matcher_set_screening(frt_matcher *m, int on) {
+    return guarded([&] {
+        if (!m) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->screen_on = on != 0;
+    });
+}
+
+unsigned frt_matcher_generation(frt_matcher *m) {
+    if (!m) return 0;
+    std::lock_guard<std::mutex> lk(m->mu);
+    return m->generation;
+}
+
+size_t frt_matcher_scan_bytes(frt_matcher *m) {
+    if (!m) return 0;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const size_t n = (size_t)m->N, d = (size_t)m->D;
+    if (m->screen && m->screen_on) return (m->d_g8 ? 1 : 2) * n * d;   // the coarse scan reads the shadow copy once per call
+    return (m->store16 ? 2 : 4) * n * d;
 }
 
 int frt_matcher_init(frt_matcher *m, const float *gallery, int num_row, int num_col) {

@@ -66,8 +66,10 @@ struct frt_coalescer {
     int inflight = 0;
     std::deque<int> queue;  // submitted batches, in ticket order
     bool stop = false;
+    bool disp_done = false;  // the dispatcher has exited: no further ticket will be queued (the completer may leave once the queue is empty)
+    int active = 0;          // callers inside frt_coalescer_infer_crops (destroy waits for them before it frees anything)
     std::mutex mu;
-    std::condition_variable cv_disp, cv_comp, cv_space;
+    std::condition_variable cv_disp, cv_comp, cv_space, cv_idle;
     std::thread t_disp, t_comp;
     long n_batches = 0, n_frames = 0;
 
@@ -135,8 +137,10 @@ struct frt_coalescer {
     void completer() {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            cv_comp.wait(lk, [&] { return stop || !queue.empty(); });
-            if (queue.empty()) return;  // (stop: batches still queued are completed first, their callers are waiting)
+            // (shutdown: every ticket the dispatcher submitted is waited for - the device work and the D2H copies into the pinned buffers
+            //  must have finished before destroy frees them; the dispatcher is joined first and sets disp_done)
+            cv_comp.wait(lk, [&] { return disp_done || !queue.empty(); });
+            if (queue.empty()) return;
             const int bi = queue.front();
             queue.pop_front();
             Batch &b = batch[bi];
@@ -222,12 +226,19 @@ void frt_coalescer_destroy(frt_coalescer *c) {
         c->stop = true;
     }
     c->cv_disp.notify_all();
-    c->cv_comp.notify_all();
     c->cv_space.notify_all();
+    // 1. the dispatcher first: it may be inside frt_pipeline_submit_crops - the ticket it gets is queued before it sees `stop`
     if (c->t_disp.joinable()) c->t_disp.join();
-    if (c->t_comp.joinable()) c->t_comp.join();
-    {   // callers still parked on a batch (destroying an object in use is the caller's bug; do not leave them asleep)
+    {
         std::lock_guard<std::mutex> lk(c->mu);
+        c->disp_done = true;
+    }
+    c->cv_comp.notify_all();
+    // 2. the completer drains every submitted ticket (frt_pipeline_wait: kernels and result copies of those batches have finished)
+    if (c->t_comp.joinable()) c->t_comp.join();
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        // 3. callers still parked on a batch that never ran (destroying an object in use is the caller's bug; do not leave them asleep)
         for (auto &b : c->batch) {
             if (b.state == frt_coalescer::OPEN || b.state == frt_coalescer::CLOSED) {
                 b.rc = FRT_ERR_INVALID;
@@ -237,6 +248,9 @@ void frt_coalescer_destroy(frt_coalescer *c) {
             }
             b.cv_done.notify_all();
         }
+        c->open = -1;
+        // 4. ... and wait until the last of them has left frt_coalescer_infer_crops: they still read the batch's buffers and this mutex
+        c->cv_idle.wait(lk, [&] { return c->active == 0; });
     }
     frt_pipeline_destroy(c->pipe);
     for (auto &b : c->batch) {
@@ -255,8 +269,20 @@ int frt_coalescer_infer_crops(frt_coalescer *c, const uint8_t *bgr, int rows, in
         if (rows != c->frame_h || cols != c->frame_w) raise(FRT_ERR_INVALID, "coalescer: frame size differs from the detector's frame size");
         if (row_stride < (size_t)cols * 3) raise(FRT_ERR_INVALID, "coalescer: row stride smaller than a row");
         std::unique_lock<std::mutex> lk(c->mu);
-        c->cv_space.wait(lk, [&] { return c->stop || (c->open >= 0 && c->batch[c->open].joined < c->max_frames); });
         if (c->stop) raise(FRT_ERR_INVALID, "coalescer: shutting down");
+        struct Active {  // counted while this call may touch the coalescer; frt_coalescer_destroy waits for zero
+            frt_coalescer *c;
+            explicit Active(frt_coalescer *c_) : c(c_) { ++c->active; }   // (under c->mu)
+            ~Active() {
+                std::lock_guard<std::mutex> g(c->mu);
+                if (--c->active == 0) c->cv_idle.notify_all();
+            }
+        } active_guard(c);
+        c->cv_space.wait(lk, [&] { return c->stop || (c->open >= 0 && c->batch[c->open].joined < c->max_frames); });
+        if (c->stop) {
+            lk.unlock();  // (the guard's destructor takes the mutex)
+            raise(FRT_ERR_INVALID, "coalescer: shutting down");
+        }
         const int bi = c->open;
         frt_coalescer::Batch &b = c->batch[bi];
         const int slot = b.joined++;
@@ -291,7 +317,7 @@ int frt_coalescer_infer_crops(frt_coalescer *c, const uint8_t *bgr, int rows, in
         lk.lock();
         if (--b.readers == 0) {  // last reader out: the staging set is free again
             b.state = frt_coalescer::FREE;
-            c->open_next_locked();
+            if (!c->stop) c->open_next_locked();
             c->cv_disp.notify_all();
         }
         lk.unlock();

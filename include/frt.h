@@ -57,6 +57,12 @@ int frt_device_count(void);
  * parks in the interrupt wait.  Process-wide.  A server with many request threads keeps the default; a throughput driver that owns its
  * core may raise it (bench.py uses 50 000 and reports it).  Returns the previous value. */
 long frt_set_wait_spin_us(long microseconds);
+/* Measurement aid (no counterpart in the reference): what this device SUSTAINS on the recogniser's matrix-core instruction mix, in TFLOP/s.
+ * Runs back-to-back v_mfma_f32_32x32x16_f16 on random fp16 operands on every SIMD for about `seconds` (0 < seconds <= 10) -
+ * mix 0: MFMAs only; 1: + one ds_read_b128 per MFMA; 2: + the global loads of the dominant conv kernel's K loop as well - and returns
+ * flop / elapsed.  The part is power-managed (1.4 kW), so this is well below the nominal 2.5 PFLOP/s; bench.py quotes the dominant
+ * kernel against both (roofline.sustained_peak). */
+int frt_probe_sustained_mfma(int device, int mix, double seconds, double *tflops_out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Detector  ==  class RetinaFace (src/retinaface.h:18-23)
@@ -143,6 +149,20 @@ int frt_matcher_init(frt_matcher *m, const float *gallery, int num_row, int num_
  * and per GPU).  With fp16 storage the similarities are DEFINED as the fp32 dot products with the fp16-rounded rows
  * (sum_k e[k] * float(half(g[k])), fp32 fmaf chain) - calculate / top1 / the pipeline all agree on them bit for bit. */
 int frt_matcher_set_storage(frt_matcher *m, int fp16);
+/* Screened top-1 on / off (default on).  Galleries of >= 32 768 rows answer top-1 calls with a coarse scan of a compact shadow copy
+ * (int8 rows with a per-row scale for 512-column fp32 galleries, fp16 otherwise) followed by an EXACT fp32 re-rank of every row the
+ * rigorous error bound cannot exclude - the result is bit-identical to the exact scan, its cost depends on the queries (a query that
+ * matches keeps one candidate block, one that matches nothing a dozen).  on = 0 makes every call take the exact fp32 scan of the
+ * whole gallery (MatMul::calculate's arithmetic, src/matmul.h:7-16, with the first-maximum epilogue of src/arcface.cpp:203-217 fused):
+ * 4 * num_col * num_row bytes per call whatever the queries - the path's worst case, reported by bench.py as `match_worst_case`. */
+int frt_matcher_set_screening(frt_matcher *m, int on);
+/* A counter that changes whenever the gallery this matcher answers from changes (init / commit / row offset; also when its scratch buffers
+ * move).  A caller that keeps (row index, similarity) pairs across calls compares it to know whether the indices still name the same rows
+ * (include/frt/arcface.h: the coalesced fast path of featureMatching / getOutputs). */
+unsigned frt_matcher_generation(frt_matcher *m);
+/* Bytes of gallery data ONE top-1 call reads in the current mode (the coarse scan's shadow copy when screening is on and the gallery is
+ * large enough for it, the stored rows otherwise; the exact re-rank's candidate rows come on top and depend on the queries). */
+size_t frt_matcher_scan_bytes(frt_matcher *m);
 /* Streaming gallery load == the loop of Database::getEmbeddings (src/db.cpp:316-346):
  *   initKnownEmbeds(n)            -> frt_matcher_gallery_begin(m, n, 512)
  *   addEmbedding(id, blob) x n    -> frt_matcher_gallery_append(m, blob, 1)     (blob = sqlite3_column_blob: raw little-endian

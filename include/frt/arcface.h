@@ -11,6 +11,12 @@
 #include <algorithm>
 #include <array>
 #include <cassert>
+#include <cstring>
+#include <iterator>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
 #include <tuple>
 
 #include "coalesce.h"
@@ -74,7 +80,10 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
         checkFrtStatus(frt_embedder_create(engineFile.c_str(), m_INPUT_C, m_INPUT_H, m_INPUT_W, outputDim, devBatch, device, &h_));
         std::cout << "[INFO] Loading ArcFace Engine...\n";
         croppedFaces.reserve((size_t)maxFacesPerScene);
+        m_device = device;
+        m_devBatch = devBatch;
         if (envFrames > 0) {
+            m_auto = true;
             try {
                 frtdetail::autoLink(false, frtdetail::Pending{device, frameWidth, frameHeight, devBatch, nullptr, h_, matmul.handle(), &m_link});
             } catch (...) {
@@ -85,8 +94,9 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     }
     ~ArcFaceIR50() {
         frtdetail::autoUnlink(false, &m_link);
-        if (m_link) m_link->shutdown();  // the coalescer borrows this object's embedder and matcher
+        if (std::shared_ptr<frtdetail::CoalesceLink> l = link()) l->shutdown();  // the coalescer borrows this object's embedder and matcher (waits for calls inside it)
         frt_embedder_destroy(h_);
+        frtdetail::retireObject(m_id);  // every thread drops its per-thread state of this object (page-locked similarity buffers) on its next access
     }
     // Opt-in request coalescing (include/frt/coalesce.h): findFace() calls of concurrent request threads on `detector` share one device
     // batch - detector, crop, recogniser, top-1 - and this object's forward() / featureMatching() / getOutputs() on the same thread, frame
@@ -96,8 +106,8 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     template <class Detector>
     void coalesceWith(Detector &detector, int maxFrames = 0, int windowUs = 100) {
         std::shared_ptr<frtdetail::CoalesceLink> l = frtdetail::makeLink(detector.handle(), h_, matmul.handle(), maxFrames, windowUs);
-        if (m_link) m_link->shutdown();
-        m_link = l;
+        if (std::shared_ptr<frtdetail::CoalesceLink> old = link()) old->shutdown();
+        std::atomic_store(&m_link, l);
         detector.attachCoalescer(l);
     }
     ArcFaceIR50(const ArcFaceIR50 &) = delete;
@@ -297,7 +307,10 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     const float *embeddings() const { return st().embeds.data(); }
     frt_embedder *handle() { return h_; }
     MatMul &matcher() { return matmul; }
-    bool coalescing() const { return m_link && m_link->c; }
+    bool coalescing() const {
+        std::shared_ptr<frtdetail::CoalesceLink> l = link();
+        return l && l->alive();
+    }
 
   private:
     // What a call leaves behind for the next call of the same request - per calling THREAD (include/frt/coalesce.h): the reference keeps
@@ -323,11 +336,28 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
   private:
     // forward() of a frame this thread's coalesced findFace() has just analysed: same frame bytes (pointer, size, sampled fingerprint),
     // same boxes, every ROI non-empty -> embeddings, crops and first maxima come from the record
+    std::shared_ptr<frtdetail::CoalesceLink> link() const { return std::atomic_load(&m_link); }
+    // FRT_COALESCE: the detector of an auto-linked pair was destroyed (its destructor shut the coalescer down) - wait for a new partner
+    void relinkIfOrphaned() {
+        if (!m_auto) return;
+        std::shared_ptr<frtdetail::CoalesceLink> l = link();
+        if (!l || l->alive()) return;
+        std::lock_guard<std::mutex> lk(m_relink);
+        l = link();
+        if (!l || l->alive()) return;
+        std::atomic_store(&m_link, std::shared_ptr<frtdetail::CoalesceLink>());
+        try {
+            frtdetail::autoLink(false, frtdetail::Pending{m_device, m_frameWidth, m_frameHeight, m_devBatch, nullptr, h_, matmul.handle(), &m_link});
+        } catch (...) {  // (a partner exists but the coalescer could not be built: stay on the plain path)
+        }
+    }
     bool forwardFromRecord(State &s, const cv::Mat &image, const std::vector<struct Bbox> &boxes) {
-        if (!m_link) return false;
+        relinkIfOrphaned();
+        std::shared_ptr<frtdetail::CoalesceLink> lnk = link();
+        if (!lnk) return false;
         frtdetail::FrameRecord &fr = frtdetail::frameRecord();
         const size_t n = boxes.size();
-        if (fr.link != m_link.get() || fr.data != image.data || fr.rows != image.rows || fr.cols != image.cols || fr.boxes.size() != n ||
+        if (fr.link != lnk.get() || fr.data != image.data || fr.rows != image.rows || fr.cols != image.cols || fr.boxes.size() != n ||
             m_INPUT_H != 112 || m_INPUT_W != 112 || m_OUTPUT_D != 512)
             return false;
         for (size_t i = 0; i < n; ++i)
@@ -356,6 +386,9 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
             s.top_sim[i] = fr.res[i].match_sim;
             if (fr.res[i].match_idx < 0) matched = false;  // the batch ran without a gallery
         }
+        // the batch's (row index, similarity) pairs name rows of the gallery it ran against: after addEmbedding / initKnownEmbeds / initMatMul
+        // they would index a different classNames - featureMatching / getOutputs then take the device path with these embeddings
+        if (!fr.galleryGen || fr.galleryGen != frt_matcher_generation(matmul.handle())) matched = false;
         s.from_record = true;
         s.top_valid = matched;
         return true;
@@ -365,6 +398,9 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
     int m_frameWidth, m_frameHeight, m_INPUT_C, m_INPUT_H, m_INPUT_W, m_OUTPUT_D, m_maxBatchSize, m_maxFacesPerScene;
     float m_knownPersonThresh;
     bool m_materialize = true;
+    bool m_auto = false;
+    int m_device = 0, m_devBatch = 0;
+    std::mutex m_relink;
     std::vector<std::string> classNames;
     MatMul matmul;
     std::shared_ptr<frtdetail::CoalesceLink> m_link;

@@ -12,7 +12,9 @@
 #ifndef FRT_COALESCE_H
 #define FRT_COALESCE_H
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <memory>
@@ -29,10 +31,39 @@ inline uint64_t nextObjectId() {
     return n++;
 }
 
-// the calling thread's instance of S for the object `id` (created on first use, destroyed with the thread)
+// Objects that have been destroyed: their per-thread slots (which may hold page-locked buffers) are dropped by each thread on its next
+// perThread() access after the destruction (a thread cannot reach into another thread's thread_local storage).
+struct DeadObjects {
+    std::mutex mu;
+    std::vector<uint64_t> ids;       // sorted
+    std::atomic<uint64_t> epoch{0};  // bumped per destruction
+};
+inline DeadObjects &deadObjects() {
+    static DeadObjects d;
+    return d;
+}
+inline void retireObject(uint64_t id) {
+    DeadObjects &d = deadObjects();
+    std::lock_guard<std::mutex> lk(d.mu);
+    d.ids.insert(std::upper_bound(d.ids.begin(), d.ids.end(), id), id);
+    d.epoch.fetch_add(1, std::memory_order_release);
+}
+
+// the calling thread's instance of S for the object `id` (created on first use; destroyed with the thread, or on this thread's first
+// access after the object itself was destroyed)
 template <class S>
 S &perThread(uint64_t id) {
     static thread_local std::vector<std::pair<uint64_t, std::unique_ptr<S>>> slots;
+    static thread_local uint64_t seen_epoch = 0;
+    DeadObjects &d = deadObjects();
+    const uint64_t ep = d.epoch.load(std::memory_order_acquire);
+    if (ep != seen_epoch) {
+        std::lock_guard<std::mutex> lk(d.mu);
+        slots.erase(std::remove_if(slots.begin(), slots.end(),
+                                   [&](const std::pair<uint64_t, std::unique_ptr<S>> &e) { return std::binary_search(d.ids.begin(), d.ids.end(), e.first); }),
+                    slots.end());
+        seen_epoch = ep;
+    }
     for (auto &e : slots)
         if (e.first == id) return *e.second;
     slots.emplace_back(id, std::unique_ptr<S>(new S()));
@@ -66,14 +97,45 @@ class PerThreadVector {
 // ---- coalescing
 struct CoalesceLink {  // shared by the detector shell and the recogniser shell; whichever dies first shuts the coalescer down
     std::mutex mu;
+    std::condition_variable cv;
     frt_coalescer *c = nullptr;
+    frt_matcher *mat = nullptr;  // the gallery the coalesced batches are matched against (for frt_matcher_generation)
     int maxFaces = 0;
+    int users = 0;               // calls inside frt_coalescer_* through this link
     ~CoalesceLink() { shutdown(); }
-    void shutdown() {
+    // a call takes the coalescer for its duration: shutdown() - run by the OTHER shell's destructor, possibly on another thread - waits for it
+    frt_coalescer *acquire() {
         std::lock_guard<std::mutex> lk(mu);
-        if (c) frt_coalescer_destroy(c);
-        c = nullptr;
+        if (!c) return nullptr;
+        ++users;
+        return c;
     }
+    void release() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--users == 0) cv.notify_all();
+    }
+    bool alive() {
+        std::lock_guard<std::mutex> lk(mu);
+        return c != nullptr;
+    }
+    void shutdown() {
+        std::unique_lock<std::mutex> lk(mu);
+        frt_coalescer *dead = c;
+        c = nullptr;  // no new call gets it
+        cv.wait(lk, [&] { return users == 0; });
+        lk.unlock();
+        if (dead) frt_coalescer_destroy(dead);
+    }
+};
+struct CoalesceUse {  // RAII: acquire / release
+    CoalesceLink *l;
+    frt_coalescer *c;
+    explicit CoalesceUse(CoalesceLink *link) : l(link), c(link ? link->acquire() : nullptr) {}
+    ~CoalesceUse() {
+        if (c) l->release();
+    }
+    CoalesceUse(const CoalesceUse &) = delete;
+    CoalesceUse &operator=(const CoalesceUse &) = delete;
 };
 
 // what a coalesced findFace() left behind for the same thread's forward() / featureMatching()
@@ -81,7 +143,10 @@ struct FrameRecord {
     const CoalesceLink *link = nullptr;
     const unsigned char *data = nullptr;
     int rows = 0, cols = 0;
-    uint64_t print = 0;  // fingerprint of sampled pixels: the frame must still be the one that was analysed
+    uint64_t print = 0;  // fingerprint of sampled pixels: the frame must still be the one that was analysed (64 x 8 sampled bytes: a frame
+                         // modified IN PLACE between findFace() and forward() - boxes drawn on it - can go unnoticed; forward() then returns the
+                         // crops of the frame as it was analysed, which is what the boxes belong to)
+    unsigned galleryGen = 0;  // frt_matcher_generation around the batch; 0 = the gallery changed meanwhile (match_idx / match_sim not usable)
     std::vector<Bbox> boxes;
     std::vector<frt_face_result> res;
     std::vector<float> embeds;          // [n][512]
@@ -146,6 +211,7 @@ inline std::shared_ptr<CoalesceLink> makeLink(frt_detector *d, frt_embedder *e, 
     checkFrtStatus(frt_detector_geometry(d, nullptr, nullptr, &mb, &mf, nullptr));
     if (frames <= 0 || frames > mb) frames = mb;
     checkFrtStatus(frt_coalescer_create(d, e, m, frames, window_us, &l->c));
+    l->mat = m;
     l->maxFaces = mf;
     return l;
 }
@@ -159,8 +225,8 @@ inline void autoLink(bool isDet, const Pending &me) {
         if (o.device != me.device || o.fw != me.fw || o.fh != me.fh) continue;
         const Pending &d = isDet ? me : o, &rc = isDet ? o : me;
         std::shared_ptr<CoalesceLink> l = makeLink(d.det, rc.emb, rc.mat, coalesceEnv().frames, coalesceEnv().window_us);
-        *d.slot = l;
-        *rc.slot = l;
+        std::atomic_store(d.slot, l);   // (request threads read the shells' link members with atomic_load)
+        std::atomic_store(rc.slot, l);
         others.erase(others.begin() + (long)i);
         return;
     }

@@ -11,6 +11,9 @@
 #endif
 #endif
 
+#if defined(FRT_EXPECT_OPENCV_BRANCH) && !defined(FRT_HAVE_OPENCV)
+#error "FRT_EXPECT_OPENCV_BRANCH: <opencv2/core.hpp> was not found on the include path"
+#endif
 #ifdef FRT_HAVE_OPENCV
 #include <opencv2/core.hpp>
 #include <opencv2/imgproc.hpp>

@@ -42,6 +42,11 @@ class MatMul {
         ensure();
         checkFrtStatus(frt_matcher_set_storage(h_, on ? 1 : 0));
     }
+    // Extension: exact fp32 scan on every top-1 call instead of the screened one (same answers; see frt_matcher_set_screening)
+    void setScreening(bool on) {
+        ensure();
+        checkFrtStatus(frt_matcher_set_screening(h_, on ? 1 : 0));
+    }
     // Extension: fused argmax (what ArcFaceIR50::getOutputs computes from the full matrix), never materialises [n x numRow].
     void top1(float *embeds, int embedCount, int *idx, float *sim) {
         ensure();

@@ -36,7 +36,10 @@ class RetinaFace {
         checkFrtStatus(frt_detector_create(engineFile.c_str(), frameWidth, frameHeight, inputShape[0], inputShape[1], inputShape[2],
                                            devBatch, maxFacesPerScene, nms_threshold, bbox_threshold, device, &h_));
         std::cout << "[INFO] Loading RetinaFace Engine...\n";
+        m_device = device;
+        m_devBatch = devBatch;
         if (envFrames > 0) {
+            m_auto = true;
             try {
                 frtdetail::autoLink(true, frtdetail::Pending{device, frameWidth, frameHeight, devBatch, h_, nullptr, nullptr, &m_link});
             } catch (...) {
@@ -47,26 +50,35 @@ class RetinaFace {
     }
     ~RetinaFace() {
         frtdetail::autoUnlink(true, &m_link);
-        if (m_link) m_link->shutdown();  // the coalescer borrows this object's detector
+        if (std::shared_ptr<frtdetail::CoalesceLink> l = link()) l->shutdown();  // the coalescer borrows this object's detector (waits for calls inside it)
         frt_detector_destroy(h_);
     }
     // set by ArcFaceIR50::coalesceWith(detector)
     void attachCoalescer(const std::shared_ptr<frtdetail::CoalesceLink> &l) {
-        if (m_link && m_link != l) m_link->shutdown();
-        m_link = l;
+        std::shared_ptr<frtdetail::CoalesceLink> old = link();
+        if (old && old != l) old->shutdown();
+        std::atomic_store(&m_link, l);
     }
-    bool coalescing() const { return m_link && m_link->c; }
+    bool coalescing() const {
+        std::shared_ptr<frtdetail::CoalesceLink> l = link();
+        return l && l->alive();
+    }
     // batches submitted / frames carried by the coalescer so far (frames / batches = the batch size the load produced)
     bool coalesceStats(long &batches, long &frames) const {
         batches = frames = 0;
-        return m_link && m_link->c && frt_coalescer_stats(m_link->c, &batches, &frames) == FRT_OK;
+        std::shared_ptr<frtdetail::CoalesceLink> l = link();
+        frtdetail::CoalesceUse use(l.get());
+        return use.c && frt_coalescer_stats(use.c, &batches, &frames) == FRT_OK;
     }
     RetinaFace(const RetinaFace &) = delete;
     RetinaFace &operator=(const RetinaFace &) = delete;
 
     // src/retinaface.cpp:147-152.  img must be CV_8UC3 of frameWidth x frameHeight (the caller resizes, src/app.cpp:301).
     std::vector<struct Bbox> findFace(cv::Mat &img) {
-        if (m_link && m_link->c && img.rows == m_frameHeight && img.cols == m_frameWidth) {
+        relinkIfOrphaned();
+        std::shared_ptr<frtdetail::CoalesceLink> lnk = link();
+        frtdetail::CoalesceUse use(img.rows == m_frameHeight && img.cols == m_frameWidth ? lnk.get() : nullptr);
+        if (use.c) {
             // coalesced: this frame joins the batch that the requests being served right now form together; the batch runs detector, crop,
             // recogniser and top-1 in one device pass and this thread keeps its frame's share for forward() / featureMatching()
             frtdetail::FrameRecord &fr = frtdetail::frameRecord();
@@ -76,14 +88,17 @@ class RetinaFace {
             fr.embeds.resize(K * 512);
             fr.crops.resize(K * 112 * 112 * 3);
             int n = 0;
-            checkFrtStatus(frt_coalescer_infer_crops(m_link->c, img.data, img.rows, img.cols, (size_t)img.step, fr.res.data(), fr.embeds.data(), fr.crops.data(), &n));
+            const unsigned gen0 = lnk->mat ? frt_matcher_generation(lnk->mat) : 0u;
+            checkFrtStatus(frt_coalescer_infer_crops(use.c, img.data, img.rows, img.cols, (size_t)img.step, fr.res.data(), fr.embeds.data(), fr.crops.data(), &n));
             fr.boxes.resize((size_t)n);
             for (int i = 0; i < n; ++i) std::memcpy(&fr.boxes[(size_t)i], &fr.res[(size_t)i].box, sizeof(Bbox));
             fr.data = img.data;
             fr.rows = img.rows;
             fr.cols = img.cols;
             fr.print = frtdetail::framePrint(img.data, img.rows, img.cols, (size_t)img.step);
-            fr.link = m_link.get();
+            const unsigned gen1 = lnk->mat ? frt_matcher_generation(lnk->mat) : 0u;
+            fr.galleryGen = gen0 == gen1 ? gen1 : 0u;  // a reload while the batch ran: its row indices may name rows of either gallery
+            fr.link = lnk.get();
             return fr.boxes;
         }
         std::vector<struct Bbox> out((size_t)m_maxFacesPerScene);
@@ -127,7 +142,25 @@ class RetinaFace {
     frt_detector *handle() { return h_; }
 
   private:
+    // FRT_COALESCE: the partner of an auto-linked pair was destroyed (its destructor shut the coalescer down) - wait for a new partner
+    std::shared_ptr<frtdetail::CoalesceLink> link() const { return std::atomic_load(&m_link); }
+    void relinkIfOrphaned() {
+        if (!m_auto) return;
+        std::shared_ptr<frtdetail::CoalesceLink> l = link();
+        if (!l || l->alive()) return;
+        std::lock_guard<std::mutex> lk(m_relink);
+        l = link();
+        if (!l || l->alive()) return;
+        std::atomic_store(&m_link, std::shared_ptr<frtdetail::CoalesceLink>());
+        try {
+            frtdetail::autoLink(true, frtdetail::Pending{m_device, m_frameWidth, m_frameHeight, m_devBatch, h_, nullptr, nullptr, &m_link});
+        } catch (...) {  // (a partner exists but the coalescer could not be built: stay on the plain path)
+        }
+    }
     frt_detector *h_;
+    bool m_auto = false;
+    int m_device = 0, m_devBatch = 0;
+    std::mutex m_relink;
     int m_maxFacesPerScene, m_maxBatchSize, m_frameWidth, m_frameHeight;
     std::shared_ptr<frtdetail::CoalesceLink> m_link;
 };

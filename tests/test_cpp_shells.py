@@ -34,6 +34,19 @@ def test_no_escape_hatch_macro_left():
             assert "FRT_ARCFACE_NO_STATIC_DEFINITION" not in open(os.path.join(root, f)).read()
 
 
+@pytest.mark.parametrize("src", ["dropin_demo.cpp", "dropin_db.cpp", "coalesce_test.cpp", "dropin_bench.cpp"])
+def test_opencv_branch_of_the_shells_parses_and_type_checks(src):
+    """SYNTAX CHECK ONLY (g++ -fsyntax-only, nothing is linked or run): the FRT_HAVE_OPENCV branch of include/frt/*.h - the one a deployment
+    with the real OpenCV takes (src/arcface.h:4-5, src/retinaface.h:4-5 include it) - against tests/cpp/opencv_decl_mock/, a declarations-only
+    description of the dozen OpenCV symbols the shells touch (cv::Mat with its MatStep `step`, Scalar, Point, rectangle, putText).  The build
+    image has no OpenCV; this proves the branch is well-formed, nothing about pixels.  (It found a missing <cstring> the cvlite branch hid.)"""
+    mock = os.path.join(ROOT, "tests", "cpp", "opencv_decl_mock")
+    assert "SYNTAX-CHECK MOCK" in open(os.path.join(mock, "opencv2", "core.hpp")).read()
+    out = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-DFRT_EXPECT_OPENCV_BRANCH", "-I", mock, "-I",
+                          os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", src)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
 def test_shells_compile_and_report_missing_engine(demo):
     out = subprocess.run([demo, "--selftest"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "selftest ok" in out.stdout, out.stdout + out.stderr
