@@ -250,10 +250,11 @@ void fold_pw(const frt::Blob &b, const std::string &conv, const std::string &bn,
     bias = bi;
 }
 inline int conv_out(int x, int stride) { return (x + 2 - 3) / stride + 1; }
-// [Cin][9][Cout] fp32 -> fp16 hi/lo split [Cin/16][9][64][hi16 | lo16] (kernels_det_conv3h.hip); empty unless Cin == 64, Cout <= 64
+// [Cin][9][Cout] fp32 -> fp16 hi/lo split [Cin/16][9][64][hi16 | lo16] (kernels_det_conv3h.hip); empty unless Cin is 64 or 16 and 16 <= Cout <= 64
 std::vector<uint16_t> pack_conv3_split(const std::vector<float> &w, int cin, int cout) {
-    if (cin != 64 || cout > 64 || cout < 16) return {};
-    std::vector<uint16_t> o((size_t)4 * 9 * 64 * 32, 0);
+    if ((cin != 64 && cin != 16) || cout > 64 || cout < 16) return {};
+    const int nch = cin / 16;
+    std::vector<uint16_t> o((size_t)nch * 9 * 64 * 32, 0);
     auto h2f = [](uint16_t h) {  // fp16 -> fp32 (normal / subnormal / zero; no inf/nan expected in weights)
         const uint32_t sgn = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 31, m = h & 1023;
         float f;
@@ -261,7 +262,7 @@ std::vector<uint16_t> pack_conv3_split(const std::vector<float> &w, int cin, int
         else f = std::ldexp((float)(m | 1024), (int)e - 25);
         return sgn ? -f : f;
     };
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < nch; ++c)
         for (int t = 0; t < 9; ++t)
             for (int co = 0; co < cout; ++co)
                 for (int k = 0; k < 16; ++k) {
@@ -527,6 +528,10 @@ void frt_detector::build(const frt::Blob &b) {
                 std::copy(w2.begin() + row * 16, w2.begin() + (row + 1) * 16, wc.begin() + row * 32 + 16);
             }
             o.c3[k] = Conv3Args{t1[k], cat[k], arena.upload(wc), arena.upload(bc), B, 16, fh[k], fw[k], 32, fh[k], fw[k], 1, 1, 64, 32};
+            {
+                const std::vector<uint16_t> ph = pack_conv3_split(wc, 16, 32);  // round 5: the 16-channel SSH convs on the split-fp16 matrix-core kernel
+                if (!ph.empty()) o.c3[k].wh = reinterpret_cast<const half_t *>(arena.upload(ph));
+            }
             o.c3[k].out2 = t2[k];
             o.c3[k].split = 16;
             o.c3[k].out2_ctotal = 16;

@@ -1,23 +1,27 @@
-// RetinaFace dense 3x3 convs with 64 input channels (FPN merges, fused SSH 64->48) on the fp16 matrix cores at fp32 accuracy.
+// RetinaFace dense 3x3 convs with 64 or 16 input channels (FPN merges, fused SSH 64->48, the SSH 16->32 / 16->16 convs) on the fp16
+// matrix cores at fp32 accuracy.
 //
 // Arithmetic spec: /root/reference/conversion/retina/models/net.py:9-17,40-66,88-96 (BN folded on the host).
 //
-// The fp32 MFMA kernel (kernels_det_conv3.hip) is bound by the fp32 matrix rate (157 TF, ~50 % reached: 181 us for the 80x80 merge).
-// Here every fp32 value x is split into two fp16 numbers, hi = fp16(x) and lo = fp16(x - hi) (x = hi + lo up to 2^-22 |x|), and
+// Every fp32 value x is split into two fp16 numbers, hi = fp16(x) and lo = fp16(x - hi) (x = hi + lo up to 2^-22 |x|), and
 //      a * b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (the dropped lo*lo term is 2^-22 relative)
 // is accumulated by three v_mfma_f32_32x32x16_f16 per 16 input channels - every fp16 x fp16 product is exact in fp32, the
 // accumulation is fp32, so the result carries fp32-class error (~1e-6 relative per layer, inside the detector's tolerances)
-// at 96 matrix-pipe clocks per 16 channels instead of 512.  Weights are split on the host, activations when the halo patch is
-// staged into LDS (the patch costs the same LDS bytes as fp32: 2 x 2 B).
+// at 96 matrix-pipe clocks per 16 channels instead of the 512 of the true-fp32 MFMA (kernels_det_conv3.hip).  Weights are split on the
+// host, activations when the halo patch is staged into LDS (the patch costs the same LDS bytes as fp32: 2 x 2 B).
 //
-//   * persistent workgroups, 4 waves; tile = 16 columns x 8*PBW rows; a wave owns PBW 32-pixel blocks x all 64 output channels.
-//     PBW = 1 (8x16 tiles, 75 KB of LDS, two workgroups per CU) measured 27 / 82 / 95 us on merge2 / merge1 / fused SSH against
-//     59 / 116 / 133 us for PBW = 2 (16x16 tiles, 98 KB, one workgroup per CU) and 54 / 181 / 223 us for the fp32 MFMA kernel:
-//     a second resident workgroup hides the per-step latencies better than the 2x operand reuse of the big tile pays;
-//   * step = (tile, 16-channel chunk): all 9 taps of the chunk's weights [9][64][hi16|lo16] sit in LDS (46 KB, single buffer:
-//     the next chunk's copy waits in registers during the step), the halo patch chunk [(8*PBW+2)x18][hi16|lo16] is
-//     double-buffered; both are fetched one step ahead; two barriers per step (54*PBW MFMAs per wave);
+//   * persistent workgroups, 4 waves; tile = 16 columns x 8 rows; a wave owns one 32-pixel block (two tile rows) x all output channels
+//     (NCB blocks of 32); 52 - 75 KB of LDS: two workgroups per CU, the second one's staging phase under the first one's MFMAs;
+//   * step = (tile, 16-channel chunk): all 9 taps of the chunk's weights [9][32 NCB][hi16|lo16] sit in LDS (single buffer: the next
+//     chunk's copy waits in registers during the step), the halo patch chunk [10 x 18][hi16|lo16] is double-buffered; both are fetched
+//     one step ahead.  With ONE chunk (16 input channels) the weights stay in LDS for as long as the pyramid level does not change;
 //   * LDS rows are 80 B (64 + 16 pad): conflict-free ds_read_b128 for both operands;
+//   * round 5: the tap loop is software-pipelined by hand.  Left to the compiler every tap was "six ds_read_b128, wait for all of them,
+//     six MFMAs" with the three MFMAs of an accumulator back to back - two exposed LDS round trips per tap, 18 per step, and a step took
+//     ~ 15 k cycles for 1.7 k cycles of matrix work per wave (merge1 98 us).  Now the fragments of tap t + 1 are requested one by one behind
+//     the MFMAs of tap t (two register sets, sched_barrier after every MFMA + read pair) and the MFMAs of the two cout blocks alternate, so
+//     that an accumulator's next MFMA is two issue slots away.  Each accumulator still sees its products in the order (chunk, tap,
+//     hi*hi, hi*lo, lo*hi): the results are bit-identical to the round-4 kernel (tools/ubench/det_conv3h_bench.hip compares them);
 //   * same epilogue conventions as the fp32 kernel (bias, ReLU, channel-split second output, up to 3 pyramid levels per launch).
 #include <cstdlib>
 
@@ -25,12 +29,17 @@
 
 namespace {
 
-constexpr int TS = 16;                    // tile width (output pixels); tile height = 8 * PBW (PBW pixel blocks per wave)
+#ifndef FRT_C3H_ABL
+#define FRT_C3H_ABL 0   // timing ablations of tools/ubench/det_conv3h_bench.hip (wrong results by design): 1 no tap loop, 2 no patch staging,
+#endif                  // 4 no weight staging, 8 no output stores, 16 no barriers
+constexpr int TS = 16;                    // tile width (output pixels); tile height 8
+constexpr int TH = 8;
 constexpr int PS = TS + 2;                // patch width
 constexpr int ROWH = 40;                  // halves per LDS row: 16 hi + 16 lo + 8 pad (80 B)
-constexpr int WCH_H = 9 * 64 * ROWH;      // halves of one weight chunk in LDS
-constexpr int WUNITS = 9 * 64 * 4;        // 16-byte units of a weight chunk (hi 2 + lo 2 per row)
-constexpr int WPT = WUNITS / 256;         // 9
+constexpr int NPOS = (TH + 2) * PS;       // halo positions (180)
+constexpr int PATCH_H = NPOS * ROWH;      // halves per patch buffer
+constexpr int PITEMS = NPOS * 4;          // (position, channel quad) items of a patch chunk
+constexpr int PPT = (PITEMS + 255) / 256; // 3
 
 struct Conv3H {
     Conv3Args p[3];
@@ -40,7 +49,6 @@ struct Conv3H {
 struct TileG {
     int lv, b, oy0, ox0;
 };
-template <int PBW>
 __device__ __forceinline__ TileG tile_g(const Conv3H &mm, int t) {
     TileG g;
     g.lv = t >= mm.base[2] ? 2 : (t >= mm.base[1] ? 1 : 0);
@@ -49,21 +57,20 @@ __device__ __forceinline__ TileG tile_g(const Conv3H &mm, int t) {
     g.b = local / per;
     const int rem = local - g.b * per;
     const int tyi = rem / tx_n;
-    g.oy0 = tyi * (8 * PBW);
+    g.oy0 = tyi * TH;
     g.ox0 = (rem - tyi * tx_n) * TS;
     return g;
 }
 
-template <int PBW>
+// NCH = input channels / 16 (4: the 64-channel convs, 1: the 16-channel SSH convs); NCB = 32-wide output-channel blocks (Cout <= 32 NCB)
+template <int NCH, int NCB>
 __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
-    constexpr int TH = 8 * PBW;               // tile height
-    constexpr int NPOS = (TH + 2) * PS;       // halo positions (180 / 324)
-    constexpr int PATCH_H = NPOS * ROWH;      // halves per patch buffer
-    constexpr int PITEMS = NPOS * 4;          // (position, channel quad) items of a patch chunk
-    constexpr int PPT = (PITEMS + 255) / 256;
+    constexpr int WROWS = 9 * 32 * NCB;       // weight rows of a chunk in LDS
+    constexpr int WUNITS = WROWS * 4;         // 16-byte units (hi 2 + lo 2 per row)
+    constexpr int WPT = (WUNITS + 255) / 256; // 9 / 5 per thread
     extern __shared__ __attribute__((aligned(16))) char smem3h[];
     half_t *pbuf = reinterpret_cast<half_t *>(smem3h);        // [2][NPOS][ROWH]
-    half_t *wbuf = pbuf + 2 * PATCH_H;                        // [9][64][ROWH]
+    half_t *wbuf = pbuf + 2 * PATCH_H;                        // [9][32 NCB][ROWH]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hi = lane >> 5;
 
@@ -77,13 +84,12 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
         if (k < k_full) return wid + k * nwg;
         return (k == k_full && (int)blockIdx.x < rem_tiles) ? k_full * nwg + (int)blockIdx.x : total;
     };
-    constexpr int NCH = 4;  // 64 input channels = 4 chunks of 16
 
     // ---- staging: patch chunk (position, channel quad) items -> registers (raw fp32), split + stored later
     floatx4 pst[PPT];
     unsigned pok = 0;
     auto fetch_patch = [&](int t, int c) {
-        const TileG g = tile_g<PBW>(mm, t);
+        const TileG g = tile_g(mm, t);
         const Conv3Args &a = mm.p[g.lv];
         const long HW = (long)a.H * a.W;
         const float *inb = a.in + ((long)g.b * a.Cin + c * 16) * HW;
@@ -123,19 +129,24 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
             }
         }
     };
-    // weights: host-packed [chunk][9][64][32 halves = hi16|lo16]; 2304 16-byte units per chunk, 9 per thread
+    // weights: host-packed [chunk][9][64][32 halves = hi16|lo16] (rows >= Cout are zero); the kernel stages rows [0, 32 NCB) of every tap
     half8 wst[WPT];
     auto fetch_weights = [&](int lv, int c) {
         const half_t *src = mm.p[lv].wh + (long)c * (9 * 64 * 32);
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) wst[i] = *reinterpret_cast<const half8 *>(src + (long)(tid + i * 256) * 8);
+        for (int i = 0; i < WPT; ++i) {
+            int u = tid + i * 256;
+            if (u >= WUNITS) u = 0;  // (only the last, partial round of the NCB = 1 shape: a clamped, unused load)
+            const int row = u >> 2, part = u & 3, tap = row / (32 * NCB), co = row - tap * (32 * NCB);
+            wst[i] = *reinterpret_cast<const half8 *>(src + ((long)(tap * 64 + co) * 4 + part) * 8);
+        }
     };
     auto store_weights = [&]() {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int u = tid + i * 256;
-            const int row = u >> 2, part = u & 3;  // row = tap*64 + cout; part: hi0, hi1, lo0, lo1 (8 halves each)
-            *reinterpret_cast<half8 *>(wbuf + row * ROWH + part * 8) = wst[i];
+            const int row = u >> 2, part = u & 3;  // row = tap*(32 NCB) + cout; part: hi0, hi1, lo0, lo1 (8 halves each)
+            if (u < WUNITS) *reinterpret_cast<half8 *>(wbuf + row * ROWH + part * 8) = wst[i];
         }
     };
 
@@ -162,115 +173,138 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
     store_weights();
     __syncthreads();
 
-    // lane geometry: pixel block pb of this wave covers tile rows 2*(PBW*wave + pb) + (r >> 4), column r & 15
-    int bbase[PBW];
-#pragma unroll
-    for (int pb = 0; pb < PBW; ++pb) bbase[pb] = ((2 * (PBW * wave + pb) + (r >> 4)) * PS + (r & 15)) * ROWH + 8 * hi;
+    // lane geometry: this wave's pixel block covers tile rows 2*wave + (r >> 4), column r & 15
+    const int bbase = ((2 * wave + (r >> 4)) * PS + (r & 15)) * ROWH + 8 * hi;
     const int abase = r * ROWH + 8 * hi;
 
-    floatx16 acc[PBW][2];  // [pixel block][cout block]
+    floatx16 acc[NCB];
 #pragma unroll
-    for (int pb = 0; pb < PBW; ++pb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[pb][cb][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+
+    // fragments of one tap: [cb] a_hi, a_lo; b_hi, b_lo - two sets, tap t + 1 lands while tap t multiplies
+    constexpr int NF = 2 * NCB + 2;
+    half8 fr[2][NF];
 
     for (;;) {
         const bool v1 = s1.t < total;
+        // (one chunk per tile: the weights in LDS are the next step's too unless the pyramid level changes)
+        const bool new_w = NCH > 1 || (v1 && lv_of(s1.t) != lv_of(s0.t));
         if (v1) {
-            fetch_patch(s1.t, s1.c);
-            fetch_weights(lv_of(s1.t), s1.c);
+            if (!(FRT_C3H_ABL & 2)) fetch_patch(s1.t, s1.c);
+            if (new_w && !(FRT_C3H_ABL & 4)) fetch_weights(lv_of(s1.t), s1.c);
         }
         const half_t *pb_ = pbuf + s0.pc * PATCH_H;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        auto read_frag = [&](int tap, int i, half8 &dst) {   // fragment i of a tap: 0 .. 2 NCB - 1 weights (cb, hi | lo), then b_hi, b_lo
             const int kh = tap / 3, kw = tap - kh * 3;
-            const int poff = (kh * PS + kw) * ROWH;
-            half8 ah[2], al[2], bh[PBW], bl[PBW];
+            if (i < 2 * NCB)
+                dst = *reinterpret_cast<const half8 *>(wbuf + (tap * 32 * NCB + (i >> 1) * 32) * ROWH + abase + 16 * (i & 1));
+            else
+                dst = *reinterpret_cast<const half8 *>(pb_ + bbase + (kh * PS + kw) * ROWH + 16 * (i - 2 * NCB));
+        };
+        if (!(FRT_C3H_ABL & 1)) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                ah[cb] = *reinterpret_cast<const half8 *>(wbuf + (tap * 64 + cb * 32) * ROWH + abase);
-                al[cb] = *reinterpret_cast<const half8 *>(wbuf + (tap * 64 + cb * 32) * ROWH + abase + 16);
-            }
+        for (int i = 0; i < NF; ++i) read_frag(0, i, fr[0][i]);
+        __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-            for (int pb = 0; pb < PBW; ++pb) {
-                bh[pb] = *reinterpret_cast<const half8 *>(pb_ + bbase[pb] + poff);
-                bl[pb] = *reinterpret_cast<const half8 *>(pb_ + bbase[pb] + poff + 16);
-            }
+        for (int tap = 0; tap < ((FRT_C3H_ABL & 1) ? 0 : 9); ++tap) {
+            half8(&f)[NF] = fr[tap & 1];
+            half8(&n)[NF] = fr[(tap + 1) & 1];
+            const half8 bh = f[2 * NCB], bl = f[2 * NCB + 1];
+            // MFMA m of the tap: product (m / NCB): hi*hi, hi*lo, lo*hi; cout block m % NCB.  Behind each one, one fragment of tap + 1.
+            // Fragment i of the NEXT set may only be overwritten once this tap's MFMAs that read slot i of THIS set ... are a different
+            // register set: no hazard; the set being refilled was consumed by tap - 1.
 #pragma unroll
-            for (int pb = 0; pb < PBW; ++pb)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    acc[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bh[pb], acc[pb][cb], 0, 0, 0);
-                    acc[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl[pb], acc[pb][cb], 0, 0, 0);
-                    acc[pb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh[pb], acc[pb][cb], 0, 0, 0);
+            for (int m = 0; m < 3 * NCB; ++m) {
+                const int prod = m / NCB, cb = m - prod * NCB;
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(prod == 2 ? f[2 * cb + 1] : f[2 * cb], prod == 1 ? bl : bh, acc[cb], 0, 0, 0);
+                // (requested in the order the next tap's MFMAs need them: a_hi(0), b_hi, a_hi(1), b_lo, a_lo(0), a_lo(1))
+                constexpr int ord2[6] = {0, 4, 2, 5, 1, 3}, ord1[4] = {0, 2, 3, 1};
+                if (tap < 8 && m < NF) {
+                    const int i = NCB == 2 ? ord2[m] : ord1[m];
+                    read_frag(tap + 1, i, n[i]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (tap < 8 && NCB == 1) {
+                read_frag(tap + 1, 1, n[1]);  // (NCB = 1: four fragments, three MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (s0.c == NCH - 1) {
             // ---- tile finished: lane (r, hi) owns pixel r of its block and channels cb*32 + (e&3) + 8*(e>>2) + 4*hi
-            const TileG g = tile_g<PBW>(mm, s0.t);
+            const TileG g = tile_g(mm, s0.t);
             const Conv3Args &a = mm.p[g.lv];
             const long HoWo = (long)a.Ho * a.Wo;
+            const int oy = g.oy0 + 2 * wave + (r >> 4), ox = g.ox0 + (r & 15);
+            const bool inside = oy < a.Ho && ox < a.Wo;
+            const long pix = inside ? (long)oy * a.Wo + ox : 0;
+            float *o1 = a.out + ((long)g.b * a.out_ctotal + a.out_coff) * HoWo + pix;
+            float *o2 = a.out2 ? a.out2 + ((long)g.b * a.out2_ctotal + a.out2_coff - a.split) * HoWo + pix : o1;
 #pragma unroll
-            for (int pb = 0; pb < PBW; ++pb) {
-                const int oy = g.oy0 + 2 * (PBW * wave + pb) + (r >> 4), ox = g.ox0 + (r & 15);
-                const bool inside = oy < a.Ho && ox < a.Wo;
-                const long pix = inside ? (long)oy * a.Wo + ox : 0;
-                float *o1 = a.out + ((long)g.b * a.out_ctotal + a.out_coff) * HoWo + pix;
-                float *o2 = a.out2 ? a.out2 + ((long)g.b * a.out2_ctotal + a.out2_coff - a.split) * HoWo + pix : o1;
+            for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                        float v = acc[pb][cb][e] + a.b[co < a.Cout ? co : 0];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (inside && co < a.Cout) (co < a.split ? o1 : o2)[co * HoWo] = v;
-                        acc[pb][cb][e] = 0.f;
-                    }
-            }
+                for (int e = 0; e < 16; ++e) {
+                    const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    float v = acc[cb][e] + a.b[co < a.Cout ? co : 0];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (inside && co < a.Cout && (!(FRT_C3H_ABL & 8) || v == 12345.678f)) (co < a.split ? o1 : o2)[co * HoWo] = v;
+                    acc[cb][e] = 0.f;
+                }
         }
         if (!v1) break;
-        store_patch(pbuf + s1.pc * PATCH_H);  // the other patch buffer: its readers finished a step ago
-        __syncthreads();                      // everybody is done with this step's weights
-        store_weights();
-        __syncthreads();
+        if (!(FRT_C3H_ABL & 2)) store_patch(pbuf + s1.pc * PATCH_H);  // the other patch buffer: its readers finished a step ago
+        if (new_w) {
+            if (!(FRT_C3H_ABL & 16)) __syncthreads();                  // everybody is done with this step's weights
+            if (!(FRT_C3H_ABL & 4)) store_weights();
+        }
+        if (!(FRT_C3H_ABL & 16)) __syncthreads();
         s0 = s1;
         s1 = advance(s1);
     }
 }
 
+template <int NCH, int NCB>
+void launch_split(const Conv3H &mm, int total, hipStream_t s) {
+    const size_t lds = (size_t)(2 * PATCH_H + 9 * 32 * NCB * ROWH) * sizeof(half_t);  // 74.9 KB / 51.8 KB: two workgroups per CU
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_split_kernel<NCH, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    int grid = 512;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL((conv3x3_split_kernel<NCH, NCB>), dim3(grid), dim3(256), lds, s, mm);
+}
+
 }  // namespace
 
-// Up to 3 same-shaped stride-1 problems with Cin == 64 in one launch.  false: shape not covered / split weights absent.
+// Up to 3 same-shaped stride-1 problems with Cin == 64 or 16 in one launch.  false: shape not covered / split weights absent.
 bool launch_conv3x3_split(const Conv3Args *a, int n, hipStream_t s) {
     static const bool off = frt_tuning_env("FRT_DET_SPLIT") && frt_tuning_env("FRT_DET_SPLIT")[0] == '0';
     if (off || n < 1 || n > 3) return false;
-    static const int pbw = frt_tuning_env("FRT_DET_SPLIT_PBW") ? atoi(frt_tuning_env("FRT_DET_SPLIT_PBW")) : 1;
-    const int th = 8 * pbw;
     Conv3H mm;
     int base = 0;
     for (int i = 0; i < 3; ++i) {
         const Conv3Args &p = a[i < n ? i : 0];
-        if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo || p.Cin != 64 || p.Cout != a[0].Cout || p.Cout > 64 || p.Cout < 16 || !p.wh) return false;
+        if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo || (p.Cin != 64 && p.Cin != 16) || p.Cin != a[0].Cin || p.Cout != a[0].Cout || p.Cout > 64 || p.Cout < 16 || !p.wh)
+            return false;
         mm.p[i] = p;
         if (!mm.p[i].out2) mm.p[i].split = p.Cout;
         mm.tiles_x[i] = (p.Wo + TS - 1) / TS;
-        mm.tiles_y[i] = (p.Ho + th - 1) / th;
+        mm.tiles_y[i] = (p.Ho + TH - 1) / TH;
         mm.base[i] = base;
         if (i < n) base += p.B * mm.tiles_x[i] * mm.tiles_y[i];
     }
     for (int i = n; i < 4; ++i) mm.base[i] = base;
-    const size_t lds = (size_t)(2 * (th + 2) * PS * ROWH + WCH_H) * sizeof(half_t);  // 75 KB (two workgroups per CU) / 98 KB
-    static bool attr_done[FRT_MAX_DEVICES] = {};
-    if (frt_first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    if (base < 1) return true;
+    const bool one = a[0].Cout <= 32;
+    if (a[0].Cin == 64) {
+        if (one) launch_split<4, 1>(mm, base, s);
+        else launch_split<4, 2>(mm, base, s);
+    } else {
+        if (one) launch_split<1, 1>(mm, base, s);
+        else launch_split<1, 2>(mm, base, s);
     }
-    int grid = pbw == 1 ? 512 : 256;
-    if (grid > base) grid = base;
-    if (pbw == 1) hipLaunchKernelGGL(conv3x3_split_kernel<1>, dim3(grid), dim3(256), lds, s, mm);
-    else hipLaunchKernelGGL(conv3x3_split_kernel<2>, dim3(grid), dim3(256), lds, s, mm);
     return true;
 }

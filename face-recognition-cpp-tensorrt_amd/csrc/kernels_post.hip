@@ -26,13 +26,25 @@ __device__ __forceinline__ int clipi(int v, int lo, int hi) {
     return t > lo ? t : lo;
 }
 
-__global__ void decode_kernel(const float *__restrict__ loc, const float *__restrict__ conf, DetGeom g, Candidate *__restrict__ cand,
-                              int *__restrict__ cand_count) {
+// One thread per (frame, anchor).  The candidate list of a frame is an unordered set (the NMS picks by (score, anchor index), never by list
+// position), so the compaction only has to be dense: a WAVE counts its candidates with one ballot, its first lane reserves that many slots
+// with ONE atomic (round 5: one atomic per candidate serialised thousands of them per frame on a single counter - 27 us per 32 frames for
+// 13 MB of head outputs), and every candidate takes the slot at its rank among the wave's candidates.
+__global__ __launch_bounds__(256) void decode_kernel(const float *__restrict__ loc, const float *__restrict__ conf, DetGeom g, Candidate *__restrict__ cand,
+                                                     int *__restrict__ cand_count) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
-    if (a >= g.A) return;
-    const float score = conf[((long)f * g.A + a) * 2 + 1];
-    if (!(score > g.bbox_thr)) return;
+    const bool in_range = a < g.A;
+    const float score = in_range ? conf[((long)f * g.A + a) * 2 + 1] : 0.f;
+    const bool take = in_range && (score > g.bbox_thr);
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0ull) return;  // (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cand_count[f], __popcll(mask));
+    base = __shfl(base, 0);
+    if (!take) return;
+    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
 
     const int k = a >= g.base[2] ? 2 : (a >= g.base[1] ? 1 : 0);
     const int rel = a - g.base[k];
@@ -47,7 +59,7 @@ __global__ void decode_kernel(const float *__restrict__ loc, const float *__rest
     const float acx = (float)((j + 0.5) * step / w);
     const float acy = (float)((i + 0.5) * step / h);
 
-    const float *bb = loc + ((long)f * g.A + a) * 4;
+    const floatx4 bb = *reinterpret_cast<const floatx4 *>(loc + ((long)f * g.A + a) * 4);
     const float l0 = bb[0], l1 = bb[1], l2 = bb[2], l3 = bb[3];
     // decode (retinaface.cpp:166-169): double intermediates, float fields
     const float cx = (float)(acx + l0 * 0.1 * asx);
@@ -77,7 +89,6 @@ __global__ void decode_kernel(const float *__restrict__ loc, const float *__rest
     r.x2 = clipi(r.x2, 0, g.frame_h - 1);
     r.score = score;
 
-    const int pos = atomicAdd(&cand_count[f], 1);
     Candidate c;
     c.box = r;
     c.anchor = a;
