@@ -154,11 +154,7 @@ __global__ __launch_bounds__(256) void dwpw_kernel(DwPwArgs a) {
 // NS = slots of the input prefetch ring (NS - 1 channels in flight ahead of the one being consumed): at 176-240 registers only two
 // waves fit a SIMD, so the bytes in flight per CU come from the ring depth (one channel ahead = 37 KB per CU: 2.3 TB/s on the 8 -> 16
 // block at 320x320).
-// DPPN (round 5): the two neighbour pixels of a thread's four - the last pixel of the thread to the left, the first of the thread to the right -
-// are taken from those threads' registers (v_mov_b32_dpp wave_shr:1 / wave_shl:1) instead of being loaded: six of a channel's nine load
-// instructions disappear from the texture path (only lanes 0 and 63, whose neighbours live in another wave, still load theirs).  Same values,
-// same arithmetic: bit-identical.
-template <int CT, int NS = 2, bool DPPN = false>
+template <int CT, int NS = 2>
 __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
     constexpr int REC = 12 + CT;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -198,21 +194,14 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
         for (int c = 0; c < CT; ++c) acc[q][c] = 0.f;
 
     floatx4 mid[NS][3];
-    float lft[NS][3], rgt[NS][3];  // (DPPN: lft holds the one edge value of lanes 0 / 63, rgt is unused)
-    const int lane = threadIdx.x & 63;
-    const bool edge_lane = lane == 0 || lane == 63;
-    const int eoff = lane == 0 ? loff : roff_r;
+    float lft[NS][3], rgt[NS][3];
     auto fetch = [&](int ci, int slot) {
         const float *x = inb + (long)ci * HW;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             mid[slot][kh] = *reinterpret_cast<const floatx4 *>(x + roff[kh]);
-            if constexpr (DPPN) {
-                lft[slot][kh] = edge_lane ? x[roff[kh] + eoff] : 0.f;
-            } else {
-                lft[slot][kh] = x[roff[kh] + loff];
-                rgt[slot][kh] = x[roff[kh] + roff_r];
-            }
+            lft[slot][kh] = x[roff[kh] + loff];
+            rgt[slot][kh] = x[roff[kh] + roff_r];
         }
     };
 #pragma unroll
@@ -232,15 +221,6 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
             float v[3][6];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                if constexpr (DPPN) {
-                    // lane i - 1's last pixel / lane i + 1's first pixel (of the SAME input row kh: neighbouring threads of an image row share oh)
-                    const int fl = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mid[half][kh][3]), 0x138, 0xf, 0xf, false);  // wave_shr:1
-                    const int fr = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mid[half][kh][0]), 0x130, 0xf, 0xf, false);  // wave_shl:1
-                    const float nl = lane == 0 ? lft[half][kh] : __builtin_bit_cast(float, fl);
-                    const float nr = lane == 63 ? lft[half][kh] : __builtin_bit_cast(float, fr);
-                    lft[half][kh] = nl;
-                    rgt[half][kh] = nr;
-                }
                 v[kh][0] = lok ? lft[half][kh] * rmask[kh] : 0.f;
                 v[kh][1] = mid[half][kh][0] * rmask[kh];
                 v[kh][2] = mid[half][kh][1] * rmask[kh];
@@ -704,20 +684,7 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
         if (a.Cout == 16 && ns16 == 4) hipLaunchKernelGGL((dwpw_row4_kernel<16, 4>), grid, dim3(256), lds, s, a);
         else if (a.Cout == 16 && ns16 == 3) hipLaunchKernelGGL((dwpw_row4_kernel<16, 3>), grid, dim3(256), lds, s, a);
         else if (a.Cout == 16) hipLaunchKernelGGL((dwpw_row4_kernel<16, 2>), grid, dim3(256), lds, s, a);
-        else {
-            // tuning build: the 32 -> 32 block as two 16-channel tiles over grid.y (depthwise part recomputed per tile) with 1 / 2 / 3 channels in flight
-            static const int r32 = frt_tuning_env("FRT_ROW4_32") ? atoi(frt_tuning_env("FRT_ROW4_32")) : 0;
-            const dim3 grid2(grid.x, 2);
-            const size_t lds16 = (size_t)a.Cin * (12 + 16) * sizeof(float);
-            if (r32 == 1) hipLaunchKernelGGL((dwpw_row4_kernel<16, 2>), grid2, dim3(256), lds16, s, a);
-            else if (r32 == 2) hipLaunchKernelGGL((dwpw_row4_kernel<16, 3>), grid2, dim3(256), lds16, s, a);
-            else if (r32 == 3) hipLaunchKernelGGL((dwpw_row4_kernel<16, 4>), grid2, dim3(256), lds16, s, a);
-            else {
-                static const bool dppn = !(frt_tuning_env("FRT_ROW4_DPP") && frt_tuning_env("FRT_ROW4_DPP")[0] == '0');
-                if (dppn) hipLaunchKernelGGL((dwpw_row4_kernel<32, 2, true>), grid, dim3(256), lds, s, a);
-                else hipLaunchKernelGGL((dwpw_row4_kernel<32, 2>), grid, dim3(256), lds, s, a);
-            }
-        }
+        else hipLaunchKernelGGL((dwpw_row4_kernel<32, 2>), grid, dim3(256), lds, s, a);
         return;
     }
     // fused while one channel tile covers every output channel (no depthwise recompute) ...
@@ -747,7 +714,7 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
 }
 
 void launch_conv3x3_multi(const Conv3Args *a, int n, hipStream_t s) {
-    if (det_mfma_enabled() && launch_conv3x3_split(a, n, s)) return;  // fp16 hi/lo split on the fp16 matrix cores (kernels_det_conv3h.hip): 64 and 16 input channels
+    if (det_mfma_enabled() && launch_conv3x3_split(a, n, s)) return;  // fp16 hi/lo split on the fp16 matrix cores (kernels_det_conv3h.hip)
     if (det_mfma_enabled() && launch_conv3x3_mfma(a, n, s)) return;  // fp32 matrix-core kernel (kernels_det_mfma.hip)
     Conv3Multi mm;
     long max_total = 0;
