@@ -278,6 +278,8 @@ def main():
                                                                  "keeps this many of its small batches in the stage pipeline at once")
     ap.add_argument("--sharded-gallery", action="store_true",
                     help="BASELINE configs[4]: gallery row-sharded over the ranks and stored as fp16; RCCL all-gather of embeddings and of the top-1 winners")
+    ap.add_argument("--fp32", action="store_true", help="recogniser in fp32 end to end (frt_embedder_set_precision(e, 1)): BASELINE configs[1]'s \"fp32\" "
+                                                        "(with --batch 1 --gallery 10000); the metric's own configuration stays fp16 MFMA")
     ap.add_argument("--exact-match", action="store_true", help="match stage = the exact fp32 scan of the whole gallery on every call "
                                                                "(frt_matcher_set_screening(m, 0): SURVEY 8(d)'s 2.048 GB per call) instead of the screened top-1")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step RCCL all-gather of the result records")
@@ -351,6 +353,8 @@ def main():
     rec_path = frt.write_weights(os.path.join(tmp, "rec.frtw"), rec_sd, 2 if args.mode == "ir" else 3)
     det = frt.RetinaFace(det_path, FW, FH, (3, H, W), B, K, 0.4, 0.6, device=local_rank)
     rec = frt.ArcFaceIR50(rec_path, FW, FH, (3, 112, 112), 512, F, K, 0.65, device=local_rank)
+    if args.fp32:
+        rec.setPrecision(True)
     gallery = s.make_gallery(args.gallery)
     t_load = time.perf_counter()
     if args.sharded_gallery:
@@ -910,7 +914,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
-            "dtype": "f16 MFMA recogniser convs (fp32 accumulate) + fp32-accurate detector (fp32 MFMA, fp16 hi/lo-split MFMA for the 64-channel 3x3 convs) + "
+            "dtype": ("f32 recogniser end to end (fp32 activations / weights, exact fp32 MFMA products)" if args.fp32 else "f16 MFMA recogniser convs (fp32 accumulate)") + " + fp32-accurate detector (fp32 MFMA, fp16 hi/lo-split MFMA for the 64-channel 3x3 convs) + "
                      + {"exact": "exact f32 MFMA match (full scan of the stored rows)",
                         "fp16": "fp16-screened coarse scan (fp16 MFMA) + exact f32 re-rank match (bit-identical to the exact f32 scan)",
                         "int8": "int8-screened coarse scan (fp16 MFMA on exactly widened int8 rows) + exact f32 re-rank match (bit-identical to the exact f32 scan)"}[scan_mode],

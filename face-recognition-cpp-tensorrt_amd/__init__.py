@@ -97,6 +97,7 @@ ABI = {
     "frt_comm_all_gather_multi": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
     "frt_comm_sync": (_i, [_vp]),
     "frt_embedder_set_se_fused": (_i, [_vp, _i]),
+    "frt_embedder_set_precision": (_i, [_vp, _i]),
     "frt_jpeg_encode_batch_after": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "frt_detector_geometry": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "frt_coalescer_create": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(_vp)]),
@@ -487,6 +488,11 @@ class ArcFaceIR50:
         self.classCount = 0
         self._known = None
         self._embeds = np.zeros((0, self.outputDim), np.float32)
+
+    def setPrecision(self, fp32):
+        """``True``: fp32 activations / weights / products end to end (BASELINE configs[1]'s "fp32"; slow, a few faces per call);
+        ``False`` (default): fp16 on the matrix cores with fp32 accumulation."""
+        _check(lib.frt_embedder_set_precision(self._h, 1 if fp32 else 0))
 
     def setSeFused(self, enable):
         """IR-SE only: SE tail inside conv2's epilogue (default) or as stand-alone launches (equal to float rounding)."""

@@ -664,7 +664,7 @@ void frt_detector::postprocess(int n, hipStream_t s, frt_bbox *boxes_out, int *n
     frt_bbox *bo = boxes_out ? boxes_out : d_boxes;  // the pipeline passes its slot buffers: no device-to-device copies afterwards
     int *no = nout_out ? nout_out : d_nout;
     launch_decode(d_loc, d_conf, n, g, d_cand, d_cand_count, s);
-    launch_nms(d_cand, d_cand_count, n, g, d_dead, bo, no, d_kept_anchor, s);
+    launch_nms(d_cand, d_loc, d_cand_count, n, g, d_dead, bo, no, d_kept_anchor, s);
     if (has_landmarks) launch_landmark_decode(d_ldm, d_kept_anchor, no, n, g, landmarks_out ? landmarks_out : d_landmarks, s);
     HIPCHK(hipGetLastError());
 }
@@ -679,6 +679,7 @@ struct ArcUnit {
     half_t *w2f2 = nullptr;                 // ... for the stride-2 strip kernel (conv2 of the first unit of a stage)
     half_t *wscf = nullptr;                 // 1x1 shortcut weights in fragment order (the stride-2 strip kernel computes the shortcut conv itself)
     float *prelu = nullptr, *s2 = nullptr, *b2 = nullptr, *ssc = nullptr, *bsc = nullptr;
+    float *s2f32 = nullptr;              // closing BatchNorm's scale WITHOUT the load-time conditioning factor (the fp32 path multiplies the blob's own weights)
     float *sn = nullptr, *bn = nullptr;  // BatchNorm that consumes this unit's output (next unit's leading BN / output_layer.0)
     float *se_w1 = nullptr, *se_w2 = nullptr;
 };
@@ -728,6 +729,25 @@ struct frt_embedder {
     static constexpr int FC_SPLITS = 49;
     double flops_per_face = 0;
 
+    // ---- fp32 end-to-end mode (frt_embedder_set_precision(e, 1); kernels_arc_f32.hip): its own weights and activation buffers, built on
+    //      first use from the blob the object was created from
+    struct F32Unit {
+        float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // [Cout][tap][Cin] fp32
+    };
+    struct F32 {
+        std::vector<void *> owned;   // device allocations of this mode
+        std::vector<F32Unit> units;
+        float *wfc = nullptr;        // [512][hw * 512 + c]
+        float *A[2] = {nullptr, nullptr}, *T = nullptr, *SCb = nullptr, *RES = nullptr, *gate = nullptr, *fc_out = nullptr;
+        int chunk = 0;               // faces per pass of this path
+        hipEvent_t done = nullptr;   // end of the last pass: one activation set, so passes on different streams run one after the other
+        bool busy = false;
+    } f32;
+    bool fp32_mode = false;
+    std::string blob_path;
+    void build_f32();
+    void forward_f32(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s);
+
     void build(const frt::Blob &b);
     // chw_dev [F][3][112][112] -> out_dev [F][512]; F <= max_batch
     void forward(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s);
@@ -758,22 +778,23 @@ struct frt_embedder {
 
 namespace {
 
-std::vector<uint16_t> conv_w_f16(const frt::Blob &b, const std::string &name, int cout, int cin, int ks) {
+std::vector<uint16_t> conv_w_f16(const float *src, int cout, int cin, int ks) {
     // [Cout][Cin][kh][kw] fp32 -> [Cout][kh][kw][Cin] fp16 (K index = tap*Cin + ci)
-    const float *src = b.get(name, (size_t)cout * cin * ks * ks).data;
     std::vector<uint16_t> w((size_t)cout * cin * ks * ks);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < ks * ks; ++t) w[((size_t)co * ks * ks + t) * cin + ci] = frt::f32_to_f16(src[((size_t)co * cin + ci) * ks * ks + t]);
     return w;
 }
+std::vector<uint16_t> conv_w_f16(const frt::Blob &b, const std::string &name, int cout, int cin, int ks) {
+    return conv_w_f16(b.get(name, (size_t)cout * cin * ks * ks).data, cout, cin, ks);
+}
 // 3x3 weights in the order the strip kernel's MFMA A fragments consume them: [Cout/32][Cin/64][tap][kk][lane = (k half, cout row)][8]
 // (kernels_arc.hip: conv_patch_kernel); a wave's load of one fragment is then one contiguous kilobyte.  Empty unless Cin % 64 == 0.
 // stride2: taps in the step order of the stride-2 strip kernel (kernels_arc_s2.hip: phase planes (odd,odd) (even,even) (odd,even) (even,odd)).
-std::vector<uint16_t> conv_w_f16_frag(const frt::Blob &b, const std::string &name, int cout, int cin, bool stride2 = false) {
+std::vector<uint16_t> conv_w_f16_frag(const float *src, int cout, int cin, bool stride2 = false) {
     if (cin % 64 || cout % 32) return {};
     static const int s2_step_of_tap[9] = {0, 5, 1, 7, 4, 8, 2, 6, 3};  // inverse of the step -> tap table 0,2,6,8,4,1,7,3,5
-    const float *src = b.get(name, (size_t)cout * cin * 9).data;
     std::vector<uint16_t> w((size_t)cout * cin * 9);
     const int nch = cin / 64;
     for (int co = 0; co < cout; ++co)
@@ -832,6 +853,7 @@ void frt_embedder::build(const frt::Blob &b) {
     }
     // units (model_irse.py:97-109 for IR-50)
     const int cfg[4][3] = {{64, 64, 3}, {64, 128, 4}, {128, 256, 14}, {256, 512, 3}};
+    const bool condition = !(frt_tuning_env("FRT_ARC_CONDITION") && frt_tuning_env("FRT_ARC_CONDITION")[0] == '0');  // (tuning build: the sweep's "off" leg)
     int h = 112, idx = 0;
     for (int st = 0; st < 4; ++st)
         for (int u = 0; u < cfg[st][2]; ++u) {
@@ -841,17 +863,60 @@ void frt_embedder::build(const frt::Blob &b) {
             a.stride = u == 0 ? 2 : 1;
             a.h_in = h;
             const std::string p = "body." + std::to_string(idx);
-            a.w1 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".res_layer.1.weight", a.depth, a.cin, 3)));
+            // Conditioning of the branch conv1 -> PReLU -> conv2 -> BN (round 5; model_irse.py:57-66).  conv1's accumulators leave as the fp16
+            // tensor T and both convs multiply fp16 weights: a trained backbone (conversion/arcface/torch2trt.py:21-22 loads one nobody here
+            // has seen) may keep that branch orders of magnitude away from 1 - tools/dynamic_range_sweep.py: a branch 1e-4 times smaller pushes
+            // T and conv1's weights into fp16's subnormals and conv2's towards its overflow, SILENTLY (1 - cos 4.8e-4).  PReLU is positively
+            // homogeneous, so for powers of two c_j, d_k > 0 the unit computes exactly the same function with
+            //     conv1 row j * c_j      conv2 column j / c_j, row k * d_k      BN scale k / d_k        (every scaling exact in binary fp)
+            // c_j brings conv1's row norm to ~ 1 (T = O(1) behind a normalised input), d_k conv2's largest row entry into [0.5, 1).  A branch
+            // that is in range already is left bit for bit as it was (the scalings commute with every rounding).
+            std::vector<float> w1v = vec_of(b, p + ".res_layer.1.weight", (size_t)a.depth * a.cin * 9);
+            std::vector<float> w2v = vec_of(b, p + ".res_layer.3.weight", (size_t)a.depth * a.depth * 9);
+            std::vector<float> dinv(a.depth, 1.f);
+            if (condition) {
+                auto pow2_inv = [](double v) {  // 2^-round(log2 v), clamped; 1 for zero / non-finite rows
+                    if (!(v > 0.0) || !std::isfinite(v)) return 1.0;
+                    const double e = std::max(-60.0, std::min(60.0, -std::nearbyint(std::log2(v))));
+                    return std::exp2(e);
+                };
+                for (int j = 0; j < a.depth; ++j) {
+                    double n2 = 0.0;
+                    float *row = &w1v[(size_t)j * a.cin * 9];
+                    for (int i = 0; i < a.cin * 9; ++i) n2 += (double)row[i] * row[i];
+                    const double c = pow2_inv(std::sqrt(n2));
+                    if (c == 1.0) continue;
+                    for (int i = 0; i < a.cin * 9; ++i) row[i] = (float)(row[i] * c);
+                    for (int k = 0; k < a.depth; ++k)
+                        for (int t = 0; t < 9; ++t) {
+                            float &v = w2v[((size_t)k * a.depth + j) * 9 + t];
+                            v = (float)(v / c);
+                        }
+                }
+                for (int k = 0; k < a.depth; ++k) {
+                    double mx = 0.0;
+                    float *row = &w2v[(size_t)k * a.depth * 9];
+                    for (int i = 0; i < a.depth * 9; ++i) mx = std::max(mx, (double)std::fabs(row[i]));
+                    double d = 1.0;
+                    if (mx > 0.0 && std::isfinite(mx) && (mx >= 2.0 || mx < 0.03125)) d = std::exp2(std::max(-60.0, std::min(60.0, -std::ceil(std::log2(mx)))));
+                    if (d == 1.0) continue;   // (entries already inside [2^-5, 2): nothing to gain, keep the trained numbers as they are)
+                    for (int i = 0; i < a.depth * 9; ++i) row[i] = (float)(row[i] * d);
+                    dinv[k] = (float)(1.0 / d);
+                }
+            }
+            a.w1 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(w1v.data(), a.depth, a.cin, 3)));
             {  // conv1 is always stride 1; conv2 only in the units that keep the resolution
-                const std::vector<uint16_t> f1 = conv_w_f16_frag(b, p + ".res_layer.1.weight", a.depth, a.cin);
+                const std::vector<uint16_t> f1 = conv_w_f16_frag(w1v.data(), a.depth, a.cin);
                 if (!f1.empty()) a.w1f = reinterpret_cast<half_t *>(arena.upload(f1));
                 // the 64 -> 64 stride-2 layer has its own kernel that stages rows in natural order and walks the taps in tap order
-                const std::vector<uint16_t> f2 = conv_w_f16_frag(b, p + ".res_layer.3.weight", a.depth, a.depth, a.stride == 2 && a.depth != 64);
+                const std::vector<uint16_t> f2 = conv_w_f16_frag(w2v.data(), a.depth, a.depth, a.stride == 2 && a.depth != 64);
                 if (!f2.empty()) (a.stride == 1 ? a.w2f : a.w2f2) = reinterpret_cast<half_t *>(arena.upload(f2));
             }
             a.prelu = arena.upload(vec_of(b, p + ".res_layer.2.weight", a.depth));
-            a.w2 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(b, p + ".res_layer.3.weight", a.depth, a.depth, 3)));
+            a.w2 = reinterpret_cast<half_t *>(arena.upload(conv_w_f16(w2v.data(), a.depth, a.depth, 3)));
             frt::bn_fold(b, p + ".res_layer.4", a.depth, sc, bi);
+            a.s2f32 = arena.upload(sc);   // (the fp32 path multiplies the blob's own weights: the unconditioned scale)
+            for (int k = 0; k < a.depth; ++k) sc[k] *= dinv[k];
             a.s2 = arena.upload(sc);
             a.b2 = arena.upload(bi);
             if (a.cin != a.depth) {
@@ -952,7 +1017,118 @@ void frt_embedder::ensure_alt() {
     has_alt = true;
 }
 
+// fp32 weights: 3x3 [Cout][Cin][3][3] -> [Cout][tap][Cin]; 1x1 and Linear as described at the kernels
+void frt_embedder::build_f32() {
+    if (!f32.units.empty()) return;
+    frt::Blob b;
+    std::string err;
+    const int rc = b.load(blob_path.c_str(), err);
+    if (rc) raise(rc, "fp32 mode: cannot re-read the weight blob: " + err);
+    auto up = [&](const std::vector<float> &v) {
+        float *d = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), v.size() * sizeof(float)));
+        f32.owned.push_back(d);
+        HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return d;
+    };
+    auto dev = [&](size_t n) {
+        float *d = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(float)));
+        f32.owned.push_back(d);
+        return d;
+    };
+    auto w3 = [&](const std::string &name, int cout, int cin) {
+        const float *src = b.get(name, (size_t)cout * cin * 9).data;
+        std::vector<float> w((size_t)cout * cin * 9);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < 9; ++t) w[((size_t)co * 9 + t) * cin + ci] = src[((size_t)co * cin + ci) * 9 + t];
+        return up(w);
+    };
+    int idx = 0;
+    for (const ArcUnit &u : units) {
+        const std::string p = "body." + std::to_string(idx++);
+        F32Unit fu;
+        fu.w1 = w3(p + ".res_layer.1.weight", u.depth, u.cin);
+        fu.w2 = w3(p + ".res_layer.3.weight", u.depth, u.depth);
+        if (u.wsc) fu.wsc = up(vec_of(b, p + ".shortcut_layer.0.weight", (size_t)u.depth * u.cin));
+        f32.units.push_back(fu);
+    }
+    {
+        const float *src = b.get("output_layer.3.weight", (size_t)512 * 25088).data;
+        std::vector<float> w((size_t)512 * 25088);
+        for (int o = 0; o < 512; ++o)
+            for (int c = 0; c < 512; ++c)
+                for (int hw = 0; hw < 49; ++hw) w[(size_t)o * 25088 + (size_t)hw * 512 + c] = src[(size_t)o * 25088 + (size_t)c * 49 + hw];
+        f32.wfc = up(w);
+    }
+    f32.chunk = std::min(max_batch, 8);
+    const size_t C = (size_t)f32.chunk, big = C * 112 * 112 * 64;
+    f32.A[0] = dev(big);
+    f32.A[1] = dev(big);
+    f32.T = dev(big);
+    f32.SCb = dev(C * 56 * 56 * 128);
+    if (se) {
+        f32.RES = dev(C * 56 * 56 * 64);
+        f32.gate = dev(C * 512);
+    }
+    f32.fc_out = dev(C * 512);
+    HIPCHK(hipEventCreateWithFlags(&f32.done, hipEventDisableTiming));
+}
+
+// Backbone.forward in fp32 (model_irse.py:166-173), CHUNK faces at a time.  The per-channel parameters (folded BatchNorms, PReLU slopes, SE
+// weights, Linear bias) are the fp32 arrays the default path's epilogues use.
+void frt_embedder::forward_f32(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s) {
+    ProfScope ps(2, "embed_network", flops_per_face * F, s);
+    if (f32.busy) HIPCHK(hipStreamWaitEvent(s, f32.done, 0));
+    for (int f0 = 0; f0 < F; f0 += f32.chunk) {
+        const int n = std::min(f32.chunk, F - f0);
+        launch_arc32_input(chw_dev + (size_t)f0 * 3 * 112 * 112, in_w, in_s0, in_b0, in_slope, f32.A[0], n, s);
+        int cur = 0;
+        const float *lead_s = in_s1, *lead_b = in_b1;  // the leading BatchNorm of the unit about to run
+        for (size_t i = 0; i < units.size(); ++i) {
+            const ArcUnit &u = units[i];
+            const F32Unit &fu = f32.units[i];
+            const int h = u.h_in, ho = h / u.stride;
+            const float *x = f32.A[cur];
+            // conv1: BN(x) (on load) -> conv3x3 -> PReLU
+            Conv32Args c1{x, fu.w1, lead_s, lead_b, f32.T, n, h, h, u.cin, h, h, u.depth, 3, 1, 1, 0, u.prelu, nullptr, nullptr, 0, 0, 0};
+            launch_conv32(c1, s);
+            // shortcut: MaxPool2d(1, stride) of x, or conv1x1 stride s + BN
+            const float *sc = x;
+            int sc_h = h, sc_stride = u.stride;
+            if (fu.wsc) {
+                Conv32Args cs{x, fu.wsc, nullptr, nullptr, f32.SCb, n, h, h, u.cin, ho, ho, u.depth, 1, u.stride, 0, 1, u.ssc, u.bsc, nullptr, 0, 0, 0};
+                launch_conv32(cs, s);
+                sc = f32.SCb;
+                sc_h = ho;
+                sc_stride = 1;
+            }
+            // conv2: conv3x3 stride s -> BN (-> SE) -> + shortcut
+            float *y = f32.A[cur ^ 1];
+            if (se) {
+                Conv32Args c2{f32.T, fu.w2, nullptr, nullptr, f32.RES, n, h, h, u.depth, ho, ho, u.depth, 3, u.stride, 1, 1, u.s2f32, u.b2, nullptr, 0, 0, 0};
+                launch_conv32(c2, s);
+                launch_se32(f32.RES, u.se_w1, u.se_w2, f32.gate, sc, y, n, ho, ho, u.depth, sc_h, sc_h, sc_stride, s);
+            } else {
+                Conv32Args c2{f32.T, fu.w2, nullptr, nullptr, y, n, h, h, u.depth, ho, ho, u.depth, 3, u.stride, 1, 2, u.s2f32, u.b2, sc, sc_h, sc_h, sc_stride};
+                launch_conv32(c2, s);
+            }
+            lead_s = u.sn;
+            lead_b = u.bn;
+            cur ^= 1;
+        }
+        // output_layer: BN2d (on load) -> Flatten -> Linear -> BN1d -> L2 normalise
+        launch_fc32(f32.A[cur], lead_s, lead_b, f32.wfc, f32.fc_out, n, s);
+        launch_fc_finalize(f32.fc_out, 1, n, fc_bias, bn_s, bn_b, valid_dev ? valid_dev + f0 : nullptr, out_dev + (size_t)f0 * 512, s);
+    }
+    HIPCHK(hipEventRecord(f32.done, s));
+    f32.busy = true;
+    HIPCHK(hipGetLastError());
+}
+
 void frt_embedder::forward(const float *chw_dev, int F, const int *valid_dev, float *out_dev, hipStream_t s) {
+    if (fp32_mode) return forward_f32(chw_dev, F, valid_dev, out_dev, s);
     ProfScope ps(2, "embed_network", flops_per_face * F, s);
     ArcInputArgs ia{chw_dev, in_w, in_s0, in_b0, in_slope, in_s1, in_b1, Y[0], Z[0], F, 112, 112, in_wh};
     launch_arc_input(ia, s);
@@ -2108,6 +2284,7 @@ int frt_embedder_create(const char *weights_path, int in_c, int in_h, int in_w, 
         e->device = device;
         e->max_batch = max_batch;
         e->se = blob.kind == 3;
+        e->blob_path = weights_path;
         HIPCHK(hipStreamCreate(&e->stream));
         HIPCHK(hipEventCreateWithFlags(&e->ev_busy[0], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&e->ev_busy[1], hipEventDisableTiming));
@@ -2125,6 +2302,8 @@ void frt_embedder_destroy(frt_embedder *e) {
         (void)hipStreamDestroy(e->stream);
     }
     if (e->d_frame) (void)hipFree(e->d_frame);
+    for (void *p : e->f32.owned) (void)hipFree(p);
+    if (e->f32.done) (void)hipEventDestroy(e->f32.done);
     if (e->h_se_error) (void)hipHostFree(e->h_se_error);
     for (hipEvent_t ev : e->ev_busy)
         if (ev) (void)hipEventDestroy(ev);
@@ -2137,6 +2316,20 @@ int frt_embedder_set_se_fused(frt_embedder *e, int enable) {
         if (!e) raise(FRT_ERR_INVALID, "null argument");
         std::lock_guard<std::mutex> lk(e->mu);
         e->se_fused = enable != 0;
+    });
+}
+
+int frt_embedder_set_precision(frt_embedder *e, int fp32) {
+    return guarded([&] {
+        if (!e) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(e->mu);
+        use_device(e->device);
+        if (fp32) {
+            HIPCHK(hipStreamSynchronize(e->stream));
+            e->build_f32();
+            HIPCHK(hipDeviceSynchronize());
+        }
+        e->fp32_mode = fp32 != 0;
     });
 }
 

@@ -109,7 +109,7 @@ struct Candidate {
     int32_t anchor;
 };
 void launch_decode(const float *loc, const float *conf, int n_frames, const DetGeom &g, Candidate *cand, int *cand_count, hipStream_t s);
-void launch_nms(const Candidate *cand, int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
+void launch_nms(Candidate *cand, const float *loc, int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
                 int *kept_anchor, hipStream_t s);
 // landmarks of the kept boxes: raw head output ldm [B][A][10] + kept anchors [B][K] -> frame coordinates (x0,y0,...,x4,y4) [B][K][10]
 void launch_landmark_decode(const float *ldm, const int *kept_anchor, const int *n_out, int n_frames, const DetGeom &g, float *out, hipStream_t s);
@@ -249,6 +249,19 @@ bool launch_arc_input_mfma(const ArcInputArgs &a, hipStream_t s);  // kernels_ar
 // [512/32 output blocks][25088/16 k steps][64 lanes][8 halfs] (lane = (output row r, k half hi)), partial [49][F][512] fp32
 void launch_fc_slices(const half_t *z, const half_t *wfrag, int F, float *partial, hipStream_t s);
 // partial [splits][F][512] -> +bias -> BN1d -> L2 normalise -> out [F][512] fp32; rows with valid[f]==0 become zeros.
+// fp32 end-to-end recogniser path (kernels_arc_f32.hip; frt_embedder_set_precision)
+struct Conv32Args {
+    const float *x, *w, *ps, *pb;
+    float *out;
+    int F, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, mode;  // mode 0: PReLU(p0)  1: BN(p0, p1)  2: BN(p0, p1) + shortcut
+    const float *p0, *p1, *sc;
+    int sc_h, sc_w, sc_stride;
+};
+void launch_arc32_input(const float *x, const float *w, const float *s0, const float *b0, const float *slope, float *y, int F, hipStream_t s);
+void launch_conv32(const Conv32Args &c, hipStream_t s);
+void launch_fc32(const float *y, const float *sn, const float *bn, const float *w, float *out, int F, hipStream_t s);
+void launch_se32(const float *res, const float *w1, const float *w2, float *gate, const float *sc, float *out, int F, int Ho, int Wo, int C, int sc_h, int sc_w, int sc_stride,
+                 hipStream_t s);
 void launch_fc_finalize(const float *partial, int splits, int F, const float *bias, const float *s, const float *b, const int *valid,
                         float *out, hipStream_t s_);
 // SE tail (IR-SE): pool -> fc1 -> relu -> fc2 -> sigmoid -> scale, + shortcut, + next BN

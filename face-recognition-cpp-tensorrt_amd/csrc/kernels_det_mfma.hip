@@ -440,12 +440,22 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
         half8 ah[CBW], al[CBW], nah[CBW], nal[CBW];
         // addresses as (uniform 64-bit base) + (32-bit lane offset): the scalar-base form of global_load.  As per-lane 64-bit pointers the
         // compiler kept one register pair per load in flight and the kernel sat at 240 VGPRs = two waves per SIMD
+        // Round 5: ONE uniform base and a RUNNING 32-bit lane offset, advanced by per-lane (opaque) strides.  Written as base + (uniform channel
+        // offset) + lane offset the compiler formed one scalar 64-bit base per load - 128 pairs over the item, 207 scalar spills, and the
+        // spill traffic (v_readlane / v_writelane) WAS the kernel: 1 245 VALU + 620 SALU instructions per 32-pixel item for ~ 300 useful ones
+        // (profiles/r04x_det_pmc.txt), 15 us per item.  The groups are requested in ascending order, so one running offset serves them all.
         const char *xin_c = reinterpret_cast<const char *>(a.in);
-        const unsigned xs_off = (unsigned)((((long)b * a.Cin + 8 * hi) * HW + p) * 4);
+        unsigned st1, st9;  // one channel plane / nine (from channel 16 g + 8 hi + 7 to 16 (g + 1) + 8 hi)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(st1) : "s"(HW * 4));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(st9) : "s"(HW * 36));
+        unsigned xo = (unsigned)((((long)b * a.Cin + 8 * hi) * HW + p) * 4);
         auto load_x = [&](int g, float (&bxv)[8]) {
+            if (g >= ngroups) return;  // (uniform)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                bxv[e] = (ok && g < ngroups) ? *reinterpret_cast<const float *>(xin_c + (size_t)(16 * g + e) * HW * 4 + (size_t)xs_off) : 0.f;
+            for (int e = 0; e < 8; ++e) {
+                bxv[e] = ok ? *reinterpret_cast<const float *>(xin_c + (size_t)xo) : 0.f;
+                xo += e == 7 ? st9 : st1;
+            }
         };
         auto load_w = [&](int g, half8 (&dh)[CBW], half8 (&dl)[CBW]) {
 #pragma unroll
@@ -542,8 +552,14 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
     char *out_c = reinterpret_cast<char *>(a.out);
     const char *add_c = reinterpret_cast<const char *>(a.add), *bp_c = reinterpret_cast<const char *>(a.bp);
     const int co_l = co_base + 4 * hi;  // this lane's first channel; + cb * 32 + (e & 3) + 8 * (e >> 2)
-    const unsigned out_off = (unsigned)((((long)b * a.Cout + co_l) * HW + p) * 4);
-    const unsigned add_off = addb ? (unsigned)(((addb - a.add) + (long)co_l * add_cs) * 4) : 0u;
+    // running lane offsets (see load_x): channel steps of the epilogue's enumeration are +1, +1, +1, +5 planes
+    unsigned oo = (unsigned)((((long)b * a.Cout + co_l) * HW + p) * 4);
+    unsigned ao = addb ? (unsigned)(((addb - a.add) + (long)co_l * add_cs) * 4) : 0u;
+    unsigned os1, os5, as1, as5;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(os1) : "s"(HW * 4));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(os5) : "s"(HW * 20));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(as1) : "s"((int)add_cs * 4));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(as5) : "s"((int)add_cs * 20));
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) {  // (one 32-channel block at a time: 32 live values instead of 64)
         float bias_v[16], add_v[16];
@@ -552,7 +568,8 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
             const int cu = cb * 32 + (e & 3) + 8 * (e >> 2);  // uniform part of the channel
             const bool cok = co_l + cu < a.Cout;
             bias_v[e] = cok ? *reinterpret_cast<const float *>(bp_c + (size_t)cu * 4 + (size_t)(unsigned)(co_l * 4)) : 0.f;
-            add_v[e] = (cok && addb) ? *reinterpret_cast<const float *>(add_c + (size_t)cu * add_cs * 4 + (size_t)add_off) : 0.f;
+            add_v[e] = (cok && addb) ? *reinterpret_cast<const float *>(add_c + (size_t)ao) : 0.f;
+            ao += (e & 3) == 3 ? as5 : as1;
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -561,8 +578,9 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_grou
                 float v = acc[cb][e] + bias_v[e];
                 if (a.relu) v = fmaxf(v, 0.f);
                 if (addb) v += add_v[e];
-                *reinterpret_cast<float *>(out_c + (size_t)cu * HW * 4 + (size_t)out_off) = v;
+                *reinterpret_cast<float *>(out_c + (size_t)oo) = v;
             }
+            oo += (e & 3) == 3 ? os5 : os1;
         }
     }
     }  // persistent item loop

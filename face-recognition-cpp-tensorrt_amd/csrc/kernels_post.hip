@@ -26,26 +26,8 @@ __device__ __forceinline__ int clipi(int v, int lo, int hi) {
     return t > lo ? t : lo;
 }
 
-// One thread per (frame, anchor).  The candidate list of a frame is an unordered set (the NMS picks by (score, anchor index), never by list
-// position), so the compaction only has to be dense: a WAVE counts its candidates with one ballot, its first lane reserves that many slots
-// with ONE atomic (round 5: one atomic per candidate serialised thousands of them per frame on a single counter - 27 us per 32 frames for
-// 13 MB of head outputs), and every candidate takes the slot at its rank among the wave's candidates.
-__global__ __launch_bounds__(256) void decode_kernel(const float *__restrict__ loc, const float *__restrict__ conf, DetGeom g, Candidate *__restrict__ cand,
-                                                     int *__restrict__ cand_count) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = blockIdx.y;
-    const bool in_range = a < g.A;
-    const float score = in_range ? conf[((long)f * g.A + a) * 2 + 1] : 0.f;
-    const bool take = in_range && (score > g.bbox_thr);
-    const unsigned long long mask = __ballot(take);
-    if (mask == 0ull) return;  // (wave-uniform)
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&cand_count[f], __popcll(mask));
-    base = __shfl(base, 0);
-    if (!take) return;
-    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-
+// Decode of ONE anchor (retinaface.cpp:161-187, 225-236): priors, box decode, corner truncation, un-letterbox, clip.
+__device__ __forceinline__ frt_bbox decode_box(const DetGeom &g, int a, const float *__restrict__ loc_f, float score) {
     const int k = a >= g.base[2] ? 2 : (a >= g.base[1] ? 1 : 0);
     const int rel = a - g.base[k];
     const int l = rel & 1, cell = rel >> 1;
@@ -59,7 +41,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const float *__restrict__ l
     const float acx = (float)((j + 0.5) * step / w);
     const float acy = (float)((i + 0.5) * step / h);
 
-    const floatx4 bb = *reinterpret_cast<const floatx4 *>(loc + ((long)f * g.A + a) * 4);
+    const floatx4 bb = *reinterpret_cast<const floatx4 *>(loc_f + (long)a * 4);
     const float l0 = bb[0], l1 = bb[1], l2 = bb[2], l3 = bb[3];
     // decode (retinaface.cpp:166-169): double intermediates, float fields
     const float cx = (float)(acx + l0 * 0.1 * asx);
@@ -88,20 +70,43 @@ __global__ __launch_bounds__(256) void decode_kernel(const float *__restrict__ l
     r.y2 = clipi(r.y2, 0, g.frame_w - 1);
     r.x2 = clipi(r.x2, 0, g.frame_h - 1);
     r.score = score;
+    return r;
+}
 
+// Threshold + compaction: one thread per (frame, anchor).  The candidate list of a frame is an unordered set (the NMS picks by (score, anchor
+// index), never by list position), so the compaction only has to be dense: a WAVE counts its candidates with one ballot, its first lane
+// reserves that many slots with ONE atomic and every candidate takes the slot at its rank among the wave's candidates.  Round 5: this kernel
+// only records (anchor, score); the box arithmetic - two double-precision exp and four double divisions per candidate - runs in nms_kernel on
+// the DENSE list.  Here it ran under the threshold branch with ~ 1 % of the lanes alive: every wave that held a single candidate walked the
+// whole double-precision path (27 us per 32 frames for ~ 5 000 candidates; the compaction atomics were never the cost).
+__global__ __launch_bounds__(256) void decode_kernel(const float *__restrict__ conf, DetGeom g, Candidate *__restrict__ cand, int *__restrict__ cand_count) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const bool in_range = a < g.A;
+    const float score = in_range ? conf[((long)f * g.A + a) * 2 + 1] : 0.f;
+    const bool take = in_range && (score > g.bbox_thr);
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0ull) return;  // (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cand_count[f], __popcll(mask));
+    base = __shfl(base, 0);
+    if (!take) return;
+    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
     Candidate c;
-    c.box = r;
+    c.box.x1 = c.box.y1 = c.box.x2 = c.box.y2 = 0;
+    c.box.score = score;
     c.anchor = a;
     cand[(long)f * g.A + pos] = c;
 }
 
 __device__ __forceinline__ bool cand_better(float s, int a, float bs, int ba) { return (s > bs) || (s == bs && a < ba); }
 
-__global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ cand_all, int *__restrict__ cand_count, DetGeom g,
+__global__ __launch_bounds__(256) void nms_kernel(Candidate *__restrict__ cand_all, const float *__restrict__ loc, int *__restrict__ cand_count, DetGeom g,
                                                   uint8_t *__restrict__ dead_all, frt_bbox *__restrict__ out, int *__restrict__ n_out,
                                                   int *__restrict__ kept_anchor) {
     const int f = blockIdx.x, tid = threadIdx.x;
-    const Candidate *cand = cand_all + (long)f * g.A;
+    Candidate *cand = cand_all + (long)f * g.A;
     uint8_t *dead = dead_all + (long)f * g.A;
     const int n = cand_count[f];
     __shared__ float s_score[4];
@@ -110,7 +115,10 @@ __global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ 
     __shared__ Candidate s_win;
     __shared__ int s_has;
 
-    for (int i = tid; i < n; i += 256) dead[i] = 0;
+    for (int i = tid; i < n; i += 256) {  // boxes of the frame's candidates (decode_kernel left anchor + score)
+        dead[i] = 0;
+        cand[i].box = decode_box(g, cand[i].anchor, loc + (long)f * g.A * 4, cand[i].box.score);
+    }
     __syncthreads();
 
     int kept = 0;
@@ -200,12 +208,13 @@ __global__ __launch_bounds__(256) void nms_kernel(const Candidate *__restrict__ 
 void launch_decode(const float *loc, const float *conf, int n_frames, const DetGeom &g, Candidate *cand, int *cand_count, hipStream_t s) {
     // cand_count is zero here: allocated zeroed, and nms_kernel (always launched after this kernel) resets the entries it consumed
     dim3 grid((g.A + 255) / 256, n_frames);
-    hipLaunchKernelGGL(decode_kernel, grid, dim3(256), 0, s, loc, conf, g, cand, cand_count);
+    (void)loc;  // (read by nms_kernel since round 5)
+    hipLaunchKernelGGL(decode_kernel, grid, dim3(256), 0, s, conf, g, cand, cand_count);
 }
 
-void launch_nms(const Candidate *cand, int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
+void launch_nms(Candidate *cand, const float *loc, int *cand_count, int n_frames, const DetGeom &g, uint8_t *dead, frt_bbox *out, int *n_out,
                 int *kept_anchor, hipStream_t s) {
-    hipLaunchKernelGGL(nms_kernel, dim3(n_frames), dim3(256), 0, s, cand, cand_count, g, dead, out, n_out, kept_anchor);
+    hipLaunchKernelGGL(nms_kernel, dim3(n_frames), dim3(256), 0, s, cand, loc, cand_count, g, dead, out, n_out, kept_anchor);
 }
 
 // ---------------------------------------------------------------- landmarks of the kept boxes (optional alignment mode)

@@ -121,6 +121,14 @@ void frt_embedder_destroy(frt_embedder *e);
  * embedder / pipeline returns FRT_ERR_DEVICE and this switch is the way back.  Takes effect for passes enqueued after the call; a
  * pipeline with hipGraph replay on must be told to re-capture (frt_pipeline_set_graph). */
 int frt_embedder_set_se_fused(frt_embedder *e, int enable);
+/* Arithmetic of the recogniser network for the passes enqueued after the call.  fp32 = 0 (default): fp16 activations and weights on the fp16
+ * matrix cores with fp32 accumulation - what the reference's TensorRT engine is built with (conversion/arcface/torch2trt.py:42-43) and what
+ * every throughput figure of this build is measured on (embeddings cosine-equal to the fp32 network within ~ 3e-6).  fp32 = 1: fp32
+ * activations, fp32 weights, every product an exact fp32 fma (v_mfma_f32_32x32x2_f32 / v_fma_f32) - BASELINE configs[1]'s "fp32"; a simple,
+ * separate path meant for a few faces per call (about 10x the time per face; 1 - cosine <= 1e-6 against the fp32 oracle).  The first call with
+ * fp32 = 1 re-reads the weight blob the object was created from and uploads fp32 copies (175 MB).  Pipelines with hipGraph replay on must be
+ * told to re-capture (frt_pipeline_set_graph). */
+int frt_embedder_set_precision(frt_embedder *e, int fp32);
 
 /* ArcFaceIR50::preprocessFace (src/arcface.cpp:105-114): u8 BGR [in_h][in_w][3] -> float32 planar RGB. */
 int frt_embedder_preprocess_face(frt_embedder *e, const uint8_t *bgr_crop, float *chw_out);

@@ -199,6 +199,63 @@ def test_dynamic_range_of_the_fp16_activation_storage(frt, synth, tmp_path, whic
     assert ((got * want).sum(1) > 1 - 1e-4).all(), (got * want).sum(1)
 
 
+@pytest.mark.parametrize("scale", [1e-6, 1e-4, 1e-2, 1e2, 1e3, 1e5])
+def test_branch_conditioning_at_load_removes_the_silent_range_failure(frt, synth, tmp_path, scale):
+    """Round-4 review item 6.  The one SILENT failure of the sweep above was a conv1 -> PReLU -> conv2 branch 1e-4 times smaller than the
+    synthetic weights keep it (1 - cos 4.8e-4, five times north_star's tolerance): T and conv1's fp16 weights in the subnormals, conv2's near
+    overflow.  libfrt now conditions every unit at load (frt_api.cpp: conv1 rows, conv2 columns / rows and the closing BatchNorm's scale by
+    powers of two - the same function, exactly); the embeddings of a branch rescaled by 1e-6 ... 1e5 match the fp32 oracle as well as the
+    well-scaled network does (1 - cos <= 1e-5)."""
+    import importlib.util
+
+    from conftest import ROOT, face_input
+    from oracle import nets
+    spec = importlib.util.spec_from_file_location("drs", os.path.join(ROOT, "tools", "dynamic_range_sweep.py"))
+    drs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drs)
+    for mode, kind in (("ir", frt.weights_io.KIND_ARCFACE_IR50),):
+        base = synth.arcface_state(2, mode, calib=synth.load_calibration(mode))
+        sd = drs.rescale(base, t=scale, mode=mode)
+        x = face_input(synth.make_faces(4))
+        want = nets.arcface_forward(base, x)   # (the fp32 oracle of the rescaled weights is the same function; at 1e-6 / 1e5 its own fp32 products still hold)
+        path = frt.write_weights(str(tmp_path / ("w_%s.frtw" % mode)), sd, kind)
+        rec = frt.ArcFaceIR50(path, maxBatchSize=4)
+        got = rec.doInference(x)
+        rec.close()
+        assert np.isfinite(got).all()
+        assert ((got * want).sum(1) > 1 - 1e-5).all(), (scale, 1 - (got * want).sum(1))
+
+
+@pytest.mark.parametrize("mode", ["ir", "ir_se"])
+def test_fp32_precision_mode_matches_the_fp32_oracle(frt, synth, tmp_path, mode):
+    """BASELINE configs[1] says "fp32".  frt_embedder_set_precision(e, 1) runs the recogniser with fp32 activations, fp32 weights and exact
+    fp32 products (kernels_arc_f32.hip): against the fp32 oracle (torch-CPU, another summation order) the embeddings agree to 1 - cos <= 1e-6
+    and element-wise to 2e-5 - two orders of magnitude tighter than north_star's tolerance, which the default fp16-MFMA path meets at ~ 3e-6.
+    Nine faces exercise the chunking (eight per pass); switching back restores the default path."""
+    from conftest import face_input
+    from oracle import nets
+    sd = synth.arcface_state(2, mode, calib=synth.load_calibration(mode))
+    kind = frt.weights_io.KIND_ARCFACE_IR50 if mode == "ir" else frt.weights_io.KIND_ARCFACE_IR_SE50
+    path = frt.write_weights(str(tmp_path / "w.frtw"), sd, kind)
+    x = face_input(synth.make_faces(9))
+    want = nets.arcface_forward(sd, x)
+    rec = frt.ArcFaceIR50(path, maxBatchSize=9)
+    fast = rec.doInference(x)
+    rec.setPrecision(True)
+    got = rec.doInference(x)
+    one = rec.doInference(x[4:5])
+    rec.setPrecision(False)
+    again = rec.doInference(x)
+    rec.close()
+    assert np.isfinite(got).all()
+    cos = (got.astype(np.float64) * want).sum(1)
+    assert (cos > 1 - 1e-6).all(), 1 - cos
+    assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
+    assert np.array_equal(one[0], got[4])                      # a face's embedding does not depend on its position in the batch
+    assert np.array_equal(again, fast)                         # back on the default path
+    assert 1 - (fast * want).sum(1).min() > 1 - (cos.min())    # ... which is the less accurate of the two
+
+
 def test_fp16_overflow_is_not_silent(frt, synth, tmp_path):
     """... and at a stream scale of 1e4 the fp16 tensors overflow: the embeddings come back non-finite, never as plausible numbers."""
     import importlib.util
