@@ -2044,8 +2044,8 @@ int frt_detector_create(const char *weights_path, int frame_w, int frame_h, int 
         d->d_loc = d->arena.alloc<float>(B * g.A * 4);
         d->d_conf = d->arena.alloc<float>(B * g.A * 2);
         d->d_cand = d->arena.alloc<Candidate>(B * g.A);
-        d->d_cand_count = d->arena.alloc<int>(B);
-        HIPCHK(hipMemset(d->d_cand_count, 0, sizeof(int) * B));  // kept at zero between calls by nms_kernel
+        d->d_cand_count = d->arena.alloc<int>((size_t)B * 32);  // one 128-byte line per frame (kernels_post.hip: CC_STRIDE)
+        HIPCHK(hipMemset(d->d_cand_count, 0, sizeof(int) * B * 32));  // kept at zero between calls by nms_kernel
         d->d_nout = d->arena.alloc<int>(B);
         d->d_dead = d->arena.alloc<uint8_t>(B * g.A);
         d->d_boxes = d->arena.alloc<frt_bbox>(B * max_faces);

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
 
 // ---------------------------------------------------------------- plain 1x1 conv, one wave = 32 pixels x CBW*32 output channels
 template <int CBW, bool SPLIT = false>
-__global__ __launch_bounds__(256) void pw_mfma_kernel(DwPwArgs a, int n_pix_groups) {
+__global__ __launch_bounds__(256, (CBW == 1 && SPLIT) ? 4 : 2) void pw_mfma_kernel(DwPwArgs a, int n_pix_groups) {  // (2nd: waves per SIMD asked of the register allocator)
     // Persistent waves (round 4): a wave lives ~ 4 us here, 70 % of it in s_waitcnt, and the counters put 1.5 waves per CU in flight on average
     // (profiles/r04x_det_pmc.txt).  The grid is now what fits the chip at once and every wave walks its share of the (pixel group, channel
     // group) items; with the scalar-base addressing (240 -> 180 / 168 -> 104 registers) that is 61 -> 59 us for the 64-channel lateral at
@@ -657,7 +657,7 @@ bool launch_dwpw_mfma(const DwPwArgs &a, hipStream_t s) {
         const int n_cgroups = (a.Cout + cbw * 32 - 1) / (cbw * 32);
         const long waves = (long)n_pix_groups * n_cgroups;
         // (persistent: two 256-thread workgroups per CU for the wide variant (180 registers), four for the narrow one (104))
-        const unsigned cap = wide ? 2 * 256 : 4 * 256;
+        const unsigned cap = wide ? 3 * 256 : 4 * 256;  // (round 5: 154 / 114 registers)
         const unsigned grid = (unsigned)std::min<long>((waves + 3) / 4, cap);
         static const bool split = !(frt_tuning_env("FRT_DET_PW_SPLIT") && frt_tuning_env("FRT_DET_PW_SPLIT")[0] == '0');
         if (split && a.wph && a.Cin % 16 == 0) {

@@ -65,9 +65,15 @@ struct WaveGeom {
     // has been delivered.  Issue order (a step = two channel pairs = 4 channels, two steps per chunk, four per 16-channel group):
     //   prologue: DMA(0 .. LA-1), A(0);   step s: [s even: DMA(s/2 + LA) at the top] ... [s % 4 == 3: A(s/4 + 1) at the end]
     // The wait for chunk c sits at the top of step 2c - 2, right behind that step's DMA issue - a whole step before the first read of the
-    // chunk (issued in step 2c - 1): MEASURED, a ds_read issued right behind "s_waitcnt vmcnt" can still see the old LDS contents (the
-    // counter drops when the data leaves for LDS, not when it is readable); 128 cycles of s_sleep were enough, a step is 300 - 500.
-    // Chunk 0 is waited for right after the prologue, followed by such a sleep.
+    // chunk (issued in step 2c - 1).  Round 4 recorded wrong sums with the read right behind the wait and read that as "the counter drops before
+    // the data is readable".  Round 5 re-examined it (advisor finding): tools/ubench/lds_dma_raw.hip hammers exactly the pattern - LDS-DMA into
+    // the same bytes, s_waitcnt vmcnt(0) or a counted vmcnt(8) with younger DMAs in flight, ds_read2_b32 of other lanes' slots in the next
+    // instruction, 4 096 one-wave workgroups x 2 000 iterations - and finds 0 stale words in 4.2e10 with nothing, s_nop, s_barrier or s_sleep in
+    // between (profiles/r05a_lds_dma_raw.txt): the issuing wave's covering vmcnt DOES order its own ds_read behind the DMA, which is also what
+    // /opt/skills/guides/MI355X_MICROARCH.md states (two-waves-per-SIMD item 7).  The round-4 failures are explained by the other defect found
+    // at the same time and fixed with the compiler barriers in the prologue below: a plain fragment load hoisted above a DMA it was counted
+    // behind made the COUNT one operation too generous.  The ordering this kernel relies on is therefore the architectural one (counted
+    // vmcnt, in-order VMEM return); the step of distance and chunk 0's s_sleep stay as margin, not as the mechanism.
     static constexpr int younger(int cw) {
         const int at_step = cw == 0 ? -1 : 2 * cw - 2;  // the wait follows the DMA issue of this step (-1: the prologue)
         int n = 0;

@@ -1,10 +1,21 @@
 #!/bin/bash
 set -u
-TAG=${1:-r05e}
+TAG=${1:-r05g}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-python -m pytest tests/test_gpu_embedder.py tests/test_gpu_headline.py -q 2>&1 | tail -25 > "$OUT/${TAG}_pytest_embed.log"
-python tools/dynamic_range_sweep.py --out "$OUT/${TAG}_dynamic_range.json" 2>&1 | grep -v amdgpu.ids | grep branch > "$OUT/${TAG}_dynamic_range.txt"
+python -m pytest tests/test_gpu_detector.py tests/test_gpu_postproc.py tests/test_gpu_headline.py tests/test_gpu_pipeline.py -q 2>&1 | tail -15 > "$OUT/${TAG}_pytest_det.log"
+cd /tmp && export TMPDIR=/tmp
+trace() {  # name, env...
+  local name=$1; shift
+  rm -rf /tmp/prof_det && mkdir -p /tmp/prof_det
+  env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_det -o st -- python "$ROOT/tools/prof_det.py" ${PB:-32} 5 > /dev/null 2>&1
+  cp "$(find /tmp/prof_det -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_det_${name}.csv" 2>/dev/null
+}
+trace b32 X=1
+PB=4 trace b4 X=1
+cd "$ROOT"
+for f in "$OUT"/${TAG}_det_*.csv; do echo "== $f"; python tools/det_table.py "$f"; done > "$OUT/${TAG}_det_tables.txt" 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench_driver.json" 2>/dev/null
 ls -la "$OUT"
