@@ -272,7 +272,7 @@ void launch_split(const Conv3H &mm, int total, hipStream_t s) {
     static bool attr_done[FRT_MAX_DEVICES] = {};
     if (frt_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_split_kernel<NCH, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    int grid = 512;
+    int grid = NCB == 1 ? 768 : 512;  // (51.8 KB of LDS and 132 - 144 registers: three workgroups per CU; 74.9 KB: two)
     if (grid > total) grid = total;
     hipLaunchKernelGGL((conv3x3_split_kernel<NCH, NCB>), dim3(grid), dim3(256), lds, s, mm);
 }

@@ -119,13 +119,80 @@ __global__ __launch_bounds__(256) void nms_kernel(Candidate *__restrict__ cand_a
     __shared__ Candidate s_win;
     __shared__ int s_has;
 
+    int kept = 0;
+    if (n <= 256) {
+        // The usual case (round 5): the frame's candidates fit one per thread - decoded into LDS once, the K rounds of {arg-max, suppress} then run
+        // on registers and LDS only (the general loop below goes back to global memory for every candidate in every round: 10 us of dependent
+        // L2 round trips per call, whatever the batch).  Same selection rule, same IoU arithmetic.
+        __shared__ Candidate s_c[256];
+        Candidate c;
+        bool alive = tid < n;
+        if (alive) {
+            c = cand[tid];
+            c.box = decode_box(g, c.anchor, loc + (long)f * g.A * 4, c.box.score);
+            s_c[tid] = c;
+        }
+        const float area = alive ? (float)((c.box.x2 - c.box.x1 + 1) * (c.box.y2 - c.box.y1 + 1)) : 0.f;
+        __syncthreads();
+        for (; kept < g.max_faces; ++kept) {
+            float bs = alive ? c.box.score : -INFINITY;
+            int ba = alive ? c.anchor : INT_MAX, bp = alive ? tid : -1;
+            for (int off = 32; off > 0; off >>= 1) {
+                const float os = __shfl_xor(bs, off);
+                const int oa = __shfl_xor(ba, off);
+                const int op = __shfl_xor(bp, off);
+                if (op >= 0 && (bp < 0 || cand_better(os, oa, bs, ba))) {
+                    bs = os;
+                    ba = oa;
+                    bp = op;
+                }
+            }
+            if ((tid & 63) == 0) {
+                s_score[tid >> 6] = bs;
+                s_anchor[tid >> 6] = ba;
+                s_pos[tid >> 6] = bp;
+            }
+            __syncthreads();
+            // every thread picks the winner of the four wave winners (same data, same rule: no second barrier needed for a broadcast)
+            float ws = s_score[0];
+            int wa = s_anchor[0], wp = s_pos[0];
+            for (int w = 1; w < 4; ++w)
+                if (s_pos[w] >= 0 && (wp < 0 || cand_better(s_score[w], s_anchor[w], ws, wa))) {
+                    ws = s_score[w];
+                    wa = s_anchor[w];
+                    wp = s_pos[w];
+                }
+            if (wp < 0) break;  // (uniform)
+            const frt_bbox wb = s_c[wp].box;
+            if (tid == wp) {
+                alive = false;
+                out[(long)f * g.max_faces + kept] = wb;
+                if (kept_anchor) kept_anchor[(long)f * g.max_faces + kept] = c.anchor;
+            }
+            if (alive) {
+                const float warea = (float)((wb.x2 - wb.x1 + 1) * (wb.y2 - wb.y1 + 1));
+                const frt_bbox b = c.box;
+                const float xx1 = (float)(wb.x1 > b.x1 ? wb.x1 : b.x1);
+                const float yy1 = (float)(wb.y1 > b.y1 ? wb.y1 : b.y1);
+                const float xx2 = (float)(wb.x2 < b.x2 ? wb.x2 : b.x2);
+                const float yy2 = (float)(wb.y2 < b.y2 ? wb.y2 : b.y2);
+                float w = xx2 - xx1 + 1;
+                float h = yy2 - yy1 + 1;
+                if (w < 0.f) w = 0.f;
+                if (h < 0.f) h = 0.f;
+                const float inter = w * h;
+                const float ovr = inter / (warea + area - inter);
+                if (ovr >= g.nms_thr) alive = false;
+            }
+            __syncthreads();  // (s_score / s_anchor / s_pos are rewritten in the next round)
+        }
+    } else {
     for (int i = tid; i < n; i += 256) {  // boxes of the frame's candidates (decode_kernel left anchor + score)
         dead[i] = 0;
         cand[i].box = decode_box(g, cand[i].anchor, loc + (long)f * g.A * 4, cand[i].box.score);
     }
     __syncthreads();
 
-    int kept = 0;
     for (; kept < g.max_faces; ++kept) {
         float bs = -INFINITY;
         int ba = INT_MAX, bp = -1;
@@ -193,6 +260,7 @@ __global__ __launch_bounds__(256) void nms_kernel(Candidate *__restrict__ cand_a
             if (ovr >= g.nms_thr) dead[i] = 1;
         }
         __syncthreads();
+    }
     }
     if (tid == 0) {
         n_out[f] = kept;

@@ -105,6 +105,36 @@ def test_screened_top1_is_bit_identical_to_the_exact_scan(frt, synth, mm):
     assert agree.mean() > 0.9 and np.abs(osim - s).max() < 2e-3 * np.abs(osim).max()  # NumPy sums in another order: near-ties may differ
 
 
+def test_screening_switch_generation_and_scan_bytes(frt, synth, mm):
+    """Round 5: frt_matcher_set_screening(m, 0) makes every top-1 call take the exact fp32 scan (bench.py's match_worst_case leg) - same
+    answers bit for bit; frt_matcher_scan_bytes reports what a call reads in either mode; frt_matcher_generation moves with the gallery."""
+    N = 50000
+    g = synth.make_gallery(N)
+    q = np.concatenate([synth.make_queries(g, [7, 49999, 1234], noise=0.01), np.random.Generator(np.random.PCG64(5)).standard_normal((29, 512)).astype(np.float32)])
+    gen0 = int(frt.lib.frt_matcher_generation(mm._h))
+    mm.init(g)
+    gen1 = int(frt.lib.frt_matcher_generation(mm._h))
+    assert gen1 != gen0
+    assert mm.scanBytes() == N * 512            # int8 shadow: one byte per element
+    i1, s1 = mm.top1(q)
+    mm.setScreening(False)
+    assert mm.scanBytes() == N * 512 * 4        # the stored fp32 rows
+    i0, s0 = mm.top1(q)
+    mm.setScreening(True)
+    i2, s2 = mm.top1(q)
+    assert np.array_equal(i0, i1) and np.array_equal(s0, s1) and np.array_equal(i2, i1) and np.array_equal(s2, s1)
+    assert list(i1[:3]) == [7, 49999, 1234]
+    mm.init(g[:100])
+    assert int(frt.lib.frt_matcher_generation(mm._h)) != gen1 and mm.scanBytes() == 100 * 512 * 4
+
+
+def test_sustained_mfma_probe_reports_a_plausible_rate(frt):
+    """frt_probe_sustained_mfma (bench.py's roofline.sustained_peak): the three instruction mixes order as expected and stay below the nominal
+    2.5 PFLOP/s."""
+    a, b, c = (frt.probe_sustained_mfma(0, m, 0.05) for m in (0, 1, 2))
+    assert 200 < c <= b * 1.05 and b <= a * 1.05 and a < 2600, (a, b, c)
+
+
 @pytest.mark.parametrize("N", [5000, 70001])
 def test_sharded_gallery_merge_equals_single_gallery(frt, synth, N):
     """Config 5 on one GPU: two matchers own disjoint row ranges (global indices via setRowOffset); the first-maximum merge of

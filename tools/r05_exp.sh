@@ -1,11 +1,11 @@
 #!/bin/bash
 set -u
-TAG=${1:-r05g}
+TAG=${1:-r05h}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-python -m pytest tests/test_gpu_detector.py tests/test_gpu_postproc.py tests/test_gpu_headline.py tests/test_gpu_pipeline.py -q 2>&1 | tail -15 > "$OUT/${TAG}_pytest_det.log"
+python -m pytest tests/test_gpu_detector.py tests/test_gpu_postproc.py tests/test_gpu_match.py -q 2>&1 | tail -15 > "$OUT/${TAG}_pytest.log"
 cd /tmp && export TMPDIR=/tmp
 trace() {  # name, env...
   local name=$1; shift
@@ -14,8 +14,11 @@ trace() {  # name, env...
   cp "$(find /tmp/prof_det -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_det_${name}.csv" 2>/dev/null
 }
 trace b32 X=1
-PB=4 trace b4 X=1
+PB=1 trace b1 X=1
 cd "$ROOT"
 for f in "$OUT"/${TAG}_det_*.csv; do echo "== $f"; python tools/det_table.py "$f"; done > "$OUT/${TAG}_det_tables.txt" 2>&1
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench_driver.json" 2>/dev/null
+for i in 1 2; do
+  python bench.py --steps 100 --no-cpu-baseline --no-extras --no-profile > "$OUT/${TAG}_bench_dual1_$i.json" 2>/dev/null
+  FRT_PIPELINE_DUAL_EMBED=0 python bench.py --steps 100 --no-cpu-baseline --no-extras --no-profile > "$OUT/${TAG}_bench_dual0_$i.json" 2>/dev/null
+done
 ls -la "$OUT"
