@@ -110,6 +110,8 @@ class ArcFaceIR50 : public ArcFaceIR50Statics<> {
         std::atomic_store(&m_link, l);
         detector.attachCoalescer(l);
     }
+    // Extension (round 5): fp32 end-to-end recogniser (BASELINE configs[1]'s "fp32"; see frt_embedder_set_precision).  Default: fp16 MFMA.
+    void setPrecisionFp32(bool on) { checkFrtStatus(frt_embedder_set_precision(h_, on ? 1 : 0)); }
     ArcFaceIR50(const ArcFaceIR50 &) = delete;
     ArcFaceIR50 &operator=(const ArcFaceIR50 &) = delete;
 

@@ -63,6 +63,8 @@ python bench.py --steps 4000 --warmup 5 --no-cpu-baseline --no-extras --no-profi
 python bench.py --mode ir_se --no-cpu-baseline > "$OUT/${TAG}_bench_ir_se.json" 2>/dev/null
 python bench.py --frame 1920x1080 --no-cpu-baseline > "$OUT/${TAG}_bench_1080p.json" 2>/dev/null
 python bench.py --batch 1 --gallery 10000 --no-cpu-baseline > "$OUT/${TAG}_bench_config1.json" 2>/dev/null
+python bench.py --batch 1 --gallery 10000 --no-cpu-baseline --fp32 > "$OUT/${TAG}_bench_config1_fp32.json" 2>/dev/null   # BASELINE configs[1] as labelled: fp32 recogniser
+python bench.py --exact-match --no-cpu-baseline --no-extras > "$OUT/${TAG}_bench_exact_match.json" 2>/dev/null         # primary region with the exact fp32 scan (SURVEY 8(d)'s match)
 python bench.py --faces 1 --no-cpu-baseline > "$OUT/${TAG}_bench_k1.json" 2>/dev/null
 FRT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_rccl_1rank.json"
 FRT_BENCH_FORCE_DIST=1 python bench.py --sharded-gallery --batch 64 --gallery 1250000 --no-cpu-baseline 2>/dev/null | head -1 > "$OUT/${TAG}_bench_sharded_1rank.json"
@@ -97,4 +99,17 @@ python tools/dwpw_wave_check.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/${TAG}_
 FRT_LIB=$ROOT/face-recognition-cpp-tensorrt_amd/libfrt_tuning.so FRT_DET_STEM_CHECK=1 python tools/stem_check_run.py 2>&1 | grep "stem check" > "$OUT/${TAG}_stem_check.txt"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFRT_TUNING -w -Iface-recognition-cpp-tensorrt_amd/csrc -o /tmp/dwpw_wave_bench tools/ubench/dwpw_wave_bench.hip 2>/dev/null &&
   for A in "32" "2" "32 64 80" "2 64 80" "32 256 20" "2 256 20"; do FRT_DWPW_WAVE_ANYB=1 timeout 60 /tmp/dwpw_wave_bench $A; done > "$OUT/${TAG}_dwpw_wave_bench.txt" 2>&1
+# 6. round 5: detector PMC passes (waves, cycles, waits, instruction mix, HBM bytes) over the detector alone; probes and harnesses
+{
+  echo "rocprofv3 --pmc (separate passes, no trace domains) over tools/prof_det.py 32 2 (detector alone, 32 frames of 640x640), medians per launch, summed over the chip."
+  echo "FETCH_SIZE / WRITE_SIZE in KB (FETCH_SIZE NOT doubled here).  SQ_WAVE_CYCLES / SQ_WAIT_* in quad-cycles."
+  for G in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "FETCH_SIZE" "WRITE_SIZE"; do
+    TARGET='prof_det.py 32 2' KFILTER='det_stem|dwpw_wave_kernel<128|conv3x3_split|pw_mfma|dwpw_mfma_kernel<2, 2, 32, 1, 2|dwpw_row4|decode|nms|heads' bash tools/pmc_pass.sh "$G"
+  done
+} > "$OUT/${TAG}_det_pmc.txt" 2>&1
+[ -x tools/ubench/lds_dma_raw ] && timeout 120 tools/ubench/lds_dma_raw > "$OUT/${TAG}_lds_dma_raw.txt" 2>&1
+[ -x tools/ubench/det_conv3h_bench ] && { timeout 300 tools/ubench/det_conv3h_bench 32; timeout 120 tools/ubench/det_conv3h_bench 4; timeout 120 tools/ubench/det_conv3h_bench 1; } > "$OUT/${TAG}_det_conv3h_bench.txt" 2>&1
+[ -x tools/ubench/plane_stride ] && timeout 300 tools/ubench/plane_stride > "$OUT/${TAG}_plane_stride.txt" 2>&1
+for f in "$OUT"/${TAG}_det_kernel_stats_b*.csv; do echo "== $(basename $f)"; python tools/det_table.py "$f"; done > "$OUT/${TAG}_det_tables.txt" 2>&1
+python -c "import __graft_entry__ as e; e.smoke()" > "$OUT/${TAG}_smoke.txt" 2>&1
 ls -la "$OUT"
