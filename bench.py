@@ -369,7 +369,11 @@ def main():
     gallery_load_s = time.perf_counter() - t_load
     if args.exact_match:
         rec.matmul.setScreening(False)
-    _sb, _rows = rec.matmul.scanBytes(), max(int(frt.lib.frt_matcher_num_rows(rec.matmul._h)), 1)
+    try:
+        _sb = rec.matmul.scanBytes()
+    except AttributeError:  # (FRT_LIB_OLD=1: an older library in a same-box A/B)
+        _sb = 512 * args.gallery if args.gallery >= 32768 else 2048 * args.gallery
+    _rows = max(int(frt.lib.frt_matcher_num_rows(rec.matmul._h)), 1)
     scan_mode = "int8" if _sb == 512 * _rows else ("fp16" if (_sb == 1024 * _rows and not args.sharded_gallery) else "exact")
     pipe = frt.Pipeline(det, rec, B, match=not args.sharded_gallery)  # sharded gallery: the pipeline produces embeddings, match + merge follow below
     # The caller's stream (NOT torch's default stream: that is the legacy NULL stream, and every operation on it - an event record, a
