@@ -1864,7 +1864,7 @@ struct frt_pipeline {
         run_part(GraphKey{0, frames_dev, nullptr, nullptr, n, slot, akey, 0u}, ds, [&](hipStream_t st) {
 #ifdef FRT_TUNING
             // timing build: FRT_PIPE_ABLATE bit 0 = no detector network after the first calls (post-processing re-reads the old head outputs),
-            // bit 1 = no recogniser network, bit 2 = no match: what each stage costs the pipelined step (profiles/r04s_stage_ablation.txt)
+            // bit 1 = no recogniser network, bit 2 = no match: what each stage costs the pipelined step (profiles/r04/r04s_stage_ablation.txt)
             static const int pipe_abl = getenv("FRT_PIPE_ABLATE") ? atoi(getenv("FRT_PIPE_ABLATE")) : 0;
             if (!(pipe_abl & 1) || call < 8u)
 #endif

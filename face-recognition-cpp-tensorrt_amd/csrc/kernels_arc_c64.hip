@@ -237,7 +237,7 @@ __global__ __launch_bounds__(128) void conv64_kernel(ConvMfmaArgs p, int n_strip
 // Round 4, built, measured and parked in tools/experiments/conv64_in_unit0_input_layer_fused.hip: this kernel computing its own input
 // patch from the 3-channel crop (the input layer - 4 MFMAs, 16 gathers and a 64-value fp32 PReLU / BN epilogue per 32 patch pixels - inside
 // the strip loop, so that the 205 MB tensor z is never written or read).  Bit-identical to the two-kernel path (goldens green) and
-// SLOWER: 379 us at 128 faces against 78 (arc_input_mfma_kernel) + 169 (this kernel) = 247 us (profiles/r04k_unit0_fused_in.txt).  The
+// SLOWER: 379 us at 128 faces against 78 (arc_input_mfma_kernel) + 169 (this kernel) = 247 us (profiles/r04/r04k_unit0_fused_in.txt).  The
 // strip loop runs one wave per SIMD; the patch build is ~ 3 000 VALU / LDS / store instructions per strip and wave in the same in-order
 // stream as the 144 MFMAs (7 261 instructions in the kernel, 800 of them AGPR moves at 498 registers), where the stand-alone input
 // kernel spreads the same work over sixteen waves per CU and is bound by its 256 MB of HBM writes.  410 MB of traffic saved, 132 us lost.

@@ -5,7 +5,7 @@
 // per step) and of a coalesced multi-threaded server (frt_coalescer_*).  Neither older kernel family is at home there:
 //   * the strip kernels (kernels_arc.hip) give a workgroup 128 output channels of a strip, i.e. 590 KB of weights (256 -> 256) or 1.18 MB
 //     (512 -> 512) through ONE CU's vector memory path (~ 80 - 130 GB/s) for 2 us of MFMAs: 13 us per 14x14 layer and 21 us per 7x7 layer
-//     at 16 faces (profiles/r04c_layers_16.txt), 26 + 4 such launches per pass;
+//     at 16 faces (profiles/r04/r04c_layers_16.txt), 26 + 4 such launches per pass;
 //   * conv_small_kernel (kernels_arc_small.hip) makes the unit 32 couts x 32 pixels but gathers every pixel 9 times from L2: 294 KB of
 //     operands per unit, fine for 25 units per block and too much for 100.
 // What bounds a launch here is the operand bytes a CU has to pull in, so the tile is chosen to minimise THEM at ~ one workgroup per CU:
@@ -37,7 +37,7 @@ constexpr int EROW = 36;   // floats per pixel row of the epilogue transpose til
 // NT pixel tiles per strip, CPW 64-channel chunks per wave (Cin = 256 * CPW), HW = map size (14 or 7), R = rows per strip.
 // PIECES = DMA pieces per patch chunk: one piece = 7 patch rows = 63 sixteen-byte units (lane 63 sits out), so a lane's (row within the
 // piece, 16-byte slot) never changes and a piece's source address is a dozen instructions (the first version divided the unit index out
-// per piece: 2.3 us of address arithmetic in front of a 2 us K loop, profiles/r04e_ks_stamps.txt).
+// per piece: 2.3 us of address arithmetic in front of a 2 us K loop, profiles/r04/r04e_ks_stamps.txt).
 template <int NT, int CPW, int HW, int R>
 __global__ __launch_bounds__(256, 1) void conv_ks_kernel(ConvMfmaArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
 #ifdef FRT_ABLATE
     // timing build, linear tiles only (tiles_x is unused there; FRT_DWPW_ABLATE): bit 0 no output stores, bit 1 every workgroup reads the
     // first rows of image 0 (cache-resident input).  Round 4, 128 -> 128 block at 40x40, 32 frames: 45 us -> 44 (no stores) / 44 (cached
-    // input) / 38 (both) in the ablation build - the launch is not memory-bound; profiles/r04o_det_ablations.txt
+    // input) / 38 (both) in the ablation build - the launch is not memory-bound; profiles/r04/r04o_det_ablations.txt
     const int abl = MODE2D ? 0 : tiles_x;
     const float *inb = a.in + (long)((ms.ok && !(abl & 2)) ? ms.b : 0) * a.Cin * HW;
 #else
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
 template <int CBW, bool SPLIT = false>
 __global__ __launch_bounds__(256, (CBW == 1 && SPLIT) ? 4 : 2) void pw_mfma_kernel(DwPwArgs a, int n_pix_groups) {  // (2nd: waves per SIMD asked of the register allocator)
     // Persistent waves (round 4): a wave lives ~ 4 us here, 70 % of it in s_waitcnt, and the counters put 1.5 waves per CU in flight on average
-    // (profiles/r04x_det_pmc.txt).  The grid is now what fits the chip at once and every wave walks its share of the (pixel group, channel
+    // (profiles/r04/r04x_det_pmc.txt).  The grid is now what fits the chip at once and every wave walks its share of the (pixel group, channel
     // group) items; with the scalar-base addressing (240 -> 180 / 168 -> 104 registers) that is 61 -> 59 us for the 64-channel lateral at
     // 80x80 and 23 -> 18.5 us for the other two at 32 frames, 13 -> 11.6 us at 4 - the wide one is still not understood (1.9 TB/s, clean
     // 128-byte accesses).
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, (CBW == 1 && SPLIT) ? 4 : 2) void pw_mfma_kern
         // 8 scalar loads the fp32 path spends on 8 k-steps), splits them, and three fp16 MFMAs replace eight fp32 ones
         const int ngroups = a.Cin / 16;
         // activations FOUR groups ahead (32 registers), weights (L2 hits) one: with one group in flight a wave paid the HBM latency once per 16
-        // channels, and few waves fit a CU (round 4: lateral 64->64 at 80x80 61 -> see profiles/r04v_laterals.txt)
+        // channels, and few waves fit a CU (round 4: lateral 64->64 at 80x80 61 -> see profiles/r04/r04v_laterals.txt)
         constexpr int DA = 4;
         float bx[DA][8];
         half8 ah[CBW], al[CBW], nah[CBW], nal[CBW];
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, (CBW == 1 && SPLIT) ? 4 : 2) void pw_mfma_kern
         // Round 5: ONE uniform base and a RUNNING 32-bit lane offset, advanced by per-lane (opaque) strides.  Written as base + (uniform channel
         // offset) + lane offset the compiler formed one scalar 64-bit base per load - 128 pairs over the item, 207 scalar spills, and the
         // spill traffic (v_readlane / v_writelane) WAS the kernel: 1 245 VALU + 620 SALU instructions per 32-pixel item for ~ 300 useful ones
-        // (profiles/r04x_det_pmc.txt), 15 us per item.  The groups are requested in ascending order, so one running offset serves them all.
+        // (profiles/r04/r04x_det_pmc.txt), 15 us per item.  The groups are requested in ascending order, so one running offset serves them all.
         const char *xin_c = reinterpret_cast<const char *>(a.in);
         unsigned st1, st9;  // one channel plane / nine (from channel 16 g + 8 hi + 7 to 16 (g + 1) + 8 hi)
         asm volatile("v_mov_b32 %0, %1" : "=v"(st1) : "s"(HW * 4));

@@ -3,7 +3,7 @@
 //
 // Why a second formulation next to dwpw_mfma_kernel (kernels_det_mfma.hip): that kernel maps a thread to (channel, 4 pixels), pays ~50
 // VALU instructions per output value on addresses, border selects, the hi/lo split and 2-byte LDS stores, and goes through four
-// barrier-separated phases per workgroup; profiles/r04o_det_ablations.txt shows the 40x40 blocks issue-/latency-bound at 0.16 of HBM with
+// barrier-separated phases per workgroup; profiles/r04/r04o_det_ablations.txt shows the 40x40 blocks issue-/latency-bound at 0.16 of HBM with
 // 85 % of the launch left when all memory traffic is removed.  Here
 //   * lane = pixel, the loop runs over channels: the depthwise weights of a channel are wave-uniform, i.e. SGPR operands of
 //     v_pk_fma_f32 (two channels per instruction), and there is no per-element address arithmetic at all;
@@ -576,7 +576,7 @@ bool launch_dwpw_wave(const DwPwArgs &a, hipStream_t s) {
     // Batch thresholds: a wave is ~ 13 / 8 / 17 us long whatever the batch (one wave = 64 pixels x every input channel), the workgroup-tiled
     // kernel finishes a few frames sooner.  Measured per launch, old / this kernel (us):  128 @ 40x40: 11.6 / 14 at 4 frames, 14.7 / 16 at 8,
     // 24.4 / 18 at 16, 39 / 20 at 32;  64 @ 80x80: 10.1 / 10 at 1, 12.9 / 11 at 4, 20.3 / 14 at 8, 56 / 36 at 32;  256 @ 20x20: 19 / 21 at 4,
-    // 25.5 / 24 at 8, 27.8 / 25 at 16, 36 / 22 at 32 (profiles/r04t_dwpw_wave.txt)
+    // 25.5 / 24 at 8, 27.8 / 25 at 16, 36 / 22 at 32 (profiles/r04/r04t_dwpw_wave.txt)
     if (a.stride == 1 && a.Cin == 128 && a.Cout == 128 && a.W == 40 && a.H == 40 && (which & 1) && (a.B >= 12 || any_batch)) {
         launch_wave<128, 128, 4, 40, 40, 1, 3>(a, s);
         return true;

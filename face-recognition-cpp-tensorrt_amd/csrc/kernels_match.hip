@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
 // The same scan for a full 128-query block with a 2 x 2 wave tiling: wave = (row half rb, query half qh) owns the 32-row blocks 2 rb, 2 rb + 1
 // and the query blocks 2 qh, 2 qh + 1 - four accumulators as before, but every query fragment read from LDS and every widened gallery
 // fragment now feeds TWO MFMAs.  With one row block x four query blocks per wave (above) the four waves read 4 x 4 KB of query fragments per
-// k-step, exactly the CU's LDS bandwidth, and the int8 scan ran at 2.95 TB/s with the matrix pipe a third busy (profiles/r04j); here the LDS
+// k-step, exactly the CU's LDS bandwidth, and the int8 scan ran at 2.95 TB/s with the matrix pipe a third busy (profiles/r04/r04j); here the LDS
 // traffic is halved (and the widening doubled: 512 VALU operations per tile and wave, still under the MFMA time).
 __global__ __launch_bounds__(256) void match_coarse_i8x4_kernel(const uint8_t *__restrict__ G8, const float *__restrict__ gscale, int N, int F,
                                                                 float *__restrict__ tilemax, int num_tiles, const float *__restrict__ Q32,

@@ -2,7 +2,7 @@
 // Context: face-recognition-cpp-tensorrt_amd/csrc/kernels_arc_c64.hip (this code sat behind conv64_kernel and uses its constants SW, PW,
 // PROWB, PATCH_B, RING, EROW); frt_embedder::forward called launch_conv64_in(conv1 args, input-layer args) instead of launch_arc_input +
 // conv1's launch.  Result: bit-identical embeddings (tests/test_gpu_embedder.py, goldens), 379 us per launch at 128 faces against
-// 78 + 169 us for the two kernels it replaces (profiles/r04k_unit0_fused_in.txt) - see the note in kernels_arc_c64.hip.
+// 78 + 169 us for the two kernels it replaces (profiles/r04/r04k_unit0_fused_in.txt) - see the note in kernels_arc_c64.hip.
 
 // ---------------------------------------------------------------- unit 0: the input layer fused into conv1's patch (round 4)
 // Unit 0 of the recogniser moved 1 024 MB through three kernels (input layer 256 MB, conv1 410, stride-2 conv2 358): the input layer wrote

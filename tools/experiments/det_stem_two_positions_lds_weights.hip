@@ -1,7 +1,7 @@
 // PARKED (round 5, not linked into libfrt.so): det_stem_kernel with TWO positions per lane in P1 / P2 and the first two layers' weights
 // broadcast from an LDS copy (ds_read_b128, in-order returns) instead of scalar loads.  Motivation: scalar loads return out of order, so every
 // use waits with lgkmcnt(0) for ALL outstanding ones - the "chunk i + 2 in flight" prefetch of the shipped kernel overlaps nothing (43 % of wave
-// cycles in s_waitcnt, profiles/r04x_det_pmc.txt).  Outcome: compiles to 288 - 332 VGPRs (one wave per SIMD instead of four; the SGPR-chunk form
+// cycles in s_waitcnt, profiles/r04/r04x_det_pmc.txt).  Outcome: compiles to 288 - 332 VGPRs (one wave per SIMD instead of four; the SGPR-chunk form
 // of the same idea: 184 VGPRs and 455 scalar spills) - the compiler keeps far more of the unrolled body live than the source suggests, and
 // neither sched_barrier fences nor opaque address offsets changed that.  Never measured on the GPU: at a quarter of the occupancy it cannot win.
 // What would: the P1 / P2 bodies as hand-written asm with fixed registers (the dwpw_wave_kernel treatment).
@@ -88,7 +88,7 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
             // instead of 27 chunks of 8 per position.  Scalar loads return out of order, so every use of one waits for ALL outstanding ones
             // (s_waitcnt lgkmcnt(0)): "chunk i + 2 in flight under chunk i" never overlapped anything, each of a position's 27 chunks paid a
             // full scalar-cache round trip for 16 cycles of arithmetic (1 instruction per ~ 9 cycles and SIMD, 43 % of wave cycles waiting,
-            // profiles/r04x_det_pmc.txt).  Now a wait buys 64 - 80 v_pk_fma_f32.  Same products in the same order per output: bit-identical.
+            // profiles/r04/r04x_det_pmc.txt).  Now a wait buys 64 - 80 v_pk_fma_f32.  Same products in the same order per output: bit-identical.
             constexpr int N1 = R1 * R1;
             const int i1 = lane + NT;
             const bool has1 = i1 < N1;
