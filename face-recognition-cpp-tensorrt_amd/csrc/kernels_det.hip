@@ -135,11 +135,17 @@ __global__ __launch_bounds__(256) void dwpw_kernel(DwPwArgs a) {
             aw = aw < a.add_w - 1 ? aw : a.add_w - 1;
             addb = a.add + ((long)pb[q] * a.Cout + co0) * a.add_h * a.add_w + ah * a.add_w + aw;
         }
+        float bq[CT], aq[CT];  // (all loads in front of the first store: see dwpw_row4_kernel's epilogue)
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            float v = acc[q][c] + a.bp[co0 + c];
+            bq[c] = a.bp[co0 + c];
+            aq[c] = addb ? addb[(long)c * a.add_h * a.add_w] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            float v = acc[q][c] + bq[c];
             if (a.relu) v = fmaxf(v, 0.f);
-            if (addb) v += addb[(long)c * a.add_h * a.add_w];
+            if (addb) v += aq[c];
             ob[(long)c * HoWo] = v;
         }
     }
@@ -251,12 +257,17 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
         }
     }
     float *ob = a.out + ((long)b * a.Cout + co0) * HW + oh * a.W + ow0;
+    // (every parameter load of the epilogue in front of its first store: for all the compiler knows the output aliases them, and left alone it
+    //  emits load -> s_waitcnt vmcnt(0) -> store once per channel - a chain of dependent memory round trips at the end of every thread; round 5)
+    float bq[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bq[c] = a.bp[co0 + c];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         floatx4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float v = acc[q][c] + a.bp[co0 + c];
+            float v = acc[q][c] + bq[c];
             if (a.relu) v = fmaxf(v, 0.f);
             o[q] = v;
         }
@@ -339,9 +350,12 @@ __global__ __launch_bounds__(256) void dwpw_pixs_kernel(DwPwArgs a) {
     }
     if (g >= total) return;
     float *ob = a.out + ((long)b * a.Cout + co0) * HoWo + p;
+    float bq[CT];  // (loads in front of the first store: see dwpw_row4_kernel's epilogue)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bq[c] = a.bp[co0 + c];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        float o = acc[c] + a.bp[co0 + c];
+        float o = acc[c] + bq[c];
         if (a.relu) o = fmaxf(o, 0.f);
         ob[(long)c * HoWo] = o;
     }
@@ -418,9 +432,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Multi mm) {
     // channel tiles at or beyond `split` belong to the second output tensor (two convs that share their input, run as one)
     float *ob = (a.out2 && co0 >= a.split) ? a.out2 + ((long)b * a.out2_ctotal + a.out2_coff + co0 - a.split) * HoWo + p
                                            : a.out + ((long)b * a.out_ctotal + a.out_coff + co0) * HoWo + p;
+    float bq[CT];  // (loads in front of the first store: see dwpw_row4_kernel's epilogue)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bq[c] = a.b[co0 + c];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        float v = acc[c] + a.b[co0 + c];
+        float v = acc[c] + bq[c];
         if (a.relu) v = fmaxf(v, 0.f);
         ob[(long)c * HoWo] = v;
     }
@@ -489,9 +506,12 @@ __global__ __launch_bounds__(256) void conv3x3_ldsw_kernel(Conv3Multi mm) {
     }
     float *ob = (a.out2 && co0 >= a.split) ? a.out2 + ((long)b * a.out2_ctotal + a.out2_coff + co0 - a.split) * HoWo + p
                                            : a.out + ((long)b * a.out_ctotal + a.out_coff + co0) * HoWo + p;
+    float bq[CT];  // (loads in front of the first store: see dwpw_row4_kernel's epilogue)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bq[c] = a.b[co0 + c];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        float v = acc[c] + a.b[co0 + c];
+        float v = acc[c] + bq[c];
         if (a.relu) v = fmaxf(v, 0.f);
         ob[(long)c * HoWo] = v;
     }
@@ -560,9 +580,12 @@ __global__ __launch_bounds__(256) void det_conv1_u8_kernel(const uint8_t *__rest
             for (int c = 0; c < 8; ++c) acc[c] = fmaf(v[ci][t], w[t * a.Cout + c], acc[c]);
     }
     float *ob = a.out + ((long)b * a.out_ctotal + a.out_coff) * HoWo + p;
+    float bq[8];  // (loads in front of the first store: see dwpw_row4_kernel's epilogue)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bq[c] = a.b[c];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        float o = acc[c] + a.b[c];
+        float o = acc[c] + bq[c];
         if (a.relu) o = fmaxf(o, 0.f);
         ob[(long)c * HoWo] = o;
     }
@@ -572,6 +595,7 @@ __global__ __launch_bounds__(256) void det_conv1_u8_kernel(const uint8_t *__rest
 struct HeadMulti {
     HeadArgs p[3];
 };
+template <int UNR>
 __global__ __launch_bounds__(256) void heads_kernel(HeadMulti mm) {
     const HeadArgs &a = mm.p[blockIdx.z];
     const long gp = (long)blockIdx.x * 256 + threadIdx.x;
@@ -585,7 +609,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadMulti mm) {
     for (int c = 0; c < 4; ++c) lc[c] = 0.f;
     const float *inb = a.in + (long)b * a.C * HW + p;
     // (sixteen loads in flight per thread: as a rolled loop every input channel was its own memory round trip - 32 us per launch at 32 frames)
-#pragma unroll 16
+#pragma unroll UNR
     for (int ci = 0; ci < a.C; ++ci) {
         const float x = inb[(long)ci * HW];
 #pragma unroll
@@ -604,9 +628,13 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadMulti mm) {
 #pragma unroll
             for (int c = 0; c < 20; ++c) ll[c] = fmaf(x, a.wl[ci * 20 + c], ll[c]);
         }
+        float blq[20];  // (in front of the first store: see dwpw_row4_kernel's epilogue)
 #pragma unroll
-        for (int c = 0; c < 20; ++c) a.ldm[an * 10 + c] = ll[c] + a.bl[c];
+        for (int c = 0; c < 20; ++c) blq[c] = a.bl[c];
+#pragma unroll
+        for (int c = 0; c < 20; ++c) a.ldm[an * 10 + c] = ll[c] + blq[c];
     }
+    const float bc0 = a.bc[0], bc1 = a.bc[1], bc2 = a.bc[2], bc3 = a.bc[3];  // (in front of the stores: see dwpw_row4_kernel's epilogue)
     floatx4 o0 = {lb[0] + a.bb[0], lb[1] + a.bb[1], lb[2] + a.bb[2], lb[3] + a.bb[3]};
     floatx4 o1 = {lb[4] + a.bb[4], lb[5] + a.bb[5], lb[6] + a.bb[6], lb[7] + a.bb[7]};
     *reinterpret_cast<floatx4 *>(a.loc + an * 4) = o0;
@@ -614,7 +642,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadMulti mm) {
     floatx4 cf;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {  // F.softmax(dim=-1) over the 2 classes (retinaface_trim.py:126): max-subtracted exp / sum
-        const float c0 = lc[2 * l] + a.bc[2 * l], c1 = lc[2 * l + 1] + a.bc[2 * l + 1];
+        const float c0 = lc[2 * l] + (l ? bc2 : bc0), c1 = lc[2 * l + 1] + (l ? bc3 : bc1);
         const float m = fmaxf(c0, c1);
         const float e0 = expf(c0 - m), e1 = expf(c1 - m);
         const float s = e0 + e1;
@@ -761,7 +789,11 @@ void launch_heads_multi(const HeadArgs *a, int n, hipStream_t s) {
         max_total = max_total > (long)a[i].B * a[i].H * a[i].W ? max_total : (long)a[i].B * a[i].H * a[i].W;
     }
     for (int i = n; i < 3; ++i) mm.p[i] = a[0];
-    hipLaunchKernelGGL(heads_kernel, dim3((unsigned)((max_total + 255) / 256), 1, n), dim3(256), 0, s, mm);
+    static const int unr = frt_tuning_env("FRT_HEADS_UNROLL") ? atoi(frt_tuning_env("FRT_HEADS_UNROLL")) : 16;  // (tuning build: input channels' loads in flight)
+    const dim3 grid((unsigned)((max_total + 255) / 256), 1, n);
+    if (unr == 64) hipLaunchKernelGGL(heads_kernel<64>, grid, dim3(256), 0, s, mm);
+    else if (unr == 32) hipLaunchKernelGGL(heads_kernel<32>, grid, dim3(256), 0, s, mm);
+    else hipLaunchKernelGGL(heads_kernel<16>, grid, dim3(256), 0, s, mm);
 }
 
 void launch_heads(const HeadArgs &a, hipStream_t s) { launch_heads_multi(&a, 1, s); }

@@ -246,12 +246,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(Conv3Mfma mm, int 
             const long pix = inside ? (long)oy * a.Wo + ox : 0;
             float *o1 = a.out + ((long)g.b * a.out_ctotal + a.out_coff) * HoWo + pix;
             float *o2 = a.out2 ? a.out2 + ((long)g.b * a.out2_ctotal + a.out2_coff - a.split) * HoWo + pix : o1;
+            float bq[CB][16];  // (in front of the first store: load / wait / store chains otherwise - the output may alias the biases for all the compiler knows)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    float v = acc[cb][e] + a.b[co < a.Cout ? co : 0];
+                    bq[cb][e] = a.b[co < a.Cout ? co : 0];
+                }
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    float v = acc[cb][e] + bq[cb][e];
                     if (a.relu) v = fmaxf(v, 0.f);
                     if (inside && co < a.Cout) (co < a.split ? o1 : o2)[co * HoWo] = v;
                     acc[cb][e] = 0.f;

@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
     extern __shared__ __attribute__((aligned(16))) char smem3h[];
     half_t *pbuf = reinterpret_cast<half_t *>(smem3h);        // [2][NPOS][ROWH]
     half_t *wbuf = pbuf + 2 * PATCH_H;                        // [9][32 NCB][ROWH]
+    __shared__ float sbias[3][64];                            // the levels' biases (read in every tile's epilogue: from global memory that was an L2 round trip per tile)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 192) {
+        const int lv = tid >> 6, co = tid & 63;
+        sbias[lv][co] = co < mm.p[lv].Cout ? mm.p[lv].b[co] : 0.f;
+    }
     const int r = lane & 31, hi = lane >> 5;
 
     const int nwg = gridDim.x;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    float v = acc[cb][e] + a.b[co < a.Cout ? co : 0];
+                    float v = acc[cb][e] + sbias[g.lv][co];
                     if (a.relu) v = fmaxf(v, 0.f);
                     if (inside && co < a.Cout && (!(FRT_C3H_ABL & 8) || v == 12345.678f)) (co < a.split ? o1 : o2)[co * HoWo] = v;
                     acc[cb][e] = 0.f;

@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "frt_kernels.h"
 
 namespace {
@@ -385,13 +387,39 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
     if (!mo.ok) return;
     const int HoWo = a.Ho * a.Wo;
     float *ob = a.out + (long)mo.b * a.Cout * HoWo + mo.oy * a.Wo + mo.ox;
+    // Round 5: the biases in front of the first store.  For all the compiler knows the output aliases them: it emitted load -> s_waitcnt
+    // vmcnt(0) -> store per channel, i.e. 16 CBW dependent memory round trips (each also waiting for the previous STORE to complete) at the end of
+    // every workgroup - the largest part of this kernel's 68 % of wave cycles in s_waitcnt (profiles/r04/r04x_det_pmc.txt).
+    float bq[CBW][16];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            bq[cb][e] = a.bp[co < a.Cout ? co : 0];  // (clamped, unconditional: a conditional load is a branch and a basic block of its own)
+        }
+    if (co_base + CBW * 32 <= a.Cout) {  // (uniform; every shape of the network: straight-line stores, no per-channel branch)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                float v = acc[cb][e] + bq[cb][e];
+                if (a.relu) v = fmaxf(v, 0.f);
+#ifdef FRT_ABLATE
+                if ((abl & 1) && v != 12345.678f) continue;
+#endif
+                ob[(long)co * HoWo] = v;
+            }
+        return;
+    }
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int co = co_base + cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
             if (co < a.Cout) {
-                float v = acc[cb][e] + a.bp[co];
+                float v = acc[cb][e] + bq[cb][e];
                 if (a.relu) v = fmaxf(v, 0.f);
 #ifdef FRT_ABLATE
                 if ((abl & 1) && v != 12345.678f) continue;
@@ -403,7 +431,7 @@ __global__ __launch_bounds__(64 * NPW * NCW) void dwpw_mfma_kernel(DwPwArgs a, i
 
 // ---------------------------------------------------------------- plain 1x1 conv, one wave = 32 pixels x CBW*32 output channels
 template <int CBW, bool SPLIT = false>
-__global__ __launch_bounds__(256, (CBW == 1 && SPLIT) ? 4 : 2) void pw_mfma_kernel(DwPwArgs a, int n_pix_groups) {  // (2nd: waves per SIMD asked of the register allocator)
+__global__ __launch_bounds__(256, SPLIT ? (CBW == 1 ? 4 : 3) : 2) void pw_mfma_kernel(DwPwArgs a, int n_pix_groups) {  // (2nd: waves per SIMD asked of the register allocator)
     // Persistent waves (round 4): a wave lives ~ 4 us here, 70 % of it in s_waitcnt, and the counters put 1.5 waves per CU in flight on average
     // (profiles/r04/r04x_det_pmc.txt).  The grid is now what fits the chip at once and every wave walks its share of the (pixel group, channel
     // group) items; with the scalar-base addressing (240 -> 180 / 168 -> 104 registers) that is 61 -> 59 us for the 64-channel lateral at
@@ -560,28 +588,41 @@ __global__ __launch_bounds__(256, (CBW == 1 && SPLIT) ? 4 : 2) void pw_mfma_kern
     asm volatile("v_mov_b32 %0, %1" : "=v"(os5) : "s"(HW * 20));
     asm volatile("v_mov_b32 %0, %1" : "=v"(as1) : "s"((int)add_cs * 4));
     asm volatile("v_mov_b32 %0, %1" : "=v"(as5) : "s"((int)add_cs * 20));
+    // Round 5: STRAIGHT-LINE epilogues.  With a per-channel "co < Cout" around every load and store each of them became a basic block of its own and
+    // the compiler's waits degenerated to "s_waitcnt vmcnt(0)" in front of every store - 32 stores per item, each waiting for the previous one to
+    // be acknowledged by memory: most of the 15 us an item took (profiles/r04/r04x_det_pmc.txt: 70 % of the wave cycles in s_waitcnt).  The channel
+    // range of an item is whole for every shape of the network (uniform test), and "has an upsample-add source" is a compile-time variant.
+    auto epilogue = [&](auto has_add_c, auto full_c) {
+        constexpr bool HAS_ADD = decltype(has_add_c)::value, FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int cb = 0; cb < CBW; ++cb) {  // (one 32-channel block at a time: 32 live values instead of 64)
-        float bias_v[16], add_v[16];
+        for (int cb = 0; cb < CBW; ++cb) {  // (one 32-channel block at a time: 32 live values instead of 64)
+            float bias_v[16], add_v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int cu = cb * 32 + (e & 3) + 8 * (e >> 2);  // uniform part of the channel
-            const bool cok = co_l + cu < a.Cout;
-            bias_v[e] = cok ? *reinterpret_cast<const float *>(bp_c + (size_t)cu * 4 + (size_t)(unsigned)(co_l * 4)) : 0.f;
-            add_v[e] = (cok && addb) ? *reinterpret_cast<const float *>(add_c + (size_t)ao) : 0.f;
-            ao += (e & 3) == 3 ? as5 : as1;
-        }
+            for (int e = 0; e < 16; ++e) {
+                const int cu = cb * 32 + (e & 3) + 8 * (e >> 2);  // uniform part of the channel
+                const bool cok = FULL || co_l + cu < a.Cout;
+                bias_v[e] = *reinterpret_cast<const float *>(bp_c + (size_t)(cok ? cu : 0) * 4 + (size_t)(unsigned)((cok ? co_l : 0) * 4));  // (clamped, unconditional)
+                if (HAS_ADD) add_v[e] = *reinterpret_cast<const float *>(add_c + (size_t)(cok ? ao : 0u));
+                ao += (e & 3) == 3 ? as5 : as1;
+            }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int cu = cb * 32 + (e & 3) + 8 * (e >> 2);
-            if (co_l + cu < a.Cout) {
+            for (int e = 0; e < 16; ++e) {
+                const int cu = cb * 32 + (e & 3) + 8 * (e >> 2);
                 float v = acc[cb][e] + bias_v[e];
                 if (a.relu) v = fmaxf(v, 0.f);
-                if (addb) v += add_v[e];
-                *reinterpret_cast<float *>(out_c + (size_t)oo) = v;
+                if (HAS_ADD) v += add_v[e];
+                if (FULL || co_l + cu < a.Cout) *reinterpret_cast<float *>(out_c + (size_t)oo) = v;
+                oo += (e & 3) == 3 ? os5 : os1;
             }
-            oo += (e & 3) == 3 ? os5 : os1;
         }
+    };
+    const bool full = co_base + CBW * 32 <= a.Cout;
+    if (addb) {
+        if (full) epilogue(std::true_type{}, std::true_type{});
+        else epilogue(std::true_type{}, std::false_type{});
+    } else {
+        if (full) epilogue(std::false_type{}, std::true_type{});
+        else epilogue(std::false_type{}, std::false_type{});
     }
     }  // persistent item loop
 }

@@ -538,6 +538,11 @@ __global__ __launch_bounds__(256) void dwpw_pix_kernel(WaveArgs a, int B, int H,
             }
         }
     }
+    float bq[NCB][16];  // (in front of the first store: the output may alias them for all the compiler knows - load / wait / store chains otherwise)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bq[cb][e] = a.bp[cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const long px = p0 + 32 * t + r;
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(256) void dwpw_pix_kernel(WaveArgs a, int B, int H,
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = cb * 32 + (e & 3) + 8 * (e >> 2);
-                ob[(long)co * HoWo] = fmaxf(acc[t][cb][e] + a.bp[co + 4 * hi], 0.f);
+                ob[(long)co * HoWo] = fmaxf(acc[t][cb][e] + bq[cb][e], 0.f);
             }
     }
 }
