@@ -119,6 +119,8 @@ ABI = {
     "frt_pipeline_set_stream": (_i, [_vp, _vp]),
     "frt_pipeline_set_overlap": (_i, [_vp, _i]),
     "frt_pipeline_set_graph": (_i, [_vp, _i]),
+    "frt_pipeline_set_pairing": (_i, [_vp, _i]),
+    "frt_pipeline_pairing_stats": (_i, [_vp, _vp, _vp]),
     "frt_detector_has_landmarks": (_i, [_vp]),
     "frt_detector_find_faces_landmarks": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _vp]),
     "frt_detector_infer_landmarks": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -713,6 +715,16 @@ class Pipeline:
     def set_graph(self, enable):
         """hipGraph replay of repeated calls (default on)."""
         _check(lib.frt_pipeline_set_graph(self._h, 1 if enable else 0))
+
+    def set_pairing(self, enable):
+        """Crop + recogniser + match of two consecutive calls as one pass (frt_pipeline_set_pairing: results complete one call later)."""
+        _check(lib.frt_pipeline_set_pairing(self._h, 1 if enable else 0))
+
+    def pairing_stats(self):
+        """-> (recogniser passes that served two calls, passes that served one)."""
+        a, b = ctypes.c_long(0), ctypes.c_long(0)
+        _check(lib.frt_pipeline_pairing_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def set_align(self, enable):
         """Optional 5-point aligned crop instead of the reference's bbox crop (needs a detector blob with LandmarkHead)."""

@@ -1552,7 +1552,10 @@ struct frt_pipeline {
     float *d_chw2 = nullptr;
     hipEvent_t ev_serial = nullptr;  // end of the last serial (profiled) call while overlap is on
     bool serial_pending = false;
-    static constexpr int NSLOT = 3;  // calls in flight between the start of D and the end of M (2: 32.5k, 3: 33.6k, 4: 33.6k faces/s)
+    // calls in flight between the start of D and the end of M (2: 32.5k, 3: 33.6k, 4: 33.6k faces/s).  Six since pairing exists: paired calls finish
+    // two at a time and one call late, so two pairs in the later stages + the detector a call or two ahead need six slots (with three the detector
+    // of call b + 5 waited for the pair (b + 2, b + 3) and the recogniser passes ran one after the other: 0.84 instead of 0.74 ms per 4-frame call)
+    static constexpr int NSLOT = 6;
     hipEvent_t ev_det[NSLOT] = {}, ev_emb[NSLOT] = {}, ev_done[NSLOT] = {};
     float *slot_embeds[NSLOT] = {};
     int *slot_valid[NSLOT] = {};
@@ -1573,7 +1576,7 @@ struct frt_pipeline {
 
     // ---- asynchronous host boundary (frt_pipeline_submit / frt_pipeline_wait): NBUF staging sets so that the H2D copy of batch
     //      b+1 (copy_stream, the SDMA engine) and the D2H of batch b-1 run under the stages of batch b
-    static constexpr int NBUF = 4;
+    static constexpr int NBUF = 8;  // (4 until pairing: up to seven batches between submit and wait)
     struct AsyncBuf {
         uint8_t *d_frames = nullptr;
         frt_face_result *d_results = nullptr;
@@ -1589,6 +1592,35 @@ struct frt_pipeline {
     uint8_t *crops_req = nullptr;    // set by submit for the next run(): the crop kernel also writes the u8 crops there
     long next_ticket = 0;
     std::mutex async_mu;
+
+    // ---- pairing (frt_pipeline_set_pairing; off by default).  A recogniser pass over 16 faces costs 0.59 ms, one over 32 faces 0.92 ms
+    //      (profiles/r05p_small_batch_layers.txt: below ~ 64 faces a pass is a chain of launch latencies, not work), and one match call scans
+    //      the gallery once whatever the number of queries.  With pairing on, the crop + recogniser + match stages of TWO consecutive calls
+    //      run as one pass: a call's detector stage is queued at the call as always, its later stages wait for the next call (or for a
+    //      flush: frt_pipeline_wait on its ticket, frt_pipeline_sync, any mode switch).  Nothing about a result changes except when it is
+    //      ready - one call later - and which batch-size class of recogniser kernels produced it (the class of the two calls' faces together).
+    //      A call is only ever deferred when it could be paired: both calls' face slots together must fit this pipeline's max_frames *
+    //      max_faces and the recogniser's max_batch, i.e. create the pipeline for twice the frames a call carries.
+    struct CallRec {
+        bool on = false;
+        unsigned call = 0;
+        int slot = 0, n = 0;
+        const uint8_t *frames = nullptr;
+        frt_face_result *results = nullptr;
+        float *embeds = nullptr;
+        uint8_t *crops = nullptr;
+        // host side of frt_pipeline_submit: the downloads of this call's results follow its match stage, wherever that is queued
+        AsyncBuf *ab = nullptr;
+        frt_face_result *h_results = nullptr;
+        float *h_embeds = nullptr;
+        uint8_t *h_crops = nullptr;
+        long ticket = -1;
+    };
+    CallRec pend;      // the call whose later stages are still to be queued
+    CallRec host_req;  // set by submit for the next run(): staging set + host destinations
+    bool pairing = false;
+    unsigned epass = 0;  // recogniser passes queued so far (activation set / stream of the next one)
+    long paired_passes = 0, single_passes = 0;
     void ensure_async() {
         if (copy_stream) return;
         // The upload stream sits in the stage streams' priority class (its own hardware-queue pool): as a normal-priority stream it is
@@ -1815,34 +1847,31 @@ struct frt_pipeline {
         hipStream_t s = stream;
         const DetGeom &g = det->g;
         const int F = n * max_faces;
-        const unsigned call = seq++;
-        const int slot = (int)(call % NSLOT);
         // Three-stage software pipeline over consecutive calls (stage-profiling mode and overlap off: everything serially on `s`):
         //   D  detector of call b+1          (fp32 / split-fp16 MFMA + latency-bound stencils)
         //   E  crop + recogniser of call b   (fp16 MFMA / LDS bound)
         //   M  match + pack of call b-1      (HBM bound: streams the 1 GB fp16 shadow gallery)
         // The caller's stream only JOINS: it waits for M of this call, so everything the caller enqueues after the call sees the
-        // results, exactly as if the call had run on that stream.  Boxes, embeddings and validity flags live in two slots.
+        // results, exactly as if the call had run on that stream.  Boxes, embeddings and validity flags live in NSLOT slots.
         // Profiled calls (frt_profile_enable 1 or 2) run serially on `s`: HIP events around a launch only measure the kernel when
         // no other stream competes for the dispatch (with four streams in flight the bracketed time was 2.7x the kernel time).
         const bool pipe3 = overlap && g_prof_kind == 0 && !serial_call;
+        // pairing: this call's later stages wait for the next call - or run together with the waiting call's
+        const bool pairable = pairing && pipe3 && 2 * F <= F_cap && 2 * F <= emb->max_batch;
+        if (pend.on && !(pairable && pend.n == n)) flush_pending();
+        const unsigned call = seq++;
+        const int slot = (int)(call % NSLOT);
         if (pipe3 && serial_pending) {  // a serial call used the shared detector / recogniser buffers on `s`: order the stages behind it
             HIPCHK(hipStreamWaitEvent(det_stream, ev_serial, 0));
             HIPCHK(hipStreamWaitEvent(emb_stream, ev_serial, 0));
             HIPCHK(hipStreamWaitEvent(emb_stream2, ev_serial, 0));
             serial_pending = false;
         }
-        const int eset = (pipe3 && dual_embed && F <= emb->max_batch) ? (int)(call & 1u) : 0;  // activation set / stream of this call's recogniser pass
-        hipStream_t ds = pipe3 ? det_stream : s, es = pipe3 ? (eset ? emb_stream2 : emb_stream) : s;
-        // match + pack follow the recogniser pass on ITS stream (they overlap the other set's pass and the next detector pass): a stream
-        // of their own measured 0.6 % slower and is one more stream competing for the four hardware queues
-        hipStream_t ms = es;
-        float *chw = eset ? d_chw2 : d_chw;
+        hipStream_t ds = pipe3 ? det_stream : s;
         if (pipe3 && call >= (unsigned)NSLOT) {
-            // slot buffers are free again once M of the call two back is done.  NB the frames must be valid when the call is made:
+            // slot buffers are free again once M of the call NSLOT back is done.  NB the frames must be valid when the call is made:
             // making D wait for prior work on `s` would serialise the stages.
             HIPCHK(hipStreamWaitEvent(ds, ev_done[slot], 0));
-            HIPCHK(hipStreamWaitEvent(es, ev_done[slot], 0));
         }
         if (ev_frames) {  // frt_pipeline_submit: the frames arrive on the copy stream
             HIPCHK(hipStreamWaitEvent(ds, ev_frames, 0));  // (crop + recogniser follow the detector through ev_det[slot])
@@ -1856,11 +1885,18 @@ struct frt_pipeline {
             HIPCHK(hipEventRecord(ev_input, s));
             HIPCHK(hipStreamWaitEvent(ds, ev_input, 0));
         }
-        const bool have_gallery = mat && mat->N > 0;
-        const unsigned gen = mat ? mat->generation : 0u;
-        uint8_t *crops_out = crops_req;  // (one call only)
+        CallRec cur = host_req;  // (staging set + host destinations when the call came through frt_pipeline_submit)
+        host_req = CallRec{};
+        cur.on = true;
+        cur.call = call;
+        cur.slot = slot;
+        cur.n = n;
+        cur.frames = frames_dev;
+        cur.results = results_dev;
+        cur.embeds = embeds_dev;
+        cur.crops = crops_req;  // (one call only)
         crops_req = nullptr;
-        const int akey = (align ? 1 : 0) | (crops_out ? 2 : 0);
+        const int akey = (align ? 1 : 0) | (cur.crops ? 2 : 0);
         run_part(GraphKey{0, frames_dev, nullptr, nullptr, n, slot, akey, 0u}, ds, [&](hipStream_t st) {
 #ifdef FRT_TUNING
             // timing build: FRT_PIPE_ABLATE bit 0 = no detector network after the first calls (post-processing re-reads the old head outputs),
@@ -1873,67 +1909,132 @@ struct frt_pipeline {
         });
         HIPCHK(hipEventRecord(det->ev_busy, ds));  // object-level detector calls wait for this (frt_detector::wait_idle)
         det->busy = true;
-        if (pipe3) {
-            HIPCHK(hipEventRecord(ev_det[slot], ds));
-            HIPCHK(hipStreamWaitEvent(es, ev_det[slot], 0));
+        if (pipe3) HIPCHK(hipEventRecord(ev_det[slot], ds));
+        if (pairable) {
+            if (!pend.on) {  // wait for a partner: nothing else is queued for this call now (the caller's stream joins with the partner's call)
+                pend = cur;
+                return;
+            }
+            CallRec two[2] = {pend, cur};
+            pend = CallRec{};
+            later_stages(two, 2, pipe3);
+            return;
         }
-        const frt_bbox *boxes = slot_boxes[slot];
-        const int *nout = slot_nout[slot];
-        float *emb_slot = slot_embeds[slot];
-        int *valid = slot_valid[slot];
-        // (a pass on activation set k follows the pass two calls back on the same set: ordered by its stream and by ev_done[slot])
-        run_part(GraphKey{1, frames_dev, nullptr, nullptr, n, slot, akey, (unsigned)eset}, es, [&](hipStream_t st) {
-            if (align) {
-                ProfScope ps(2, "align_faces", (double)F * 112 * 112 * 3, st);
-                launch_align_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, slot_landmarks[slot],
-                                   nout, max_faces, F, 0, crops_out, chw, valid, st);
-            } else {
-                ProfScope ps(2, "crop_faces", (double)F * 112 * 112 * 3, st);
-                launch_crop_faces(frames_dev, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, boxes, nout, max_faces,
-                                  F, 0, 112, 112, crops_out, chw, valid, st);
+        later_stages(&cur, 1, pipe3);
+    }
+
+    // the waiting call's crop + recogniser + match on their own (its partner never came)
+    void flush_pending() {
+        if (!pend.on) return;
+        CallRec one = pend;
+        pend = CallRec{};
+        later_stages(&one, 1, true);  // (a call is only ever deferred in the three-stream mode: its detector stage sits on det_stream)
+    }
+
+    // E and M of one call, or of two consecutive calls as ONE recogniser pass and ONE match call (pairing)
+    void later_stages(const CallRec *c, int nc, bool pipe3) {
+        hipStream_t s = stream;
+        const DetGeom &g = det->g;
+        int Fc[2] = {0, 0}, Ftot = 0;
+        for (int i = 0; i < nc; ++i) {
+            Fc[i] = c[i].n * max_faces;
+            Ftot += Fc[i];
+        }
+        (nc == 2 ? paired_passes : single_passes) += 1;
+        const int eset = (pipe3 && dual_embed && Ftot <= emb->max_batch) ? (int)(epass++ & 1u) : 0;  // activation set / stream of this recogniser pass
+        hipStream_t es = pipe3 ? (eset ? emb_stream2 : emb_stream) : s;
+        // match + pack follow the recogniser pass on ITS stream (they overlap the other set's pass and the next detector pass): a stream
+        // of their own measured 0.6 % slower and is one more stream competing for the four hardware queues
+        hipStream_t ms = es;
+        float *chw = eset ? d_chw2 : d_chw;
+        // embeddings and validity flags of the pass: the first call's slot (two calls together fit one slot: run() checked)
+        float *emb_slot = slot_embeds[c[0].slot];
+        int *valid = slot_valid[c[0].slot];
+        for (int i = 0; i < nc; ++i) {
+            if (pipe3 && c[i].call >= (unsigned)NSLOT) HIPCHK(hipStreamWaitEvent(es, ev_done[c[i].slot], 0));
+            if (pipe3) HIPCHK(hipStreamWaitEvent(es, ev_det[c[i].slot], 0));
+        }
+        const bool have_gallery = mat && mat->N > 0;
+        const unsigned gen = mat ? mat->generation : 0u;
+        const int akey = (align ? 1 : 0) | (c[0].crops ? 2 : 0);
+        // (a pass on activation set k follows the previous pass on the same set: ordered by its stream)
+        auto stage_e = [&](hipStream_t st) {
+            int f_off = 0;
+            for (int i = 0; i < nc; ++i) {
+                const int sl = c[i].slot;
+                if (align) {
+                    ProfScope ps(2, "align_faces", (double)Fc[i] * 112 * 112 * 3, st);
+                    launch_align_faces(c[i].frames, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, slot_landmarks[sl],
+                                       slot_nout[sl], max_faces, Fc[i], 0, c[i].crops, chw + (size_t)f_off * 3 * 112 * 112, valid + f_off, st);
+                } else {
+                    ProfScope ps(2, "crop_faces", (double)Fc[i] * 112 * 112 * 3, st);
+                    launch_crop_faces(c[i].frames, g.frame_h, g.frame_w, (size_t)g.frame_w * 3, (size_t)g.frame_w * g.frame_h * 3, slot_boxes[sl],
+                                      slot_nout[sl], max_faces, Fc[i], 0, 112, 112, c[i].crops, chw + (size_t)f_off * 3 * 112 * 112, valid + f_off, st);
+                }
+                f_off += Fc[i];
             }
 #ifdef FRT_TUNING
             static const int pipe_abl = getenv("FRT_PIPE_ABLATE") ? atoi(getenv("FRT_PIPE_ABLATE")) : 0;
-            if (!(pipe_abl & 2) || call < 8u)
+            if (!(pipe_abl & 2) || c[0].call < 8u)
 #endif
-            for (int f0 = 0; f0 < F; f0 += emb->max_batch) {
-                const int nf = std::min(emb->max_batch, F - f0);
+            for (int f0 = 0; f0 < Ftot; f0 += emb->max_batch) {
+                const int nf = std::min(emb->max_batch, Ftot - f0);
                 emb->forward_set(eset, chw + (size_t)f0 * 3 * 112 * 112, nf, valid + f0, emb_slot + (size_t)f0 * 512, st);
             }
-        });
+        };
+        if (nc == 1) run_part(GraphKey{1, c[0].frames, nullptr, nullptr, c[0].n, c[0].slot, akey, (unsigned)eset}, es, stage_e);
+        else stage_e(es);
         HIPCHK(hipEventRecord(emb->ev_busy[eset], es));
         emb->busy[eset] = true;
         if (pipe3) {
-            HIPCHK(hipEventRecord(ev_emb[slot], es));
-            HIPCHK(hipStreamWaitEvent(ms, ev_emb[slot], 0));
+            HIPCHK(hipEventRecord(ev_emb[c[0].slot], es));
+            HIPCHK(hipStreamWaitEvent(ms, ev_emb[c[0].slot], 0));
         }
         // consecutive calls' match stages sit on DIFFERENT streams (their recogniser passes') but share the matcher's scratch and this
         // pipeline's d_idx / d_sim: each one starts behind the previous one's end (they rarely meet: 0.3 ms every 3.3 ms, half a
         // period apart - which is exactly why an unordered pair showed up as one failing equality test in several hundred)
         // (the serial branch too: an object-level frt_matcher_top1_dev / topk_dev on another stream shares d_partial / the pair lists with this stage)
         if (mat && mat->busy) HIPCHK(hipStreamWaitEvent(ms, mat->ev_busy, 0));
-        run_part(GraphKey{2, nullptr, results_dev, embeds_dev, n, slot, akey, gen}, ms, [&](hipStream_t st) {
+        auto stage_m = [&](hipStream_t st) {
 #ifdef FRT_TUNING
             static const int pipe_abl = getenv("FRT_PIPE_ABLATE") ? atoi(getenv("FRT_PIPE_ABLATE")) : 0;
-            if (!(pipe_abl & 4) || call < 8u)
+            if (!(pipe_abl & 4) || c[0].call < 8u)
 #endif
-            if (have_gallery) mat->top1_dev(emb_slot, F, d_idx, d_sim, st);
-            {
-                ProfScope ps(2, "pack_results", (double)F, st);
-                launch_pack_results(boxes, nout, valid, have_gallery ? d_idx : nullptr, have_gallery ? d_sim : nullptr, max_faces, F, results_dev, st);
+            if (have_gallery) mat->top1_dev(emb_slot, Ftot, d_idx, d_sim, st);
+            int f_off = 0;
+            for (int i = 0; i < nc; ++i) {
+                const int sl = c[i].slot;
+                {
+                    ProfScope ps(2, "pack_results", (double)Fc[i], st);
+                    launch_pack_results(slot_boxes[sl], slot_nout[sl], valid + f_off, have_gallery ? d_idx + f_off : nullptr, have_gallery ? d_sim + f_off : nullptr,
+                                        max_faces, Fc[i], c[i].results, st);
+                }
+                if (c[i].embeds)
+                    HIPCHK(hipMemcpyAsync(c[i].embeds, emb_slot + (size_t)f_off * 512, sizeof(float) * 512 * Fc[i], hipMemcpyDeviceToDevice, st));
+                f_off += Fc[i];
             }
-            if (embeds_dev) HIPCHK(hipMemcpyAsync(embeds_dev, emb_slot, sizeof(float) * 512 * F, hipMemcpyDeviceToDevice, st));
-        });
+        };
+        if (nc == 1) run_part(GraphKey{2, nullptr, c[0].results, c[0].embeds, c[0].n, c[0].slot, akey, gen}, ms, stage_m);
+        else stage_m(ms);
         if (mat) {
             HIPCHK(hipEventRecord(mat->ev_busy, ms));
             mat->busy = true;
         }
         if (pipe3) {
-            HIPCHK(hipEventRecord(ev_done[slot], ms));
-            HIPCHK(hipStreamWaitEvent(s, ev_done[slot], 0));  // the caller's stream joins here
+            for (int i = 0; i < nc; ++i) HIPCHK(hipEventRecord(ev_done[c[i].slot], ms));
+            HIPCHK(hipStreamWaitEvent(s, ev_done[c[0].slot], 0));  // the caller's stream joins here
         } else if (overlap) {
             HIPCHK(hipEventRecord(ev_serial, s));
             serial_pending = true;
+        }
+        // calls that came through frt_pipeline_submit: their downloads follow the join
+        for (int i = 0; i < nc; ++i) {
+            if (!c[i].ab) continue;
+            AsyncBuf &b = *c[i].ab;
+            HIPCHK(hipMemcpyAsync(c[i].h_results, b.d_results, sizeof(frt_face_result) * Fc[i], hipMemcpyDeviceToHost, s));
+            if (c[i].h_embeds) HIPCHK(hipMemcpyAsync(c[i].h_embeds, b.d_embeds, sizeof(float) * 512 * Fc[i], hipMemcpyDeviceToHost, s));
+            if (c[i].h_crops) HIPCHK(hipMemcpyAsync(c[i].h_crops, b.d_crops, (size_t)Fc[i] * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipEventRecord(b.ev_out, s));
         }
     }
 };
@@ -2927,6 +3028,8 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     delete p;
 }
 
+static void pipeline_flush_locked(frt_pipeline *p);
+
 // Caller holds p->run_mu.
 static void pipeline_lock_run(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev) {
     if (n_frames < 1 || n_frames > p->max_frames) raise(FRT_ERR_CAPACITY, "pipeline: more frames than max_frames");
@@ -2971,6 +3074,7 @@ int frt_pipeline_check_overlap(frt_pipeline *p, float *ratio_out) {
         use_device(p->det->device);
         std::lock_guard<std::mutex> la(p->async_mu);  // same order as pipeline_submit_impl: async_mu, then run_mu
         std::lock_guard<std::mutex> lk(p->run_mu);
+        pipeline_flush_locked(p);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
@@ -2996,6 +3100,10 @@ int frt_pipeline_sync(frt_pipeline *p) {
     return guarded([&] {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
+        {
+            std::lock_guard<std::mutex> lk(p->run_mu);
+            pipeline_flush_locked(p);
+        }
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
@@ -3009,6 +3117,7 @@ int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream) {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
+        pipeline_flush_locked(p);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
@@ -3022,6 +3131,7 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable) {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
+        pipeline_flush_locked(p);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
@@ -3037,6 +3147,7 @@ int frt_pipeline_set_graph(frt_pipeline *p, int enable) {
         if (!p) raise(FRT_ERR_INVALID, "null argument");
         std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
+        pipeline_flush_locked(p);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
@@ -3052,11 +3163,31 @@ int frt_pipeline_set_align(frt_pipeline *p, int enable) {
         if (enable && !p->det->has_landmarks) raise(FRT_ERR_FORMAT, "pipeline: alignment needs a detector blob with the LandmarkHead");
         std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
+        pipeline_flush_locked(p);
         HIPCHK(hipStreamSynchronize(p->det_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream));
         HIPCHK(hipStreamSynchronize(p->emb_stream2));
         HIPCHK(hipStreamSynchronize(p->stream));
         p->align = enable != 0;
+    });
+}
+
+int frt_pipeline_set_pairing(frt_pipeline *p, int enable) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(p->run_mu);
+        use_device(p->det->device);
+        pipeline_flush_locked(p);
+        p->pairing = enable != 0;
+    });
+}
+
+int frt_pipeline_pairing_stats(frt_pipeline *p, long *paired_passes, long *single_passes) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(p->run_mu);
+        if (paired_passes) *paired_passes = p->paired_passes;
+        if (single_passes) *single_passes = p->single_passes;
     });
 }
 
@@ -3078,7 +3209,7 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     // overlap with: upload, detector, recogniser, match and download go down ONE stream - no stream-to-stream event hand-overs on its
     // critical path (5 of them otherwise; one 4-face call 1.02 -> 0.94 ms, profiles/r03/r03u_sync_overlap.txt).  Calls that arrive while
     // another is in flight take the stage streams as before (and are ordered behind this one through ev_serial).
-    bool lone = synchronous && p->overlap;
+    bool lone = synchronous && p->overlap && !p->pend.on;
     for (int i = 0; lone && i < frt_pipeline::NBUF; ++i)
         if (p->abuf[i].ticket >= 0 && i != (int)(ticket % frt_pipeline::NBUF) && hipEventQuery(p->abuf[i].ev_out) != hipSuccess) lone = false;
     if (lone) {
@@ -3090,23 +3221,36 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     }
     p->serial_call = lone;
     p->crops_req = crops_host ? b.d_crops : nullptr;
+    // the downloads and the "results have left" event are queued by the pipeline behind this call's match stage - now, or (pairing) with the next call
+    p->host_req = frt_pipeline::CallRec{};
+    p->host_req.ab = &b;
+    p->host_req.h_results = results;
+    p->host_req.h_embeds = embeds_out;
+    p->host_req.h_crops = crops_host;
+    p->host_req.ticket = ticket;
     try {
         pipeline_lock_run(p, b.d_frames, n_frames, b.d_results, embeds_out ? b.d_embeds : nullptr);
     } catch (...) {
         p->ev_frames = nullptr;
         p->crops_req = nullptr;
+        p->host_req = frt_pipeline::CallRec{};
         p->serial_call = false;
         throw;
     }
     p->serial_call = false;
-    const int F = n_frames * p->max_faces;
-    HIPCHK(hipMemcpyAsync(results, b.d_results, sizeof(frt_face_result) * F, hipMemcpyDeviceToHost, s));
-    if (embeds_out) HIPCHK(hipMemcpyAsync(embeds_out, b.d_embeds, sizeof(float) * 512 * F, hipMemcpyDeviceToHost, s));
-    if (crops_host) HIPCHK(hipMemcpyAsync(crops_host, b.d_crops, (size_t)F * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(b.ev_out, s));
     b.ticket = ticket;
     p->next_ticket = ticket + 1;
     return ticket;
+}
+
+// Caller holds p->run_mu: queue the later stages of a call that is waiting for a partner (pairing).
+static void pipeline_flush_locked(frt_pipeline *p) {
+    if (!p->pend.on) return;
+    std::lock_guard<std::mutex> l1(p->det->mu);
+    std::lock_guard<std::mutex> l2(p->emb->mu);
+    std::unique_lock<std::mutex> l3;
+    if (p->mat) l3 = std::unique_lock<std::mutex>(p->mat->mu);
+    p->flush_pending();
 }
 
 static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
@@ -3117,6 +3261,10 @@ static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
         if (ticket < 0 || ticket >= p->next_ticket) raise(FRT_ERR_INVALID, "pipeline: unknown ticket");
         frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
         if (b.ticket > ticket) return;  // its staging set was reused, which submit only does after that batch completed
+        {
+            std::lock_guard<std::mutex> lr(p->run_mu);
+            if (p->pend.on && p->pend.ticket == ticket) pipeline_flush_locked(p);  // pairing: nobody came to share its recogniser pass
+        }
         ev = b.ev_out;
     }
     wait_event_spinning(ev);

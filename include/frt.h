@@ -319,6 +319,22 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
  * and mode repeat is captured on its second occurrence and replayed afterwards; callers that never repeat their buffers stay
  * on eager launches.  Automatically off while frt_profile_enable() records events. */
 int frt_pipeline_set_graph(frt_pipeline *p, int enable);
+/* Pairing of consecutive calls (default OFF; no reference counterpart - the reference answers one request at a time, src/app.cpp:243-287).
+ * Below ~ 64 faces a recogniser pass is a chain of launch latencies, not work: 16 faces cost 0.59 ms, 32 faces 0.92 ms, and one match call
+ * scans the gallery once whatever the number of queries.  With pairing on, the crop + recogniser + match stages of TWO consecutive calls run
+ * as ONE pass: a call's detector stage is queued at the call as always; its later stages are queued with the next call - or alone at a
+ * flush: frt_pipeline_wait on its ticket, frt_pipeline_sync, any frt_pipeline_set_*.  What changes for the caller:
+ *   - the results of a call are complete one call later: on the frt_pipeline_run_dev path the pipeline stream joins them at the NEXT call (or
+ *     at frt_pipeline_sync), not at the call itself; frt_pipeline_submit / frt_pipeline_wait keep their contract (wait flushes when needed);
+ *   - frames handed to frt_pipeline_run_dev must stay valid until that later join;
+ *   - the embeddings come from the recogniser kernels chosen for BOTH calls' faces together (tile shapes follow the number of faces per pass):
+ *     boxes, validity and matched rows are the unpaired pipeline's, embeddings agree with it to fp16 rounding (cosine >= 1 - 1e-5; the same
+ *     relation as between any two batch sizes, tests/test_gpu_embedder.py, tests/test_gpu_pipeline.py).
+ * A call is only deferred when it can be paired: twice its face slots must fit max_frames * max_faces of the pipeline and the recogniser's
+ * max_batch (create the pipeline for twice the frames a call carries); other calls run as without pairing.  frt_pipeline_pairing_stats counts
+ * the recogniser passes that served two calls and those that served one. */
+int frt_pipeline_set_pairing(frt_pipeline *p, int enable);
+int frt_pipeline_pairing_stats(frt_pipeline *p, long *paired_passes_out, long *single_passes_out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Request coalescing (opt-in).  The reference answers ONE frame per request (src/app.cpp:293-352) from a Crow server that runs

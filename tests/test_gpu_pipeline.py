@@ -470,3 +470,98 @@ def test_stream_overlap_self_check_reports_a_clean_pipeline(frt, synth, blobs):
     pipe.close()
     det.close()
     rec.close()
+
+
+def test_pairing_of_consecutive_calls_changes_nothing_but_the_pass_count(frt, synth, blobs):
+    """frt_pipeline_set_pairing: crop + recogniser + match of two consecutive calls as ONE pass.  Four frames x four face slots per call = 16
+    faces, 32 per paired pass: the two sizes take different tile shapes of the recogniser kernels, so embeddings agree to fp16 rounding (cosine
+    >= 1 - 1e-5), everything else - boxes, validity, the matched rows - is identical to the unpaired pipeline; the submit / wait contract holds
+    (waiting on the ticket of a call that is still waiting for a partner flushes it), and so does the device-resident path."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 4, 4, 320, 320
+
+    def same(got, want):  # records: everything exact but the similarity, which follows the embedding
+        got, want = np.asarray(got).view(frt.RESULT_DTYPE), np.asarray(want).view(frt.RESULT_DTYPE)
+        return all(np.array_equal(got[k], want[k]) for k in ("x1", "y1", "x2", "y2", "frame", "match_idx", "valid")) and \
+            float(np.abs(got["match_sim"] - want["match_sim"]).max()) < 2e-4
+
+    def same_emb(got, want):
+        n = np.linalg.norm(want, axis=1) > 0.5
+        return np.array_equal(got[~n], want[~n]) and float((got[n] * want[n]).sum(1).min(initial=1.0)) > 1 - 1e-5 and float(np.abs(got - want).max()) < 2e-3
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), 2 * B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=2 * B * K, maxFacesPerScene=K)
+    rec.setGallery(synth.make_gallery(3000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, 2 * B)                       # room for two calls' face slots: the condition for pairing
+    n_batches = 7                                              # odd: the last call finds no partner
+    batches = [synth.make_frames(B, H, W, start=5 * i) for i in range(n_batches)]
+    pinned = [torch.from_numpy(b).pin_memory() for b in batches]
+
+    def through_submit(order):
+        res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in batches]
+        emb = [torch.zeros(B * K, 512).pin_memory() for _ in batches]
+        tickets = [pipe.submit(pinned[i].numpy(), res[i].numpy().view(frt.RESULT_DTYPE), emb[i].numpy()) for i in range(n_batches)]
+        for i in order:
+            pipe.wait(tickets[i])
+        return [r.numpy().view(frt.RESULT_DTYPE).copy() for r in res], [e.numpy().copy() for e in emb]
+
+    # every face gets its own gallery row (similarity ~ 1, far above the next row), so that "the same matched rows" does not hang on the last
+    # bits of an embedding
+    _r0, emb0 = through_submit(range(n_batches))
+    gal = synth.make_gallery(3000)
+    all_emb = np.concatenate(emb0)
+    ok = np.linalg.norm(all_emb, axis=1) > 0.5
+    slots = (np.arange(len(all_emb)) * 23 + 5)
+    gal[slots[ok]] = all_emb[ok]
+    rec.setGallery(gal)
+    rec.initMatMul()
+    want_res, want_emb = through_submit(range(n_batches))
+    assert sum(int(w["valid"].sum()) for w in want_res) > 0
+    for i, w in enumerate(want_res):
+        v = w["valid"] != 0
+        assert np.array_equal(w["match_idx"][v], slots[i * B * K:(i + 1) * B * K][v]) and (w["match_sim"][v] > 0.99).all()
+    p0, s0 = pipe.pairing_stats()
+    assert p0 == 0 and s0 == 2 * n_batches
+    pipe.set_pairing(True)
+    for order in (range(n_batches), reversed(range(n_batches))):
+        got_res, got_emb = through_submit(list(order))
+        for i in range(n_batches):
+            assert same(got_res[i], want_res[i]), i
+            assert same_emb(got_emb[i], want_emb[i]), i
+    p1, s1 = pipe.pairing_stats()
+    assert p1 - p0 == 2 * (n_batches // 2) and s1 - s0 == 2       # per round: three pairs and the odd call out
+    # a call waited for before its partner arrives runs alone
+    r = torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+    t = pipe.submit(pinned[0].numpy(), r.numpy().view(frt.RESULT_DTYPE), None)
+    pipe.wait(t)
+    assert same(r.numpy().view(frt.RESULT_DTYPE), want_res[0])
+    assert pipe.pairing_stats() == (p1, s1 + 1)
+    # synchronous calls never wait for a partner; a call with too many frames for a pair runs as always
+    res_sync, emb_sync = pipe.run(batches[1])
+    assert same(res_sync, want_res[1]) and same_emb(emb_sync, want_emb[1])
+    big = np.concatenate([batches[2], batches[3]])
+    res_big, _ = pipe.run(big)
+    assert same(res_big[:B * K], want_res[2])
+    # device-resident path: results are complete after the next call's join or after sync
+    d_frames = [torch.from_numpy(b).cuda() for b in batches]
+    d_res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in batches]
+    d_emb = [torch.zeros(B * K, 512, device="cuda") for _ in batches]
+    pipe.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    pa, sa = pipe.pairing_stats()
+    for f, rr, ee in zip(d_frames, d_res, d_emb):
+        pipe.run_dev(f.data_ptr(), B, rr.data_ptr(), ee.data_ptr())
+    pipe.sync()
+    torch.cuda.synchronize()
+    for i in range(n_batches):
+        assert same(d_res[i].cpu().numpy(), want_res[i]), i
+        assert same_emb(d_emb[i].cpu().numpy(), want_emb[i]), i
+    pb, sb = pipe.pairing_stats()
+    assert (pb - pa, sb - sa) == (n_batches // 2, 1)
+    pipe.set_pairing(False)
+    pipe.set_stream(None)
+    pipe.close()
+    det.close()
+    rec.close()
