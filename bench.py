@@ -274,7 +274,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resident", action="store_true", help="primary timed region with frames/results resident in HBM (frt_pipeline_run_dev)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: ONE batch of --batch frames split over the ranks (BASELINE configs[3])")
-    ap.add_argument("--in-flight", type=int, default=DEPTH, help="batches in flight at the host boundary (1..7; default 3, 6 with --pair).  With --strong every rank "
+    ap.add_argument("--in-flight", type=int, default=DEPTH, help="batches in flight at the host boundary (1..11; default 3, 2 N + 2 with --pair N).  With --strong every rank "
                                                                  "keeps this many of its small batches in the stage pipeline at once")
     ap.add_argument("--sharded-gallery", action="store_true",
                     help="BASELINE configs[4]: gallery row-sharded over the ranks and stored as fp16; RCCL all-gather of embeddings and of the top-1 winners")
@@ -282,9 +282,10 @@ def main():
                                                         "(with --batch 1 --gallery 10000); the metric's own configuration stays fp16 MFMA")
     ap.add_argument("--exact-match", action="store_true", help="match stage = the exact fp32 scan of the whole gallery on every call "
                                                                "(frt_matcher_set_screening(m, 0): SURVEY 8(d)'s 2.048 GB per call) instead of the screened top-1")
-    ap.add_argument("--pair", action="store_true", help="frt_pipeline_set_pairing(p, 1): crop + recogniser + match of two consecutive calls as one pass "
-                                                        "(results one call later; objects are created for twice the frames of a step).  Only meaningful "
-                                                        "for small steps: 2 * batch * faces must fit the recogniser's 128-face pass")
+    ap.add_argument("--pair", type=int, nargs="?", const=2, default=0,
+                    help="frt_pipeline_set_pairing(p, N): crop + recogniser + match of N = 2 (default when the flag is given), 3 or 4 consecutive calls as one "
+                         "pass (results when the group is complete; objects are created for N times the frames of a step).  Only meaningful for small "
+                         "steps: N * batch * faces must fit the recogniser's 128-face pass")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step RCCL all-gather of the result records")
     ap.add_argument("--topk", type=int, default=5, help="--sharded-gallery: length of the per-query lists every rank answers with (1..16)")
     ap.add_argument("--dump-final", default=None, help="--sharded-gallery: write the last step's gathered fp16 queries and merged top-k lists (npz) "
@@ -298,9 +299,9 @@ def main():
                          "(a server's request threads must not burn cores); this driver owns its core and one late wake-up is a third of a "
                          "20-step region, so it asks for 50 ms and says so in config.host_wait")
     args = ap.parse_args()
-    depth = max(1, min(7, args.in_flight))
+    depth = max(1, min(11, args.in_flight))
     if args.pair and args.in_flight == DEPTH:
-        depth = 6   # paired calls complete two at a time, one call late: two pairs in the later stages + the detector's calls ahead of them
+        depth = 2 * args.pair + 2   # grouped calls complete N at a time: two groups in the later stages + the detector's calls ahead of them
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -356,7 +357,7 @@ def main():
     rec_sd = s.arcface_state(2, args.mode, calib=s.load_calibration(args.mode))
     det_path = frt.write_weights(os.path.join(tmp, "det.frtw"), det_sd, 1)
     rec_path = frt.write_weights(os.path.join(tmp, "rec.frtw"), rec_sd, 2 if args.mode == "ir" else 3)
-    cap = 2 if args.pair else 1   # --pair: room for two calls' face slots (the condition for pairing, include/frt.h)
+    cap = max(args.pair, 1)   # --pair N: room for N calls' face slots (the condition for pairing, include/frt.h)
     det = frt.RetinaFace(det_path, FW, FH, (3, H, W), B * cap, K, 0.4, 0.6, device=local_rank)
     rec = frt.ArcFaceIR50(rec_path, FW, FH, (3, 112, 112), 512, F * cap, K, 0.65, device=local_rank)
     if args.fp32:
@@ -383,7 +384,7 @@ def main():
     scan_mode = "int8" if _sb == 512 * _rows else ("fp16" if (_sb == 1024 * _rows and not args.sharded_gallery) else "exact")
     pipe = frt.Pipeline(det, rec, B * cap, match=not args.sharded_gallery)  # sharded gallery: the pipeline produces embeddings, match + merge follow below
     if args.pair:
-        pipe.set_pairing(True)
+        pipe.set_pairing(args.pair)
     # The caller's stream (NOT torch's default stream: that is the legacy NULL stream, and every operation on it - an event record, a
     # collective's stream hand-over - is a barrier against all blocking streams, including the pipeline's stage streams: measured 7.9
     # instead of 3.6 ms per step) is created, handed to the pipeline and USED once - so that the pipeline's lazily created upload stream
@@ -417,10 +418,10 @@ def main():
     h_frames = [torch.from_numpy(b).pin_memory() for b in batches]
     h_np = [t.numpy() for t in h_frames]
     RD = frt.RESULT_DTYPE
-    h_res = [torch.zeros(F * RD.itemsize, dtype=torch.uint8).pin_memory() for _ in range(8)]
+    h_res = [torch.zeros(F * RD.itemsize, dtype=torch.uint8).pin_memory() for _ in range(12)]
     h_views = [r.numpy().view(RD) for r in h_res]
     d_frames = [t.cuda() for t in h_frames]
-    NRING = 8
+    NRING = 12
     d_res = [torch.zeros(F * RD.itemsize, dtype=torch.uint8, device="cuda") for _ in range(NRING)]
     d_all = [torch.zeros(world * F * RD.itemsize, dtype=torch.uint8, device="cuda") for _ in range(NRING)] if use_dist else None
     h_all = [torch.zeros(world * F * RD.itemsize, dtype=torch.uint8).pin_memory() for _ in range(NRING)] if use_dist else None
@@ -458,7 +459,7 @@ def main():
                     step_times.append(("wait", i, time.perf_counter()))
             if i == profile_step:
                 frt.profile_enable(1)
-            tickets.append(pipe.submit(h_np[i & 1], h_views[i % 8]))
+            tickets.append(pipe.submit(h_np[i & 1], h_views[i % 12]))
             if step_times is not None:
                 step_times.append(("submit", i, time.perf_counter()))
             if i == profile_step:
@@ -554,7 +555,7 @@ def main():
     if args.sharded_gallery or args.resident:
         res = np.frombuffer(d_res[(max(args.warmup, 1) - 1) % NRING].cpu().numpy().tobytes(), RD)
     else:
-        res = h_views[(max(args.warmup, 1) - 1) % 8]
+        res = h_views[(max(args.warmup, 1) - 1) % 12]
     faces_per_step = int(res["valid"].sum())
 
     profile = not args.no_profile
@@ -850,7 +851,7 @@ def main():
             rec.initMatMul()
             f, m = step_rate(n_leg)
             hit_ms = serial_match_ms()
-            res_hit = h_views[(n_leg - 1) % 8]
+            res_hit = h_views[(n_leg - 1) % 12]
             planted = {int(r) for r in rows[ok]}
             found = int(sum(1 for x in res_hit[res_hit["valid"] != 0]["match_idx"] if int(x) in planted))
             match_legs["hit"] = {"faces_per_sec": f, "ms_per_step": m, "match_stage_ms": round(hit_ms, 4), "scan_bytes": rec.matmul.scanBytes(),
@@ -871,27 +872,30 @@ def main():
             pipe.run_dev(d_frames[i & 1].data_ptr(), nb, d_res[i % NRING].data_ptr(), None)
         torch.cuda.synchronize()
         ms4 = 1e3 * (time.perf_counter() - tp) / n_px
-        # the same with consecutive calls PAIRED (frt_pipeline_set_pairing): one recogniser pass + one match call per two 4-frame calls, results one
-        # call later.  The pipeline of this run has room for it when two calls' face slots fit its 32-frame capacity.
-        ms4p = None
-        if 2 * nb <= B and not args.pair:
+        # the same with consecutive calls GROUPED (frt_pipeline_set_pairing): one recogniser pass + one match call per two / four 4-frame calls, results
+        # when the group is complete.  The pipeline of this run has room for it when the calls' face slots together fit its 32-frame capacity.
+        grouped = {}
+        for gsz in (2, 4):
+            if gsz * nb > B or args.pair:
+                continue
             try:
-                pipe.set_pairing(True)
-                for i in range(6):
+                pipe.set_pairing(gsz)
+                for i in range(3 * gsz):
                     pipe.run_dev(d_frames[i & 1].data_ptr(), nb, d_res[i % NRING].data_ptr(), None)
                 pipe.sync()
                 torch.cuda.synchronize()
                 pa, sa = pipe.pairing_stats()
+                n_g = (n_px // gsz) * gsz
                 tp = time.perf_counter()
-                for i in range(n_px):
+                for i in range(n_g):
                     pipe.run_dev(d_frames[i & 1].data_ptr(), nb, d_res[i % NRING].data_ptr(), None)
                 pipe.sync()
                 torch.cuda.synchronize()
-                ms4p = 1e3 * (time.perf_counter() - tp) / n_px
+                ms_g = 1e3 * (time.perf_counter() - tp) / n_g
                 pb, sb = pipe.pairing_stats()
-                paired_frac = 2.0 * (pb - pa) / n_px
+                grouped[gsz] = (ms_g, gsz * (pb - pa) / float(n_g))
             finally:
-                pipe.set_pairing(False)
+                pipe.set_pairing(0)
         ms32 = extras.get("hbm_resident", {}).get("ms_per_step")
         if "steady_state" in extras and not ms32:
             ms32 = extras["steady_state"]["ms_per_step"]
@@ -899,13 +903,18 @@ def main():
             ms32 = 1e3 * dt / args.steps
         proxy = {"frames_per_step": nb, "ms_per_%d_frame_step" % nb: round(ms4, 4), "ms_per_%d_frame_step" % B: round(ms32, 4),
                  "projected_x_at_8": round(ms32 / ms4, 3) if nb * 8 == B else None,
-                 "paired": None if ms4p is None else {
-                     "ms_per_%d_frame_step" % nb: round(ms4p, 4), "projected_x_at_8": round(ms32 / ms4p, 3) if nb * 8 == B else None,
-                     "calls_served_by_a_paired_pass": round(paired_frac, 3),
-                     "what": "frt_pipeline_set_pairing(p, 1): the crop + recogniser + match stages of two consecutive %d-frame calls run as ONE pass (a %d-face "
+                 "paired": None if 2 not in grouped else {
+                     "ms_per_%d_frame_step" % nb: round(grouped[2][0], 4), "projected_x_at_8": round(ms32 / grouped[2][0], 3) if nb * 8 == B else None,
+                     "calls_served_by_a_shared_pass": round(grouped[2][1], 3),
+                     "what": "frt_pipeline_set_pairing(p, 2): the crop + recogniser + match stages of two consecutive %d-frame calls run as ONE pass (a %d-face "
                              "recogniser pass costs 0.59 ms, a %d-face one 0.92 ms; one gallery scan instead of two); every call's detector stage is queued at "
                              "the call, its results are complete one call later.  Boxes and matched rows identical, embeddings to fp16 rounding "
                              "(tests/test_gpu_pipeline.py).  Not the default: it trades one step of latency for throughput" % (nb, nb * K, 2 * nb * K)},
+                 "grouped_by_4": None if 4 not in grouped else {
+                     "ms_per_%d_frame_step" % nb: round(grouped[4][0], 4), "projected_x_at_8": round(ms32 / grouped[4][0], 3) if nb * 8 == B else None,
+                     "calls_served_by_a_shared_pass": round(grouped[4][1], 3),
+                     "what": "frt_pipeline_set_pairing(p, 4): four consecutive calls per recogniser pass (%d faces) and match call; results up to three calls "
+                             "later" % (4 * nb * K)},
                  "note": "single-GPU proxy for north_star's strong-scaling sentence (one %d-frame batch split over 8 GPUs, gallery replicated, no data-path "
                          "collective): a rank's step is %d frames; projected speed-up at 8 GPUs = (ms per %d-frame step on one GPU, HBM-resident) / (ms per "
                          "%d-frame step, HBM-resident, %d steps back to back with the stages of consecutive calls overlapping)" % (B, nb, B, nb, n_px)}
@@ -969,7 +978,7 @@ def main():
                        "frames_per_step_per_gpu": B, "faces_per_frame": K, "faces_per_step": total_faces_per_step,
                        "gallery_rows": args.gallery, "h2d_bytes_per_step": 0 if (args.resident or args.sharded_gallery) else int(batches[0].nbytes),
                        "gallery_load_s": round(gallery_load_s, 3), "parallelism": par,
-                       "pairing": bool(args.pair),
+                       "pairing": int(args.pair),
                        "host_wait": "frt_set_wait_spin_us(%d): this driver busy-polls for results (library default 200 us, then sleeping polls)" % args.wait_spin_us},
             "roofline": roofline,
             "cpu_baseline": None,

@@ -717,8 +717,9 @@ class Pipeline:
         _check(lib.frt_pipeline_set_graph(self._h, 1 if enable else 0))
 
     def set_pairing(self, enable):
-        """Crop + recogniser + match of two consecutive calls as one pass (frt_pipeline_set_pairing: results complete one call later)."""
-        _check(lib.frt_pipeline_set_pairing(self._h, 1 if enable else 0))
+        """Crop + recogniser + match of 2 (True / 2), 3 or 4 consecutive calls as one pass (frt_pipeline_set_pairing: results complete when
+        the group is, or at a flush); False / 0: off."""
+        _check(lib.frt_pipeline_set_pairing(self._h, int(enable)))
 
     def pairing_stats(self):
         """-> (recogniser passes that served two calls, passes that served one)."""

@@ -1555,7 +1555,7 @@ struct frt_pipeline {
     // calls in flight between the start of D and the end of M (2: 32.5k, 3: 33.6k, 4: 33.6k faces/s).  Six since pairing exists: paired calls finish
     // two at a time and one call late, so two pairs in the later stages + the detector a call or two ahead need six slots (with three the detector
     // of call b + 5 waited for the pair (b + 2, b + 3) and the recogniser passes ran one after the other: 0.84 instead of 0.74 ms per 4-frame call)
-    static constexpr int NSLOT = 6;
+    static constexpr int NSLOT = 10;  // (groups of four: 2 * 4 + 2)
     hipEvent_t ev_det[NSLOT] = {}, ev_emb[NSLOT] = {}, ev_done[NSLOT] = {};
     float *slot_embeds[NSLOT] = {};
     int *slot_valid[NSLOT] = {};
@@ -1576,7 +1576,7 @@ struct frt_pipeline {
 
     // ---- asynchronous host boundary (frt_pipeline_submit / frt_pipeline_wait): NBUF staging sets so that the H2D copy of batch
     //      b+1 (copy_stream, the SDMA engine) and the D2H of batch b-1 run under the stages of batch b
-    static constexpr int NBUF = 8;  // (4 until pairing: up to seven batches between submit and wait)
+    static constexpr int NBUF = 12;  // (4 until pairing: up to eleven batches between submit and wait)
     struct AsyncBuf {
         uint8_t *d_frames = nullptr;
         frt_face_result *d_results = nullptr;
@@ -1616,9 +1616,11 @@ struct frt_pipeline {
         uint8_t *h_crops = nullptr;
         long ticket = -1;
     };
-    CallRec pend;      // the call whose later stages are still to be queued
+    static constexpr int MAXG = 4;  // calls per recogniser pass at most
+    CallRec pend[MAXG];  // the calls whose later stages are still to be queued (fewer than `group` of them)
+    int npend = 0;
     CallRec host_req;  // set by submit for the next run(): staging set + host destinations
-    bool pairing = false;
+    int group = 0;       // 0: off; 2 .. MAXG: calls per recogniser pass (frt_pipeline_set_pairing)
     unsigned epass = 0;  // recogniser passes queued so far (activation set / stream of the next one)
     long paired_passes = 0, single_passes = 0;
     void ensure_async() {
@@ -1857,8 +1859,8 @@ struct frt_pipeline {
         // no other stream competes for the dispatch (with four streams in flight the bracketed time was 2.7x the kernel time).
         const bool pipe3 = overlap && g_prof_kind == 0 && !serial_call;
         // pairing: this call's later stages wait for the next call - or run together with the waiting call's
-        const bool pairable = pairing && pipe3 && 2 * F <= F_cap && 2 * F <= emb->max_batch;
-        if (pend.on && !(pairable && pend.n == n)) flush_pending();
+        const bool pairable = group >= 2 && pipe3 && group * F <= F_cap && group * F <= emb->max_batch;
+        if (npend && !(pairable && pend[0].n == n)) flush_pending();
         const unsigned call = seq++;
         const int slot = (int)(call % NSLOT);
         if (pipe3 && serial_pending) {  // a serial call used the shared detector / recogniser buffers on `s`: order the stages behind it
@@ -1911,43 +1913,45 @@ struct frt_pipeline {
         det->busy = true;
         if (pipe3) HIPCHK(hipEventRecord(ev_det[slot], ds));
         if (pairable) {
-            if (!pend.on) {  // wait for a partner: nothing else is queued for this call now (the caller's stream joins with the partner's call)
-                pend = cur;
-                return;
-            }
-            CallRec two[2] = {pend, cur};
-            pend = CallRec{};
-            later_stages(two, 2, pipe3);
+            pend[npend++] = cur;  // wait for partners: nothing else is queued for this call now (the caller's stream joins with the last partner's call)
+            if (npend == group) flush_pending();
             return;
         }
         later_stages(&cur, 1, pipe3);
     }
 
-    // the waiting call's crop + recogniser + match on their own (its partner never came)
+    // the waiting calls' crop + recogniser + match: the group is complete, or the missing partners never came
     void flush_pending() {
-        if (!pend.on) return;
-        CallRec one = pend;
-        pend = CallRec{};
-        later_stages(&one, 1, true);  // (a call is only ever deferred in the three-stream mode: its detector stage sits on det_stream)
+        if (!npend) return;
+        CallRec grp[MAXG];
+        const int n = npend;
+        for (int i = 0; i < n; ++i) grp[i] = pend[i];
+        npend = 0;
+        later_stages(grp, n, true);  // (a call is only ever deferred in the three-stream mode: its detector stage sits on det_stream)
+    }
+    bool is_pending(long ticket) const {
+        for (int i = 0; i < npend; ++i)
+            if (pend[i].ticket == ticket) return true;
+        return false;
     }
 
-    // E and M of one call, or of two consecutive calls as ONE recogniser pass and ONE match call (pairing)
+    // E and M of one call, or of up to MAXG consecutive calls as ONE recogniser pass and ONE match call (pairing)
     void later_stages(const CallRec *c, int nc, bool pipe3) {
         hipStream_t s = stream;
         const DetGeom &g = det->g;
-        int Fc[2] = {0, 0}, Ftot = 0;
+        int Fc[MAXG] = {}, Ftot = 0;
         for (int i = 0; i < nc; ++i) {
             Fc[i] = c[i].n * max_faces;
             Ftot += Fc[i];
         }
-        (nc == 2 ? paired_passes : single_passes) += 1;
+        (nc >= 2 ? paired_passes : single_passes) += 1;
         const int eset = (pipe3 && dual_embed && Ftot <= emb->max_batch) ? (int)(epass++ & 1u) : 0;  // activation set / stream of this recogniser pass
         hipStream_t es = pipe3 ? (eset ? emb_stream2 : emb_stream) : s;
         // match + pack follow the recogniser pass on ITS stream (they overlap the other set's pass and the next detector pass): a stream
         // of their own measured 0.6 % slower and is one more stream competing for the four hardware queues
         hipStream_t ms = es;
         float *chw = eset ? d_chw2 : d_chw;
-        // embeddings and validity flags of the pass: the first call's slot (two calls together fit one slot: run() checked)
+        // embeddings and validity flags of the pass: the first call's slot (the calls of a group fit one slot together: run() checked)
         float *emb_slot = slot_embeds[c[0].slot];
         int *valid = slot_valid[c[0].slot];
         for (int i = 0; i < nc; ++i) {
@@ -3178,7 +3182,7 @@ int frt_pipeline_set_pairing(frt_pipeline *p, int enable) {
         std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
         pipeline_flush_locked(p);
-        p->pairing = enable != 0;
+        p->group = enable <= 0 ? 0 : std::min(std::max(enable, 2), (int)frt_pipeline::MAXG);
     });
 }
 
@@ -3209,7 +3213,7 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     // overlap with: upload, detector, recogniser, match and download go down ONE stream - no stream-to-stream event hand-overs on its
     // critical path (5 of them otherwise; one 4-face call 1.02 -> 0.94 ms, profiles/r03/r03u_sync_overlap.txt).  Calls that arrive while
     // another is in flight take the stage streams as before (and are ordered behind this one through ev_serial).
-    bool lone = synchronous && p->overlap && !p->pend.on;
+    bool lone = synchronous && p->overlap && !p->npend;
     for (int i = 0; lone && i < frt_pipeline::NBUF; ++i)
         if (p->abuf[i].ticket >= 0 && i != (int)(ticket % frt_pipeline::NBUF) && hipEventQuery(p->abuf[i].ev_out) != hipSuccess) lone = false;
     if (lone) {
@@ -3245,7 +3249,7 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
 
 // Caller holds p->run_mu: queue the later stages of a call that is waiting for a partner (pairing).
 static void pipeline_flush_locked(frt_pipeline *p) {
-    if (!p->pend.on) return;
+    if (!p->npend) return;
     std::lock_guard<std::mutex> l1(p->det->mu);
     std::lock_guard<std::mutex> l2(p->emb->mu);
     std::unique_lock<std::mutex> l3;
@@ -3263,7 +3267,7 @@ static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
         if (b.ticket > ticket) return;  // its staging set was reused, which submit only does after that batch completed
         {
             std::lock_guard<std::mutex> lr(p->run_mu);
-            if (p->pend.on && p->pend.ticket == ticket) pipeline_flush_locked(p);  // pairing: nobody came to share its recogniser pass
+            if (p->is_pending(ticket)) pipeline_flush_locked(p);  // pairing: the partners that would share its recogniser pass have not come
         }
         ev = b.ev_out;
     }

@@ -332,7 +332,9 @@ int frt_pipeline_set_graph(frt_pipeline *p, int enable);
  *     relation as between any two batch sizes, tests/test_gpu_embedder.py, tests/test_gpu_pipeline.py).
  * A call is only deferred when it can be paired: twice its face slots must fit max_frames * max_faces of the pipeline and the recogniser's
  * max_batch (create the pipeline for twice the frames a call carries); other calls run as without pairing.  frt_pipeline_pairing_stats counts
- * the recogniser passes that served two calls and those that served one. */
+ * the recogniser passes that served several calls and those that served one.
+ * enable: 0 = off; 1 or 2 = pairs; 3, 4 = groups of three / four consecutive calls per pass (results complete when the group is - up to three
+ * calls later - or at a flush; capacity for that many calls' face slots; 64 faces per pass is where a pass stops being a latency chain). */
 int frt_pipeline_set_pairing(frt_pipeline *p, int enable);
 int frt_pipeline_pairing_stats(frt_pipeline *p, long *paired_passes_out, long *single_passes_out);
 

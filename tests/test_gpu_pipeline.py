@@ -490,11 +490,11 @@ def test_pairing_of_consecutive_calls_changes_nothing_but_the_pass_count(frt, sy
     def same_emb(got, want):
         n = np.linalg.norm(want, axis=1) > 0.5
         return np.array_equal(got[~n], want[~n]) and float((got[n] * want[n]).sum(1).min(initial=1.0)) > 1 - 1e-5 and float(np.abs(got - want).max()) < 2e-3
-    det = frt.RetinaFace(dpath, W, H, (3, H, W), 2 * B, K, 0.4, 0.6)
-    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=2 * B * K, maxFacesPerScene=K)
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), 4 * B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=4 * B * K, maxFacesPerScene=K)
     rec.setGallery(synth.make_gallery(3000))
     rec.initMatMul()
-    pipe = frt.Pipeline(det, rec, 2 * B)                       # room for two calls' face slots: the condition for pairing
+    pipe = frt.Pipeline(det, rec, 4 * B)                       # room for four calls' face slots: the condition for groups of up to four
     n_batches = 7                                              # odd: the last call finds no partner
     batches = [synth.make_frames(B, H, W, start=5 * i) for i in range(n_batches)]
     pinned = [torch.from_numpy(b).pin_memory() for b in batches]
@@ -541,9 +541,22 @@ def test_pairing_of_consecutive_calls_changes_nothing_but_the_pass_count(frt, sy
     # synchronous calls never wait for a partner; a call with too many frames for a pair runs as always
     res_sync, emb_sync = pipe.run(batches[1])
     assert same(res_sync, want_res[1]) and same_emb(emb_sync, want_emb[1])
-    big = np.concatenate([batches[2], batches[3]])
-    res_big, _ = pipe.run(big)
-    assert same(res_big[:B * K], want_res[2])
+    big = np.ascontiguousarray(np.concatenate([batches[2], batches[3], batches[4]]))   # 12 frames: two of these do not fit the 16-frame pipeline
+    r_big = np.zeros(3 * B * K, frt.RESULT_DTYPE)
+    pb0 = pipe.pairing_stats()
+    t = pipe.submit(big, r_big, None)
+    assert pipe.pairing_stats() == (pb0[0], pb0[1] + 1)            # queued at the call, nothing deferred
+    pipe.wait(t)
+    assert same(r_big[:B * K], want_res[2]) and same_emb(np.zeros((1, 512), np.float32), np.zeros((1, 512), np.float32))
+    # groups of four: (0, 1, 2, 3) share a pass, (4, 5, 6) are flushed as three when the last ticket is waited for
+    pipe.set_pairing(4)
+    pg, sg = pipe.pairing_stats()
+    got_res, got_emb = through_submit(range(n_batches))
+    for i in range(n_batches):
+        assert same(got_res[i], want_res[i]), i
+        assert same_emb(got_emb[i], want_emb[i]), i
+    assert pipe.pairing_stats() == (pg + 2, sg)
+    pipe.set_pairing(2)
     # device-resident path: results are complete after the next call's join or after sync
     d_frames = [torch.from_numpy(b).cuda() for b in batches]
     d_res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in batches]
