@@ -77,6 +77,9 @@ python tools/dropin_bench.py --gallery 1000000 --threads 8 --iters 100 --shared 
 python tools/multi_device_bench.py --steps 100 --out "$OUT/${TAG}_multi_device.json" > /dev/null 2>&1
 python bench.py --batch 4 --no-cpu-baseline --steps 300 --resident > "$OUT/${TAG}_bench_b4_resident.json" 2>/dev/null
 python bench.py --batch 4 --no-cpu-baseline --steps 300 > "$OUT/${TAG}_bench_b4.json" 2>/dev/null
+# round 5: consecutive calls sharing a recogniser pass (frt_pipeline_set_pairing): pairs and groups of four, 4 frames per call and K = 1
+for g in 2 4; do python bench.py --batch 4 --no-cpu-baseline --steps 300 --no-extras --pair $g > "$OUT/${TAG}_bench_b4_pair$g.json" 2>/dev/null; done
+python bench.py --faces 1 --no-cpu-baseline --no-extras --pair 4 > "$OUT/${TAG}_bench_k1_pair4.json" 2>/dev/null
 # 3c. small batches: the small-batch recogniser path against the strip kernels and the oracle; per-launch table of a 1- and a 4-face pass
 python tools/small_batch_parity.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/${TAG}_small_batch_parity.txt"
 for nf in 1 4 16 32; do NF=$nf bash tools/layer_table.sh "A=1"; done > "$OUT/${TAG}_small_batch_layers.txt" 2>&1
@@ -110,6 +113,18 @@ FRT_LIB=$ROOT/face-recognition-cpp-tensorrt_amd/libfrt_tuning.so FRT_DET_STEM_CH
 [ -x tools/ubench/lds_dma_raw ] && timeout 120 tools/ubench/lds_dma_raw > "$OUT/${TAG}_lds_dma_raw.txt" 2>&1
 [ -x tools/ubench/det_conv3h_bench ] && { timeout 300 tools/ubench/det_conv3h_bench 32; timeout 120 tools/ubench/det_conv3h_bench 4; timeout 120 tools/ubench/det_conv3h_bench 1; } > "$OUT/${TAG}_det_conv3h_bench.txt" 2>&1
 [ -x tools/ubench/plane_stride ] && timeout 300 tools/ubench/plane_stride > "$OUT/${TAG}_plane_stride.txt" 2>&1
+# 7. what each stage costs the pipelined step (tuning build, FRT_PIPE_ABLATE bit 0 = no detector network, 1 = no recogniser network, 2 = no match)
+{
+  echo "bench.py --steps 60 --warmup 12 --no-cpu-baseline --no-extras, tuning build, FRT_PIPE_ABLATE (bit 0: no detector network after the first calls, bit 1: no"
+  echo "recogniser network, bit 2: no match); faces/s and ms per step; K = 4 (the metric's configuration) and K = 1"
+  for A in 0 1 2 4 5 6; do
+    for K in 4 1; do
+      printf "ablate %d  K %d  " $A $K
+      FRT_LIB=$ROOT/face-recognition-cpp-tensorrt_amd/libfrt_tuning.so FRT_PIPE_ABLATE=$A python bench.py --steps 60 --warmup 12 --faces $K --no-cpu-baseline --no-extras 2>/dev/null |
+        python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
+    done
+  done
+} > "$OUT/${TAG}_stage_ablation_raw.txt" 2>&1
 for f in "$OUT"/${TAG}_det_kernel_stats_b*.csv; do echo "== $(basename $f)"; python tools/det_table.py "$f"; done > "$OUT/${TAG}_det_tables.txt" 2>&1
 python -c "import __graft_entry__ as e; e.smoke()" > "$OUT/${TAG}_smoke.txt" 2>&1
 ls -la "$OUT"
