@@ -3001,9 +3001,18 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
     });
 }
 
+static void pipeline_flush_locked(frt_pipeline *p);
+
 void frt_pipeline_destroy(frt_pipeline *p) {
     if (!p) return;
     (void)hipSetDevice(p->det->device);
+    if (p->npend) {  // pairing: calls still waiting for partners run now - a submitted batch is never dropped
+        try {
+            std::lock_guard<std::mutex> lk(p->run_mu);
+            pipeline_flush_locked(p);
+        } catch (...) {
+        }
+    }
     if (p->det_stream) (void)hipStreamSynchronize(p->det_stream);
     if (p->emb_stream) (void)hipStreamSynchronize(p->emb_stream);
     if (p->emb_stream2) (void)hipStreamSynchronize(p->emb_stream2);
@@ -3031,8 +3040,6 @@ void frt_pipeline_destroy(frt_pipeline *p) {
     p->arena.release();
     delete p;
 }
-
-static void pipeline_flush_locked(frt_pipeline *p);
 
 // Caller holds p->run_mu.
 static void pipeline_lock_run(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev) {

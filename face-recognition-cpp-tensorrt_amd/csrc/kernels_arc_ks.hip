@@ -111,9 +111,10 @@ __global__ __launch_bounds__(256, 1) void conv_ks_kernel(ConvMfmaArgs p) {
         load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW == 2 ? 60 : 24) : "memory");
-    // The patch is wave-private: no barrier follows.  Measured in kernels_det_wave.hip (round 4): a ds_read issued right behind the vmcnt
-    // wait of an LDS-DMA can still see the old LDS contents; 128 cycles were enough there.  The K loop's first read sits ~ 50 instructions
-    // further down and every test has passed without this sleep, but "the compiler happened to put enough in between" is not an ordering.
+    // The patch is wave-private: no barrier follows.  Round 4 suspected (kernels_det_wave.hip) that a ds_read issued right behind the vmcnt wait
+    // of an LDS-DMA could still see the old LDS contents; round 5's probe (tools/ubench/lds_dma_raw.hip: 0 stale words in 4.2e10 with nothing in
+    // between) says the issuing wave's covering vmcnt does order its own reads, and the round-4 symptom was a miscounted wait.  The sleep is
+    // kept as margin (64 cycles once per workgroup), not as the mechanism.
     asm volatile("s_sleep 2" ::: "memory");
     KS_STAMP(2);
 

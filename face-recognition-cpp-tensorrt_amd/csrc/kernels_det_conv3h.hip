@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
         sbias[lv][co] = co < mm.p[lv].Cout ? mm.p[lv].b[co] : 0.f;
     }
     const int r = lane & 31, hi = lane >> 5;
+    const int co0 = blockIdx.y * (32 * NCB);  // grid.y > 1: the output channels split over workgroups (a few frames per call: twice the workgroups, half the weights each)
 
     const int nwg = gridDim.x;
     const int bq = nwg >> 3, brem = nwg & 7;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
     // weights: host-packed [chunk][9][64][32 halves = hi16|lo16] (rows >= Cout are zero); the kernel stages rows [0, 32 NCB) of every tap
     half8 wst[WPT];
     auto fetch_weights = [&](int lv, int c) {
-        const half_t *src = mm.p[lv].wh + (long)c * (9 * 64 * 32);
+        const half_t *src = mm.p[lv].wh + (long)c * (9 * 64 * 32) + co0 * 32;  // (this workgroup's first output channel: a uniform offset, rows are 32 halves)
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             int u = tid + i * 256;
@@ -246,16 +247,19 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
             const int oy = g.oy0 + 2 * wave + (r >> 4), ox = g.ox0 + (r & 15);
             const bool inside = oy < a.Ho && ox < a.Wo;
             const long pix = inside ? (long)oy * a.Wo + ox : 0;
-            float *o1 = a.out + ((long)g.b * a.out_ctotal + a.out_coff) * HoWo + pix;
-            float *o2 = a.out2 ? a.out2 + ((long)g.b * a.out2_ctotal + a.out2_coff - a.split) * HoWo + pix : o1;
+            // (this workgroup's first output channel co0 enters through uniform quantities only: bases and limits)
+            float *o1 = a.out + ((long)g.b * a.out_ctotal + a.out_coff + co0) * HoWo + pix;
+            float *o2 = a.out2 ? a.out2 + ((long)g.b * a.out2_ctotal + a.out2_coff - a.split + co0) * HoWo + pix : o1;
+            const float *sb = &sbias[g.lv][co0];
+            const int cout_l = a.Cout - co0, split_l = a.split - co0;
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    float v = acc[cb][e] + sbias[g.lv][co];
+                    float v = acc[cb][e] + sb[co];
                     if (a.relu) v = fmaxf(v, 0.f);
-                    if (inside && co < a.Cout && (!(FRT_C3H_ABL & 8) || v == 12345.678f)) (co < a.split ? o1 : o2)[co * HoWo] = v;
+                    if (inside && co < cout_l && (!(FRT_C3H_ABL & 8) || v == 12345.678f)) (co < split_l ? o1 : o2)[co * HoWo] = v;
                     acc[cb][e] = 0.f;
                 }
         }
@@ -272,14 +276,14 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(Conv3H mm) {
 }
 
 template <int NCH, int NCB>
-void launch_split(const Conv3H &mm, int total, hipStream_t s) {
+void launch_split(const Conv3H &mm, int total, hipStream_t s, int cout_groups = 1) {
     const size_t lds = (size_t)(2 * PATCH_H + 9 * 32 * NCB * ROWH) * sizeof(half_t);  // 74.9 KB / 51.8 KB: two workgroups per CU
     static bool attr_done[FRT_MAX_DEVICES] = {};
     if (frt_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_split_kernel<NCH, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     int grid = NCB == 1 ? 768 : 512;  // (51.8 KB of LDS and 132 - 144 registers: three workgroups per CU; 74.9 KB: two)
     if (grid > total) grid = total;
-    hipLaunchKernelGGL((conv3x3_split_kernel<NCH, NCB>), dim3(grid), dim3(256), lds, s, mm);
+    hipLaunchKernelGGL((conv3x3_split_kernel<NCH, NCB>), dim3(grid, cout_groups), dim3(256), lds, s, mm);
 }
 
 }  // namespace
@@ -305,7 +309,11 @@ bool launch_conv3x3_split(const Conv3Args *a, int n, hipStream_t s) {
     if (base < 1) return true;
     const bool one = a[0].Cout <= 32;
     if (a[0].Cin == 64) {
+        // a few frames per call: fewer tiles than CUs - the 64 output channels as two workgroups of 32 (same accumulation order per channel:
+        // bit-identical; every workgroup stages half the weights and the whole patch)
+        static const int small_tiles = frt_tuning_env("FRT_C3H_SPLIT_TILES") ? atoi(frt_tuning_env("FRT_C3H_SPLIT_TILES")) : 384;
         if (one) launch_split<4, 1>(mm, base, s);
+        else if (base <= small_tiles) launch_split<4, 1>(mm, base, s, 2);
         else launch_split<4, 2>(mm, base, s);
     } else {
         if (one) launch_split<1, 1>(mm, base, s);

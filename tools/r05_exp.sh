@@ -1,25 +1,28 @@
 #!/bin/bash
-# scratch: groups of 2 / 4 consecutive calls per recogniser pass - tests, 4-frame step, the proxy in the default line
+# scratch: conv3x3_split - output channels split over two workgroups at a few frames per call; second workgroup of a CU started late (skew)
 set -u
-TAG=${1:-r05y}
+TAG=${1:-r06a}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_coalesce.py tests/test_cpp_shells.py -q -x 2>&1 | tail -15 > "$OUT/${TAG}_pytest.log"
-for g in 0 2 3 4; do
-python bench.py --batch 4 --no-cpu-baseline --steps 300 --no-extras --pair $g > "$OUT/${TAG}_bench_b4_pair$g.json" 2>/dev/null
+{
+for b in 1 4 32; do echo "== frames $b"; timeout 300 tools/ubench/det_conv3h_bench $b | grep -v "^ssh 16"; done
+for k in 1 2 3 5; do echo "== skew $k, frames 32"; timeout 300 tools/ubench/det_conv3h_bench_skew$k 32 | grep -v "^ssh 16"; done
+} > "$OUT/${TAG}_conv3h.txt" 2>&1
+python -m pytest tests/test_gpu_detector.py tests/test_gpu_headline.py -q -x 2>&1 | tail -5 > "$OUT/${TAG}_pytest.log"
+cd /tmp && export TMPDIR=/tmp
+trace() {  # name, env...
+  local name=$1; shift
+  rm -rf /tmp/prof_det && mkdir -p /tmp/prof_det
+  env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_det -o st -- python "$ROOT/tools/prof_det.py" ${PB:-32} 5 > /dev/null 2>&1
+  cp "$(find /tmp/prof_det -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_det_${name}.csv" 2>/dev/null
+}
+T="FRT_LIB=$ROOT/face-recognition-cpp-tensorrt_amd/libfrt_tuning.so"
+for b in 1 2 4 8; do
+  PB=$b trace split_b$b $T
+  PB=$b trace nosplit_b$b $T FRT_C3H_SPLIT_TILES=0
 done
-python bench.py --faces 1 --no-cpu-baseline --steps 100 --no-extras --pair 4 > "$OUT/${TAG}_bench_k1_pair4.json" 2>/dev/null
-python bench.py --batch 16 --no-cpu-baseline --steps 100 --no-extras > "$OUT/${TAG}_bench_b16.json" 2>/dev/null
-python bench.py --no-cpu-baseline --steps 50 > "$OUT/${TAG}_bench.json" 2>"$OUT/${TAG}_bench.stderr"
-python - "$OUT" "$TAG" <<'PY'
-import json,sys,glob,os
-out,tag=sys.argv[1:3]
-for f in sorted(glob.glob(os.path.join(out,tag+"_bench*.json"))):
-    try: d=json.loads(open(f).read().strip().splitlines()[-1])
-    except Exception as e: print(os.path.basename(f),"unreadable"); continue
-    p=d.get("strong_scaling_proxy") or {}
-    print(os.path.basename(f), d["value"], d["ms_per_step"], {k:(v if not isinstance(v,dict) else {a:b for a,b in v.items() if a!="what"}) for k,v in p.items() if k!="note"})
-PY
-cat "$OUT/${TAG}_pytest.log"
+cd "$ROOT"
+for f in "$OUT"/${TAG}_det_*.csv; do echo "== $(basename $f)"; python tools/det_table.py "$f" | grep -E "conv3x3_split|kernels per"; done > "$OUT/${TAG}_det_tables.txt" 2>&1
+cat "$OUT/${TAG}_conv3h.txt" "$OUT/${TAG}_det_tables.txt" "$OUT/${TAG}_pytest.log"
