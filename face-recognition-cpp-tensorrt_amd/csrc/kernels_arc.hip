@@ -498,18 +498,25 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     const int n_chunks = p.Cin >> 6;
 
     // ---- patch DMA descriptors: slot q of this lane covers 16-byte chunk g = (q*4 + wave)*64 + lane of the patch image
+    //      (round 5: the two divisions by run-time values per descriptor are reciprocal multiplies with one correction step - integer division
+    //      is ~ 40 instructions on this ISA, and conv_s2_kernel's phase stamps had shown 12 us of such arithmetic in front of its first DMA)
     int poff[NSLOT];
+    {
+        const int patch_px = (R + 2) * Wp;
+        const float inv_patch = 1.0f / (float)patch_px, inv_wp = 1.0f / (float)Wp;
 #pragma unroll
-    for (int q = 0; q < NSLOT; ++q) {
-        const int g = PAIR ? (q * 2 + (wave & 1)) * 64 + lane : (q * 4 + wave) * 64 + lane;
-        const int prow = g / 9, pos = g - prow * 9;
-        poff[q] = -1;
-        if (pos < 8 && prow < NP && strip_ok) {
-            const int il = prow / ((R + 2) * Wp);
-            const int rem = prow - il * ((R + 2) * Wp);
-            const int pr = rem / Wp, pc = rem - pr * Wp;
+        for (int q = 0; q < NSLOT; ++q) {
+            const int g = PAIR ? (q * 2 + (wave & 1)) * 64 + lane : (q * 4 + wave) * 64 + lane;
+            const int prow = g / 9, pos = g - prow * 9;
+            int il = (int)(((float)prow + 0.5f) * inv_patch);
+            int rem = prow - il * patch_px;
+            if (rem < 0) { --il; rem += patch_px; } else if (rem >= patch_px) { ++il; rem -= patch_px; }
+            int pr = (int)(((float)rem + 0.5f) * inv_wp);
+            int pc = rem - pr * Wp;
+            if (pc < 0) { --pr; pc += Wp; } else if (pc >= Wp) { ++pr; pc -= Wp; }
             const int iy = row0 + pr - 1, ix = pc - 1, b = img0 + il;
-            if (b < p.B && iy >= 0 && iy < H && ix >= 0 && ix < W) poff[q] = ((b * H + iy) * W + ix) * p.Cin + pos * 8;
+            const bool live = pos < 8 && prow < NP && strip_ok && b < p.B && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            poff[q] = live ? ((b * H + iy) * W + ix) * p.Cin + pos * 8 : -1;
         }
     }
     // ---- weights: each wave consumes only its own 32 cout rows, so the A fragments never touch LDS: lane (r, hi) loads its
@@ -530,9 +537,13 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
         if (linear) {
             pidx = sl < R * Wp ? sl : 0;
         } else if (sl < n_valid) {
-            const int il = sl / (R * W);
-            const int rem = sl - il * (R * W);
-            const int rr = rem / W, cc = rem - rr * W;
+            const int per = R * W;
+            int il = (int)(((float)sl + 0.5f) * (1.0f / (float)per));
+            int rem = sl - il * per;
+            if (rem < 0) { --il; rem += per; } else if (rem >= per) { ++il; rem -= per; }
+            int rr = (int)(((float)rem + 0.5f) * (1.0f / (float)W));
+            int cc = rem - rr * W;
+            if (cc < 0) { --rr; cc += W; } else if (cc >= W) { ++rr; cc -= W; }
             pidx = (il * (R + 2) + rr) * Wp + cc;
         }
         pbase[j] = pidx * PROW + hi * 16;

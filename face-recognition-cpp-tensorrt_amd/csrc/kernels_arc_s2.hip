@@ -22,6 +22,10 @@
 #include "frt_kernels.h"
 #include "frt_se_device.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
 #include <type_traits>
 
 namespace {
@@ -53,6 +57,15 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
     const int strips_per_img = Ho / R;
     const int n_valid = n_img * R * Wo;
 
+#ifdef FRT_ABLATE
+    // timing build (FRT_S2_STAMPS=1): phase stamps (100 MHz constant clock) of wave 0 of the first and the last workgroup into p.outf
+    unsigned long long *stamps = (p.outf && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+                                     ? reinterpret_cast<unsigned long long *>(p.outf) + (blockIdx.x ? 8 : 0) : nullptr;
+#define S2_STAMP(i) do { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define S2_STAMP(i) do { } while (0)
+#endif
+    S2_STAMP(0);
     const int n_co_tiles = p.Cout >> 7;
     const int nblk = gridDim.x, bq = nblk >> 3, brem = nblk & 7;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -63,39 +76,35 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
     const int oy0 = (strip % strips_per_img) * R;
     const int n_chunks = p.Cin >> 6;
 
-    // ---- plane DMA descriptors: piece q of plane s covers 16-byte chunk g = (q*4 + wave)*64 + lane of the plane image
+    // ---- plane DMA descriptors: piece q of plane s covers 16-byte chunk g = (q*4 + wave)*64 + lane of the plane image.
+    //      A piece's pixel (image, plane row, plane column) is the same in all four planes and in the shortcut plane - it is decomposed ONCE per
+    //      piece, with reciprocal multiplies + one correction step instead of integer divisions by run-time values (round 5: phase stamps showed
+    //      11.8 - 15 us of a 35 - 48 us launch in front of the first DMA: 36 descriptors x 3 divisions per thread; FRT_S2_STAMPS, tuning build)
     int poff[4][PP];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int q = 0; q < PP; ++q) {
-            const int g = (q * 4 + wave) * 64 + lane;
-            const int px = g / 9, pos = g - px * 9;
-            poff[s][q] = -1;
-            if (pos < 8 && px < NPp) {
-                const int il = px / ((R + 1) * Wq);
-                const int rem = px - il * ((R + 1) * Wq);
-                const int i = rem / Wq, j = rem - i * Wq;
-                const int y = 2 * (oy0 + i) - kRowPar[s], x = 2 * j - kColPar[s], b = img0 + il;
-                if (b < p.B && y >= 0 && y < H && x >= 0 && x < W) poff[s][q] = ((b * H + y) * W + x) * p.Cin + pos * 8;
-            }
-        }
-    // shortcut planes: the (even, even) geometry on the shortcut conv's input tensor [B][H][W][Csc]
-    const int n_sc = SCF ? (p.Csc >> 6) : 0;  // 64-channel chunks: 1, 2 or 4 (<= the four plane buffers)
+    const int n_sc = SCF ? (p.Csc >> 6) : 0;  // 64-channel chunks of the shortcut conv: 1, 2 or 4 (<= the four plane buffers)
     int poff_sc[SCF ? PP : 1];
-    if constexpr (SCF) {
+    {
+        const int plane_px = (R + 1) * Wq;
+        const float inv_plane = 1.0f / (float)plane_px, inv_row = 1.0f / (float)Wq;
 #pragma unroll
         for (int q = 0; q < PP; ++q) {
             const int g = (q * 4 + wave) * 64 + lane;
             const int px = g / 9, pos = g - px * 9;
-            poff_sc[q] = -1;
-            if (pos < 8 && px < NPp) {
-                const int il = px / ((R + 1) * Wq);
-                const int rem = px - il * ((R + 1) * Wq);
-                const int i = rem / Wq, j = rem - i * Wq;
-                const int y = 2 * (oy0 + i), x = 2 * j, b = img0 + il;
-                if (b < p.B && y < H && x < W) poff_sc[q] = ((b * H + y) * W + x) * p.Csc + pos * 8;
+            int il = (int)(((float)px + 0.5f) * inv_plane);
+            int rem = px - il * plane_px;
+            if (rem < 0) { --il; rem += plane_px; } else if (rem >= plane_px) { ++il; rem -= plane_px; }
+            int i = (int)(((float)rem + 0.5f) * inv_row);
+            int j = rem - i * Wq;
+            if (j < 0) { --i; j += Wq; } else if (j >= Wq) { ++i; j -= Wq; }
+            const int b = img0 + il;
+            const bool live = pos < 8 && px < NPp && b < p.B;
+            const int ye = 2 * (oy0 + i), xe = 2 * j;  // the (even, even) input pixel of this plane pixel
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int y = ye - kRowPar[s], x = xe - kColPar[s];
+                poff[s][q] = (live && y >= 0 && y < H && x >= 0 && x < W) ? ((b * H + y) * W + x) * p.Cin + pos * 8 : -1;
             }
+            if constexpr (SCF) poff_sc[q] = (live && ye < H && xe < W) ? ((b * H + ye) * W + xe) * p.Csc + pos * 8 : -1;
         }
     }
     const half_t *wfrag = p.wf + ((long)((co_base + cow) >> 5) * n_chunks) * (9 * 4 * 512) + lane * 8;
@@ -107,9 +116,13 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
         if (linear) {
             pidx = sl < R * Wq ? sl : 0;
         } else if (sl < n_valid) {
-            const int il = sl / (R * Wo);
-            const int rem = sl - il * (R * Wo);
-            const int rr = rem / Wo, cc = rem - rr * Wo;
+            const int per = R * Wo;
+            int il = (int)(((float)sl + 0.5f) * (1.0f / (float)per));
+            int rem = sl - il * per;
+            if (rem < 0) { --il; rem += per; } else if (rem >= per) { ++il; rem -= per; }
+            int rr = (int)(((float)rem + 0.5f) * (1.0f / (float)Wo));
+            int cc = rem - rr * Wo;
+            if (cc < 0) { --rr; cc += Wo; } else if (cc >= Wo) { ++rr; cc -= Wo; }
             pidx = (il * (R + 1) + rr) * Wq + cc;
         }
         pbase[j] = pidx * PROW + hi * 16;
@@ -151,8 +164,10 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
     load_w(0, 0, std::integral_constant<int, 0>{});
     load_w(0, 1, std::integral_constant<int, 1>{});
     half8 bf[BFD][NT];
+    S2_STAMP(1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LA) : "memory");  // this wave's plane pieces have landed (younger: the fragment loads)
     __builtin_amdgcn_s_barrier();                                    // ... and everybody else's
+    S2_STAMP(2);
 #pragma unroll
     for (int k2 = 0; k2 < BFD; ++k2)
 #pragma unroll
@@ -206,6 +221,7 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
         step(c, std::integral_constant<int, 7>{});
         step(c, std::integral_constant<int, 8>{});
     }
+    S2_STAMP(3);
     floatx16 acc_sc[SCF ? NT : 1];
     if constexpr (SCF) {  // this wave's shortcut weight fragments: [32-cout block][chunk][kk][lane][8 halfs], requested under the tail DMAs
         half8 wsc[4][4];
@@ -236,6 +252,7 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's dummy DMAs still target LDS
     }
     __syncthreads();
+    S2_STAMP(4);
 
     // ------------------------------------------------------------------ epilogue (per wave: 32 couts x NT pixel tiles) through LDS
     constexpr int EROW = 36;  // floats per pixel row (32 + 4 pad)
@@ -349,6 +366,10 @@ __global__ __launch_bounds__(256, 1) void conv_s2_kernel(ConvMfmaArgs p, int R, 
             }
         }
     }
+#ifdef FRT_ABLATE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S2_STAMP(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ 64 -> 64, stride 2 (112 -> 56)
@@ -542,6 +563,40 @@ bool s2c64_applies(const ConvMfmaArgs &a) {
     return !off;
 }
 
+#ifdef FRT_ABLATE
+// timing build, FRT_S2_STAMPS=1: every launch leaves its stamps in the next slot of a device ring; averages per (NT, Cin) printed at exit
+struct S2Stamps {
+    unsigned long long *dev = nullptr;
+    int n = 0;
+    static constexpr int CAP = 2048;
+    int kind[CAP];
+    ~S2Stamps() {
+        if (!dev || !n) return;
+        const int m = std::min(n, CAP);
+        std::vector<unsigned long long> h((size_t)m * 16);
+        if (hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+        std::vector<int> kinds;
+        for (int i = 0; i < m; ++i)
+            if (std::find(kinds.begin(), kinds.end(), kind[i]) == kinds.end()) kinds.push_back(kind[i]);
+        for (int k : kinds) {
+            double d[2][6] = {};
+            int cnt = 0;
+            for (int i = m / 2; i < m; ++i) {  // second half of the run (warm)
+                if (kind[i] != k) continue;
+                ++cnt;
+                for (int b = 0; b < 2; ++b)
+                    for (int j = 1; j < 6; ++j) d[b][j] += (double)(h[(size_t)i * 16 + b * 8 + j] - h[(size_t)i * 16 + b * 8 + j - 1]) * 0.01;
+            }
+            if (!cnt) continue;
+            for (int b = 0; b < 2; ++b)
+                fprintf(stderr, "[s2 stamps] NT %d Cin %d B %d %s workgroup, %d launches: descriptors + DMA / weight issue %.2f | planes landed %.2f | K loop %.2f | shortcut conv %.2f | epilogue %.2f us\n",
+                        k & 15, (k >> 4) & 1023, k >> 14, b ? "last" : "first", cnt, d[b][1] / cnt, d[b][2] / cnt, d[b][3] / cnt, d[b][4] / cnt, d[b][5] / cnt);
+        }
+    }
+};
+static S2Stamps g_s2_stamps;
+#endif
+
 template <int NT, int PP, bool SEP = false, bool SCF = false>
 void launch_s2_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
     constexpr size_t lds = (size_t)4 * PP * 4096;
@@ -551,6 +606,19 @@ void launch_s2_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_s2_kernel<NT, PP, SEP, SCF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int strips = ((a.B + n_img - 1) / n_img) * (a.Ho / R);
     const int linear = (n_img == 1 && R * (a.Wo + 1) <= NT * 32) ? 1 : 0;
+#ifdef FRT_ABLATE
+    static const bool want_stamps = frt_tuning_env("FRT_S2_STAMPS") != nullptr;
+    if (want_stamps && !SEP) {
+        if (!g_s2_stamps.dev && hipMalloc(reinterpret_cast<void **>(&g_s2_stamps.dev), S2Stamps::CAP * 16 * 8) != hipSuccess) g_s2_stamps.dev = nullptr;
+        if (g_s2_stamps.dev && g_s2_stamps.n < S2Stamps::CAP) {
+            ConvMfmaArgs b = a;
+            b.outf = reinterpret_cast<float *>(g_s2_stamps.dev + (size_t)g_s2_stamps.n * 16);
+            g_s2_stamps.kind[g_s2_stamps.n++] = NT | (a.Cin << 4) | (a.B << 14);
+            hipLaunchKernelGGL((conv_s2_kernel<NT, PP, SEP, SCF>), dim3(strips * (a.Cout / 128)), dim3(256), lds, s, b, R, n_img, linear);
+            return;
+        }
+    }
+#endif
     hipLaunchKernelGGL((conv_s2_kernel<NT, PP, SEP, SCF>), dim3(strips * (a.Cout / 128)), dim3(256), lds, s, a, R, n_img, linear);
 }
 
