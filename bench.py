@@ -55,6 +55,7 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0  # dense; /opt/skills/guides/MI355X_MICROARCH.md 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # same guide: fp32 matrix / vector
 PEAK_HBM_BPS = 8.0e12            # same guide: HBM3E
 DET_ACT_BYTES_PER_640_FRAME = 27.45e6 * 4  # detector activations (fp32) written + read once per 640x640 frame
+DET_FP16_BYTES_PER_640_FRAME = 54.9e6       # the same tensors at the reference engine's fp16 (2 B x 27.45 M elements, written + read)
 DEPTH = 3                        # batches in flight at the host boundary
 
 
@@ -758,6 +759,7 @@ def main():
             # every stage against ITS bound (round-3 review item 14): algorithmic bytes / flops of one step over the stage's own serial time
             wk = {k: v[1] / 3 for k, v in agg.items()}
             det_bytes = DET_ACT_BYTES_PER_640_FRAME * (H * W) / (640.0 * 640.0) * B
+            det_bytes16 = DET_FP16_BYTES_PER_640_FRAME * (H * W) / (640.0 * 640.0) * B
             det_flop = wk.get("det_network", 0.0)
             rec_flop = wk.get("embed_network", 0.0)
             n_rows = int(frt.lib.frt_matcher_num_rows(rec.matmul._h))
@@ -773,10 +775,15 @@ def main():
                 "detector": {"bound": "hbm", "ms": round(stage_ms["detector"], 4), "bytes": int(det_bytes), "flop": det_flop,
                              "achieved_TBps": round(det_bytes / (stage_ms["detector"] * 1e-3) / 1e12, 3) if stage_ms["detector"] > 0 else None,
                              "frac_hbm": frac(det_bytes, stage_ms["detector"], PEAK_HBM_BPS),
+                             "bytes_fp16_algorithmic": int(det_bytes16),
+                             "frac_hbm_fp16_algorithmic": frac(det_bytes16, stage_ms["detector"], PEAK_HBM_BPS),
                              "frac_fp32_matrix": frac(det_flop, stage_ms["detector"], PEAK_FP32_MATRIX_TFLOPS * 1e12),
                              "note": "ALGORITHMIC bytes: fp32 NCHW activations, every tensor of the layer-by-layer network written once and read once (27.45 M "
                                      "elements per 640x640 frame, DESIGN 3); since round 4 the fused stem kernel never writes two of them (-0.63 GB per 32 "
-                                     "frames), so frac_hbm prices the work done, not the traffic on the bus"},
+                                     "frames), so frac_hbm prices the work done, not the traffic on the bus.  "
+                                     "frac_hbm_fp16_algorithmic is the same stage against SURVEY 8(d)'s own denominator (54.9 MB per frame: the tensors at "
+                                     "the reference engine's fp16); the activations stay fp32 here because fp16 storage of even the first tensor moves "
+                                     "7.5 % of the box coordinates against the fp32 oracle (profiles/r02/r02_det_fp16_storage_study.txt)"},
                 "recogniser": {"bound": "mfma", "ms": round(stage_ms["recogniser"], 4), "flop": rec_flop,
                                "achieved_TFLOPs": round(rec_flop / (stage_ms["recogniser"] * 1e-3) / 1e12, 1) if stage_ms["recogniser"] > 0 else None,
                                "frac_mfma": frac(rec_flop, stage_ms["recogniser"], PEAK_FP16_MFMA_TFLOPS * 1e12),

@@ -33,9 +33,9 @@ inline bool frt_first_use_on_device(bool (&done)[FRT_MAX_DEVICES]) {
 }
 
 // ---------------------------------------------------------------- utilities (kernels_util.hip)
-void launch_spin(double microseconds, hipStream_t s);
+void launch_spin(double microseconds, hipStream_t s);  // one wave busy-waiting on the constant device clock
 // sustained matrix-core rate probe (kernels_util.hip); returns the flop of the launch
-double launch_mfma_probe(int mix, int n_wg, int iters, const void *src, float *out, hipStream_t s);  // one wave busy-waiting on the constant device clock
+double launch_mfma_probe(int mix, int n_wg, int iters, const void *src, float *out, hipStream_t s);
 
 // ---------------------------------------------------------------- match (kernels_match.hip)
 struct MatchPartial {  // one per (workgroup, query)

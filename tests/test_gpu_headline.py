@@ -265,3 +265,70 @@ def test_bench_line_contract():
     assert "conv_patch_kernel" in r["kernel"] and r["launches"] == 34
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "faces/sec" and c["sample"]
+
+
+@pytest.mark.parametrize("mode", ["ir", "ir_se"])
+def test_configs1_batch1_fp32_one_workload(frt, orc, synth, blobs, mode):
+    """BASELINE configs[1] as ONE workload in the precision it names: 640x640, batch 1, 10k x 512 gallery, recogniser in fp32 mode
+    (setPrecision(True)), through the reference's own call sequence findFace -> forward -> featureMatching -> getOutputs
+    (src/app.cpp:304-310) AND through Pipeline.run, against the oracle run stage by stage: boxes by the census rule (every coordinate
+    within one pixel, at most one of a frame's differing), 1 - cos <= 1e-6 wherever the crop is the oracle's, identical top-1 rows,
+    |delta sim| < 1e-5.  Then back to the default precision: same boxes / rows, embeddings within north_star's 1e-4."""
+    dpath, dsd = blobs("det")
+    rpath, rsd = blobs(mode)
+    K, H, W, N = 4, 640, 640, 10_000
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), 1, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=K, maxFacesPerScene=K)
+    rec.setPrecision(True)
+    frames = synth.make_frames(3, H, W, start=500)
+    gal = synth.make_gallery(N)
+    want = []
+    for f in range(len(frames)):
+        boxes, emb = oracle_frame(orc, dsd, rsd, frames[f], H, W, K)
+        assert len(boxes) == K
+        slots = 11 + 3001 * f + 701 * np.arange(K)
+        gal[slots] = emb
+        want.append((boxes, emb, slots))
+    rec.initKnownEmbeds(N)
+    rec.addEmbeddings([str(i) for i in range(N)], gal)
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, 1)
+    off_total = 0
+    fp32_embeds = []
+    for f in range(len(frames)):
+        oboxes, oemb, slots = want[f]
+        # (1) the reference's call sequence, one frame per call
+        boxes = det.findFace(frames[f])
+        assert len(boxes) == K
+        d = np.stack([np.abs(boxes[c].astype(np.int64) - oboxes[c].astype(np.int64)) for c in ("x1", "y1", "x2", "y2")], 1)
+        assert d.max() <= 1 and (d != 0).sum() <= 1, (f, boxes, oboxes)
+        off_total += int((d != 0).sum())
+        emb = rec.forward(frames[f], boxes)
+        sims = rec.featureMatching()
+        names, best = rec.getOutputs(sims)
+        for j in range(K):
+            cos = float((emb[j].astype(np.float64) * oemb[j]).sum())
+            if d[j].max() == 0:
+                assert cos > 1 - 1e-6, (f, j, 1 - cos)
+            assert names[j] == str(slots[j]), (f, j, names[j], slots[j])  # identical top-1 IDs
+            assert abs(best[j] - cos) < 1e-5, (f, j, best[j], cos)
+        # (2) the same frame through the fused pipeline: same boxes, same rows, the same embeddings to fp32 rounding
+        res, pemb = pipe.run(frames[f][None])
+        assert res["valid"].all()
+        for c in ("x1", "y1", "x2", "y2"):
+            assert np.array_equal(res[c], boxes[c]), (f, c)
+        assert np.array_equal(res["match_idx"], slots), (f, res["match_idx"], slots)
+        assert ((pemb.astype(np.float64) * emb).sum(1) > 1 - 1e-6).all()
+        assert np.abs(res["match_sim"] - np.asarray(best, np.float32)).max() < 1e-5
+        fp32_embeds.append(pemb.copy())
+    assert off_total <= 1, off_total
+    # back on the default (fp16 MFMA) path: the mode is a switch, not a rebuild - and it is the less accurate of the two
+    rec.setPrecision(False)
+    for f in range(len(frames)):
+        res, pemb = pipe.run(frames[f][None])
+        assert np.array_equal(res["match_idx"], want[f][2])
+        assert ((pemb.astype(np.float64) * fp32_embeds[f]).sum(1) > 1 - COS_TOL).all()
+        assert not np.array_equal(pemb, fp32_embeds[f])
+    pipe.close()
+    det.close()
+    rec.close()

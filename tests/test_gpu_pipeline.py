@@ -547,7 +547,11 @@ def test_pairing_of_consecutive_calls_changes_nothing_but_the_pass_count(frt, sy
     t = pipe.submit(big, r_big, None)
     assert pipe.pairing_stats() == (pb0[0], pb0[1] + 1)            # queued at the call, nothing deferred
     pipe.wait(t)
-    assert same(r_big[:B * K], want_res[2]) and same_emb(np.zeros((1, 512), np.float32), np.zeros((1, 512), np.float32))
+    for part, src in enumerate((2, 3, 4)):                        # every third of the 12-frame call against the batch it was built from
+        seg = r_big[part * B * K:(part + 1) * B * K].copy()
+        assert np.array_equal(seg["frame"], want_res[src]["frame"] + part * B), part
+        seg["frame"] -= part * B                                    # (frame indices count within the call)
+        assert same(seg, want_res[src]), part
     # groups of four: (0, 1, 2, 3) share a pass, (4, 5, 6) are flushed as three when the last ticket is waited for
     pipe.set_pairing(4)
     pg, sg = pipe.pairing_stats()
