@@ -465,12 +465,19 @@ __device__ __forceinline__ void se_fc_gate(const float *sp, float *shid, const f
 // PAIR (Cout == 64, Cin == 64): one workgroup handles TWO strips; waves (0,1) own the first, waves (2,3) the second, each wave
 // one 32-cout fragment of its strip.  Each half stages its own patch (128 threads per patch image); the whole K loop (9 taps)
 // runs on that single resident patch.
-template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7, int BFD = 2, int WR = 3, bool SEP = false>  // SEP: SE pooling + gate in the epilogue (below); WR: weight register ring depth in steps (3 or 9); NT pixel tiles per strip; PPS patch DMA pieces per thread per step during taps 0..PT-1; BFD: depth (kk-slots) of the B fragment ring
-__global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
+// CPT ("compact", round 6): the strip is NT*32 CONSECUTIVE pixels of the flattened (image, row, column) index - no dead pixel slots
+// (a 14x14 image is 6.125 tiles: 8 images = 49 tiles = 7 strips; the padded row enumeration spends 28 of every 224 slots on the two halo
+// columns).  A strip then spans image boundaries, so the patch is a window of the STACKED images - one zero separator row between two
+// images (bottom halo of one, top halo of the next), NO halo columns (they would break the one-to-one slot -> patch-row walk): the taps
+// with kw = 0 / kw = 2 point the lanes whose pixel sits in the first / last image column at a zero pixel (patch pixel 0) instead - one
+// v_cndmask on the ADDRESS per (tap, tile), masks wave-uniform in scalar registers.  R carries the patch's row count, n_img / linear unused.
+template <int PPS, int PT, int NW, bool SINGLE, int ABL, bool PAIR, int NT, int BFD, int WR, bool SEP, bool CPT>  // SEP: SE pooling + gate in the epilogue (below); WR: weight register ring depth in steps (3 or 9); NT pixel tiles per strip; PPS patch DMA pieces per thread per step during taps 0..PT-1; BFD: depth (kk-slots) of the B fragment ring
+__device__ __forceinline__ void conv_patch_body(const ConvMfmaArgs &p, int R, int n_img, int linear) {
     // linear != 0: pixel slots are enumerated over the PADDED row width (slot == patch row of tap (0,0), slots in the two halo
     // columns are dead).  The 32 lanes of a fragment read then touch 32 consecutive patch rows -> no LDS bank conflicts; the
     // image-row wrap of the compact enumeration (a 2-row skip) costs ~40 % extra LDS cycles (measured SQ_LDS_BANK_CONFLICT).
     static_assert(!PAIR || SINGLE, "pair mode needs the single-chunk path");
+    static_assert(!CPT || (!PAIR && !SINGLE && !SEP && BFD == 1), "compact strips: the main two-buffer variant only (the SE tail pools per image)");
     constexpr int NSLOT = PAIR ? 34 : PT * PPS;
     constexpr int PATCH_B = NSLOT * (PAIR ? 128 : 256) * 16;  // bytes per patch buffer (whole DMA slots)
     constexpr int PROW = 144;                    // bytes per patch pixel row
@@ -478,8 +485,8 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char *patch = smem + (PAIR ? (wave >> 1) * PATCH_B : 0);  // LDS holds ONLY patches; weights go L2 -> registers
     const int r = lane & 31, hi = lane >> 5;
-    const int H = p.H, W = p.W, Wp = W + 2;
-    const int NP = n_img * (R + 2) * Wp;
+    const int H = p.H, W = p.W, Wp = CPT ? W : W + 2;
+    const int NP = CPT ? R * W + 1 : n_img * (R + 2) * Wp;
     const int strips_per_img = (H + R - 1) / R;  // (the last strip of an image may be ragged - linear enumeration only, see patch_geometry)
     const int n_valid = n_img * R * W;
 
@@ -491,9 +498,15 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     const int strip = PAIR ? (lid / n_co_tiles) * 2 + (wave >> 1) : lid / n_co_tiles;
     const int co_base = PAIR ? 0 : co_tile * 128;
     const int cow = PAIR ? (wave & 1) * 32 : wave * 32;  // this wave's cout rows inside the tile
-    const bool strip_ok = strip < ((p.B + n_img - 1) / n_img) * strips_per_img;
-    const int img0 = (strip / strips_per_img) * n_img;
-    const int row0 = (strip % strips_per_img) * R;
+    const int c_mlo = strip * (NT * 32);  // compact: first pixel of the strip
+    const bool strip_ok = CPT ? c_mlo < p.B * H * W : strip < ((p.B + n_img - 1) / n_img) * strips_per_img;
+    const int img0 = CPT ? 0 : (strip / strips_per_img) * n_img;
+    const int row0 = CPT ? 0 : (strip % strips_per_img) * R;
+    // compact: image / in-image offset of the first pixel, and the STACKED row (image b occupies rows b*(H+1) .. b*(H+1)+H-1, row b*(H+1)+H is
+    // the zero separator) of patch row 0 = one above the first pixel's (wave-uniform divisions, once)
+    const int c_img_lo = CPT ? c_mlo / (H * W) : 0;
+    const int c_rem_lo = CPT ? c_mlo - c_img_lo * (H * W) : 0;
+    const int c_top = CPT ? c_img_lo * (H + 1) + c_rem_lo / W - 1 : 0;
 
     const int n_chunks = p.Cin >> 6;
 
@@ -508,6 +521,20 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
         for (int q = 0; q < NSLOT; ++q) {
             const int g = PAIR ? (q * 2 + (wave & 1)) * 64 + lane : (q * 4 + wave) * 64 + lane;
             const int prow = g / 9, pos = g - prow * 9;
+            if constexpr (CPT) {
+                const int pp = prow - 1;  // patch pixel 0 is the zero pixel
+                const float inv_w = 1.0f / (float)W, inv_h1 = 1.0f / (float)(H + 1);
+                int pr = (int)(((float)pp + 0.5f) * inv_w);
+                int pc = pp - pr * W;
+                if (pc < 0) { --pr; pc += W; } else if (pc >= W) { ++pr; pc -= W; }
+                const int sr = c_top + pr;
+                int b = (int)(((float)sr + 0.5f) * inv_h1);
+                int iy = sr - b * (H + 1);
+                if (iy < 0) { --b; iy += H + 1; } else if (iy > H) { ++b; iy -= H + 1; }
+                const bool live = pos < 8 && pp >= 0 && pr < R && strip_ok && sr >= 0 && b < p.B && iy < H;
+                poff[q] = live ? ((b * H + iy) * W + pc) * p.Cin + pos * 8 : -1;
+                continue;
+            }
             int il = (int)(((float)prow + 0.5f) * inv_patch);
             int rem = prow - il * patch_px;
             if (rem < 0) { --il; rem += patch_px; } else if (rem >= patch_px) { ++il; rem -= patch_px; }
@@ -530,11 +557,27 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     const half_t *wfrag = p.wf + ((long)((co_base + cow) >> 5) * n_chunks) * (9 * 4 * 512) + lane * 8;
     // ---- B-fragment base addresses: pixel slot -> patch row of tap (0,0)
     int pbase[NT];
+    unsigned long long mL[CPT ? NT : 1], mR[CPT ? NT : 1];  // compact: lanes whose pixel sits in the first / last image column (wave-uniform masks)
+    const int zoff = hi * 16;                               // ... and where those lanes read instead for kw = 0 / kw = 2: the zero pixel
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int sl = j * 32 + r;
         int pidx = 0;
-        if (linear) {
+        if constexpr (CPT) {
+            const int u = c_rem_lo + sl;  // < H*W + NT*32
+            const int per = H * W;
+            int il = (int)(((float)u + 0.5f) * (1.0f / (float)per));
+            int rem = u - il * per;
+            if (rem < 0) { --il; rem += per; } else if (rem >= per) { ++il; rem -= per; }
+            int rr = (int)(((float)rem + 0.5f) * (1.0f / (float)W));
+            int cc = rem - rr * W;
+            if (cc < 0) { --rr; cc += W; } else if (cc >= W) { ++rr; cc -= W; }
+            const bool in = c_mlo + sl < p.B * per;
+            // own input pixel = patch pixel 1 + (stacked row - c_top) * W + cc; tap (kh, kw) reads that + (kh - 1) * W + (kw - 1)
+            pidx = in ? ((c_img_lo + il) * (H + 1) + rr - c_top) * W + cc - W : 0;
+            mL[j] = __builtin_amdgcn_ballot_w64(cc == 0);
+            mR[j] = __builtin_amdgcn_ballot_w64(cc == W - 1);
+        } else if (linear) {
             pidx = sl < R * Wp ? sl : 0;
         } else if (sl < n_valid) {
             const int per = R * W;
@@ -595,20 +638,29 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
     // just consumed with the fragment two kk-slots ahead - in the second half of a step that is the NEXT tap's fragment (the
     // patch is resident).  sched_barrier(0) pins the order (left alone hipcc emits "2 reads, lgkmcnt(0), 1 MFMA").
     half8 bf[BFD][NT];
+    // B fragment of pixel tile j for tap T, kk-slot kko, from the patch buffer at byte offset bufoff (kko is a literal after unrolling: an
+    // instruction immediate; compact strips redirect the first / last column's lanes for kw = 0 / 2)
+    auto frag = [&](int j, auto tap_c, int bufoff, int kko) -> half8 {
+        constexpr int T = decltype(tap_c)::value;
+        const int dpo = ((T / 3) * Wp + (T % 3)) * PROW + bufoff;  // wave-uniform
+        int a = pbase[j] + dpo;
+        if constexpr (CPT && T % 3 == 0) a = __builtin_amdgcn_inverse_ballot_w64(mL[j]) ? zoff + bufoff : a;
+        if constexpr (CPT && T % 3 == 2) a = __builtin_amdgcn_inverse_ballot_w64(mR[j]) ? zoff + bufoff : a;
+        return *reinterpret_cast<const half8 *>(patch + a + kko * 32);
+    };
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LA) : "memory");  // this wave's patch(0) pieces have landed (younger: the 4*LA fragment loads)
     __builtin_amdgcn_s_barrier();                     // ... and everybody else's
 #pragma unroll
     for (int k2 = 0; k2 < BFD; ++k2)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[k2][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + k2 * 32);
+        for (int j = 0; j < NT; ++j) bf[k2][j] = frag(j, std::integral_constant<int, 0>{}, 0, k2);
 
     auto step = [&](int c, auto tap_c) {
         constexpr int TAP = decltype(tap_c)::value;
         constexpr int NTAP = (TAP + 1) % 9;
         constexpr int AS = TAP % WR;  // register-ring slot of this step's weight fragments (9 taps = 3 x 3: compile time)
         const int pbuf = SINGLE ? 0 : (c & 1) * PATCH_B;
-        const int dp = ((TAP / 3) * Wp + (TAP % 3)) * PROW + pbuf;
-        const int dpn = ((NTAP / 3) * Wp + (NTAP % 3)) * PROW + (TAP == 8 ? (SINGLE ? 0 : ((c + 1) & 1) * PATCH_B) : pbuf);
+        const int pbufn = TAP == 8 ? (SINGLE ? 0 : ((c + 1) & 1) * PATCH_B) : pbuf;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int cur = BFD == 2 ? (kk & 1) : 0;
@@ -626,8 +678,8 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
                 if (ABL == 2) asm volatile("" ::"v"(areg[AS][kk]), "v"(bf[cur][j]));
                 else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[AS][kk], bf[cur][j], acc[j], 0, 0, 0);
                 if (ABL == 8 || ABL == 9) {
-                } else if (kk + BFD < 4) bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dp + (kk + BFD) * 32);
-                else bf[cur][j] = *reinterpret_cast<const half8 *>(patch + pbase[j] + dpn + (kk + BFD - 4) * 32);
+                } else if (kk + BFD < 4) bf[cur][j] = frag(j, std::integral_constant<int, TAP>{}, pbuf, kk + BFD);
+                else bf[cur][j] = frag(j, std::integral_constant<int, NTAP>{}, pbufn, kk + BFD - 4);
                 constexpr int JL = NT > 1 ? 1 : 0;  // pixel-tile slot that carries the loads of future steps
                 if (ABL != 1 && ABL != 7 && ABL != 9 && kk == 0 && j == JL) {  // weight fragments of step t+2 into the slot step t-1 used
                     constexpr int T2 = TAP + LA;
@@ -678,10 +730,14 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
         q3[1] = *reinterpret_cast<const floatx4 *>(p.p3 + cch + 4);
     }
     // pixel slots of a strip are CONTIGUOUS in the flattened (image, row, column) index: m = m0 + slot (no divisions)
-    const long m0 = ((long)img0 * H + row0) * W;
+    const long m0 = CPT ? (long)c_mlo : ((long)img0 * H + row0) * W;
     const long Mtot = (long)p.B * H * W;
     const float inv_wp = 1.0f / (float)Wp;
     auto slot_pixel = [&](int sl, long &m) -> bool {  // pixel slot -> flattened output pixel index; false for dead slots
+        if constexpr (CPT) {
+            m = m0 + sl;
+            return m < Mtot;
+        }
         if (linear) {
             const int rr = (int)(((float)sl + 0.5f) * inv_wp);  // exact for sl < 2^20
             const int cc = sl - rr * Wp;
@@ -751,6 +807,17 @@ __global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvM
             }
         }
     }
+}
+
+template <int PPS, int PT, int NW, bool SINGLE, int ABL = 0, bool PAIR = false, int NT = 7, int BFD = 2, int WR = 3, bool SEP = false>
+__global__ __launch_bounds__(256, BFD == 1 ? 2 : 1) void conv_patch_kernel(ConvMfmaArgs p, int R, int n_img, int linear) {
+    conv_patch_body<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR, SEP, false>(p, R, n_img, linear);
+}
+
+// compact strips (see CPT above): NT pixel tiles = NT*32 consecutive pixels per strip; npr = rows of the stacked-image patch window
+template <int NT, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv_patchc_kernel(ConvMfmaArgs p, int npr) {
+    conv_patch_body<10, 1, 5, false, ABL, false, NT, 1, 3, false, true>(p, npr, 1, 0);
 }
 
 // ---------------------------------------------------------------- input layer: conv3x3 3->64 + BN + PReLU (+ unit-0 leading BN)
@@ -1040,6 +1107,33 @@ void launch_patch_t(const ConvMfmaArgs &a, int R, int n_img, hipStream_t s) {
     hipLaunchKernelGGL((conv_patch_kernel<PPS, PT, NW, SINGLE, ABL, PAIR, NT, BFD, WR, SEP>), grid, dim3(256), lds, s, a, R, n_img, linear);
 }
 
+// compact strips: rows of the stacked-image patch window the tallest strip of the launch needs (top halo + the rows its pixels touch, zero
+// separators included + bottom halo), or 0 when the layer / batch is not served by conv_patchc_kernel<NT>
+int compact_patch_rows(const ConvMfmaArgs &a, int nt) {
+    const int P = a.H * a.W, S = nt * 32;
+    const long M = (long)a.B * P;
+    int worst = 0;
+    // the (image, row) phase of a strip's first pixel repeats every lcm(P, S) pixels: walk one period (or the whole batch if shorter)
+    long period = (long)P * S;
+    for (long m = 0; m < M && m < period; m += S) {
+        const long last = (m + S - 1 < M ? m + S - 1 : M - 1);
+        const int sr0 = (int)(m / P) * (a.H + 1) + (int)(m % P) / a.W, sr1 = (int)(last / P) * (a.H + 1) + (int)(last % P) / a.W;
+        worst = sr1 - sr0 + 3 > worst ? sr1 - sr0 + 3 : worst;
+    }
+    return worst;
+}
+
+template <int NT, int ABL = 0>
+void launch_patchc_t(const ConvMfmaArgs &a, int npr, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 10 * 4096;
+    static bool attr_done[FRT_MAX_DEVICES] = {};
+    if (frt_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_patchc_kernel<NT, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long M = (long)a.B * a.H * a.W;
+    const int strips = (int)((M + NT * 32 - 1) / (NT * 32));
+    hipLaunchKernelGGL((conv_patchc_kernel<NT, ABL>), dim3(strips * (a.Cout / 128)), dim3(256), lds, s, a, npr);
+}
+
 int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage (default: 64 KB ring, 2 workgroups per CU), 3 = LDS-DMA 3-stage
     static int impl = -1;
     if (impl < 0) {
@@ -1053,7 +1147,7 @@ int conv_impl() {  // FRT_CONV_IMPL: 1 = v1 register-staged, 2 = LDS-DMA 2-stage
 }  // namespace
 
 // Which kernel symbol a launch resolves to (also the profiling label, so bench.py / rocprofv3 can be matched by name).
-enum { CV_V1_22, CV_V1_14, CV_G2_22, CV_G2_14, CV_G3_22, CV_G3_14, CV_P_PAIR, CV_P_SINGLE, CV_P_255, CV_P_264, CV_P_255_NT4, CV_P_NT2, CV_P_NT1 };
+enum { CV_V1_22, CV_V1_14, CV_G2_22, CV_G2_14, CV_G3_22, CV_G3_14, CV_P_PAIR, CV_P_SINGLE, CV_P_255, CV_P_264, CV_P_255_NT4, CV_P_NT2, CV_P_NT1, CV_PC_7, CV_PC_4 };
 static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
     const int impl = conv_impl();
     static const int use_patch = frt_tuning_env("FRT_CONV_PATCH") ? atoi(frt_tuning_env("FRT_CONV_PATCH")) : 1;
@@ -1064,6 +1158,18 @@ static int conv_variant(const ConvMfmaArgs &a, int &R, int &n_img) {
         if (single) return CV_P_SINGLE;       // 15 slots (60 KB)
         if (nt == 1) return CV_P_NT1;         // short strips for small batches: 2 x 20 KB patch buffers
         if (nt == 2) return CV_P_NT2;
+        // compact strips (round 6) wherever the full-batch geometry leaves dead pixel slots: whole 14x14 images in 7 tiles (196 of 224 slots
+        // live) -> 8 images per 7 strips; two 7x7 images in 4 tiles (98 of 128) -> 128 images per 49 strips.  Not for the fused SE tail (it
+        // pools per image inside a strip) - conv_se_fused asks with the SE scratch set.
+        static const bool compact_on = !(frt_tuning_env("FRT_CONV_COMPACT") && frt_tuning_env("FRT_CONV_COMPACT")[0] == '0');
+        const bool epi_ok = a.mode == EPI_PRELU || a.mode == EPI_BN || (a.mode == EPI_BN_ADD_BN && !a.se_pool);
+        if (compact_on && epi_ok && slots <= 10 && ((nt == 7 && n_img == 1 && R == a.H && a.H * a.W < 224) || (nt == 4 && n_img == 2 && 2 * a.H * a.W < 128))) {
+            const int npr = compact_patch_rows(a, nt);
+            if (npr > 0 && (npr * a.W + 1) * 9 <= 10 * 256) {
+                R = npr;
+                return nt == 7 ? CV_PC_7 : CV_PC_4;
+            }
+        }
         if (nt == 4) return CV_P_255_NT4;     // 4 pixel tiles per strip (small maps)
         return slots <= 10 ? CV_P_255 : CV_P_264;  // 2 x 40 KB / 2 x 48 KB patch buffers
     }
@@ -1078,7 +1184,8 @@ const char *conv_kernel_label(const ConvMfmaArgs &a) {
                                   "conv_glds_kernel<2, 2, 3, 0>", "conv_glds_kernel<1, 4, 3, 0>", "conv_patch_kernel<3, 5, 5, true, 0, true, 7, 2, 3>",
                                   "conv_patch_kernel<3, 5, 5, true, 0, false, 7, 1, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 7, 1, 3>",
                                   "conv_patch_kernel<2, 6, 4, false, 0, false, 7, 2, 3>", "conv_patch_kernel<10, 1, 5, false, 0, false, 4, 1, 3>",
-                                  "conv_patch_kernel<5, 1, 5, false, 0, false, 2, 1, 3>", "conv_patch_kernel<5, 1, 5, false, 0, false, 1, 1, 3>"};
+                                  "conv_patch_kernel<5, 1, 5, false, 0, false, 2, 1, 3>", "conv_patch_kernel<5, 1, 5, false, 0, false, 1, 1, 3>",
+                                  "conv_patchc_kernel<7, 0>", "conv_patchc_kernel<4, 0>"};
     if (conv_small_applies(a)) return a.mode == EPI_BN_ADD_BN && a.scx ? "conv_small_kernel<true>" : "conv_small_kernel<false>";
     if (conv_ks_applies(a)) return "conv_ks_kernel";
     if (const char *l2 = conv_s2_label(a)) return l2;
@@ -1178,6 +1285,14 @@ void launch_conv_mfma(const ConvMfmaArgs &a, hipStream_t s) {
             //  runs at 0.94 of the rate the part sustains for its instruction mix.)
             return launch_patch_t<10, 1, 5, false, 0, false, 7, 1>(a, R, n_img, s);
         case CV_P_264: return launch_patch_t<2, 6, 4, false>(a, R, n_img, s);
+        case CV_PC_7:
+#ifdef FRT_ABLATE
+            if (abl == 22) return launch_patchc_t<7, 2>(a, R, s);
+            if (abl == 24) return launch_patchc_t<7, 4>(a, R, s);
+            if (abl == 25) return launch_patchc_t<7, 5>(a, R, s);
+#endif
+            return launch_patchc_t<7>(a, R, s);
+        case CV_PC_4: return launch_patchc_t<4>(a, R, s);
         case CV_P_255_NT4:
 #ifdef FRT_ABLATE
             if (abl == 11) return launch_patch_t<2, 5, 5, false, 0, false, 4>(a, R, n_img, s);

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Same-box A/B of two builds of libfrt.so: alternating legs of the benchmark's timed region (no side measurements).
+#   tools/ab_lib.sh TAG OLD_LIB [legs] [-- bench args]      (OLD_LIB relative to the package directory, e.g. libfrt_r05.so)
+set -u
+TAG=${1:-ab}; OLDLIB=${2:-libfrt_r05.so}; LEGS=${3:-3}
+shift 3 2>/dev/null || true
+[ "${1:-}" = "--" ] && shift
+ARGS=${*:---steps 200}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+OLD="FRT_LIB=$ROOT/face-recognition-cpp-tensorrt_amd/$OLDLIB"
+leg() {  # label, env...
+  local label=$1; shift
+  env "$@" python bench.py $ARGS --no-cpu-baseline --no-extras --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$label', d['value'], d['ms_per_step'])"
+}
+{
+echo "# bench.py $ARGS  (old = $OLDLIB)"
+for i in $(seq $LEGS); do
+  leg old $OLD
+  leg new FRT_AB=new
+done
+} > "$OUT/ab.txt" 2>&1
+cat "$OUT/ab.txt"
