@@ -879,6 +879,32 @@ def main():
             pipe.run_dev(d_frames[i & 1].data_ptr(), nb, d_res[i % NRING].data_ptr(), None)
         torch.cuda.synchronize()
         ms4 = 1e3 * (time.perf_counter() - tp) / n_px
+        # the DEFAULT mode of the library at the host boundary (frt_pipeline_submit / wait, adaptive pairing: a call's later stages share a pass with
+        # the next call's only while the recogniser is busy anyway) and the same loop with pairing switched off
+        host_legs = {}
+        if not args.pair and 2 * nb <= B:
+            depth_p = 8
+
+            def host_leg(n):
+                tk = []
+                for i in range(n):
+                    if len(tk) >= depth_p:
+                        pipe.wait(tk.pop(0))
+                    tk.append(pipe.submit(h_np[i & 1][:nb], h_views[i % 12][:nb * K]))
+                for t in tk:
+                    pipe.wait(t)
+            try:
+                for mode_p, name_p in ((-1, "adaptive"), (0, "off")):
+                    pipe.set_pairing(mode_p)
+                    host_leg(24)
+                    pa, sa = pipe.pairing_stats()
+                    tp = time.perf_counter()
+                    host_leg(n_px)
+                    ms_h = 1e3 * (time.perf_counter() - tp) / n_px
+                    pb, sb = pipe.pairing_stats()
+                    host_legs[name_p] = (ms_h, n_px / float(max(pb - pa + sb - sa, 1)))
+            finally:
+                pipe.set_pairing(-1)
         # the same with consecutive calls GROUPED (frt_pipeline_set_pairing): one recogniser pass + one match call per two / four 4-frame calls, results
         # when the group is complete.  The pipeline of this run has room for it when the calls' face slots together fit its 32-frame capacity.
         grouped = {}
@@ -902,21 +928,35 @@ def main():
                 pb, sb = pipe.pairing_stats()
                 grouped[gsz] = (ms_g, gsz * (pb - pa) / float(n_g))
             finally:
-                pipe.set_pairing(0)
+                pipe.set_pairing(-1)
         ms32 = extras.get("hbm_resident", {}).get("ms_per_step")
         if "steady_state" in extras and not ms32:
             ms32 = extras["steady_state"]["ms_per_step"]
         if not ms32:
             ms32 = 1e3 * dt / args.steps
-        proxy = {"frames_per_step": nb, "ms_per_%d_frame_step" % nb: round(ms4, 4), "ms_per_%d_frame_step" % B: round(ms32, 4),
-                 "projected_x_at_8": round(ms32 / ms4, 3) if nb * 8 == B else None,
+        ms_def = host_legs["adaptive"][0] if "adaptive" in host_legs else ms4
+        proxy = {"frames_per_step": nb, "ms_per_%d_frame_step" % nb: round(ms_def, 4), "ms_per_%d_frame_step" % B: round(ms32, 4),
+                 "projected_x_at_8": round(ms32 / ms_def, 3) if nb * 8 == B else None,
+                 "measured_on_hardware": False,
+                 "default_mode": None if "adaptive" not in host_legs else {
+                     "ms_per_%d_frame_step" % nb: round(host_legs["adaptive"][0], 4), "calls_per_recogniser_pass": round(host_legs["adaptive"][1], 3),
+                     "boundary": "frt_pipeline_submit / frt_pipeline_wait (pinned host frames in, host records out), 8 calls in flight",
+                     "what": "the library as shipped (frt_pipeline_set_pairing(p, -1), adaptive): a call's crop + recogniser + match stages are held back only "
+                             "while the recogniser is still busy with earlier calls and then share ONE pass with the next call's (up to four calls per pass); "
+                             "a call that finds the recogniser idle is queued at once - a lone caller sees the unpaired pipeline and its latency "
+                             "(tests/test_gpu_pipeline.py::test_adaptive_pairing_*)"},
+                 "pairing_off": None if "off" not in host_legs else {
+                     "ms_per_%d_frame_step" % nb: round(host_legs["off"][0], 4), "projected_x_at_8": round(ms32 / host_legs["off"][0], 3) if nb * 8 == B else None,
+                     "calls_per_recogniser_pass": round(host_legs["off"][1], 3), "what": "same loop, frt_pipeline_set_pairing(p, 0): every call its own pass"},
+                 "run_dev_unpaired": {"ms_per_%d_frame_step" % nb: round(ms4, 4), "projected_x_at_8": round(ms32 / ms4, 3) if nb * 8 == B else None,
+                                      "what": "frt_pipeline_run_dev calls (HBM-resident) are never held by the default mode: the pipeline stream joins each call's results at the call"},
                  "paired": None if 2 not in grouped else {
                      "ms_per_%d_frame_step" % nb: round(grouped[2][0], 4), "projected_x_at_8": round(ms32 / grouped[2][0], 3) if nb * 8 == B else None,
                      "calls_served_by_a_shared_pass": round(grouped[2][1], 3),
                      "what": "frt_pipeline_set_pairing(p, 2): the crop + recogniser + match stages of two consecutive %d-frame calls run as ONE pass (a %d-face "
                              "recogniser pass costs 0.59 ms, a %d-face one 0.92 ms; one gallery scan instead of two); every call's detector stage is queued at "
                              "the call, its results are complete one call later.  Boxes and matched rows identical, embeddings to fp16 rounding "
-                             "(tests/test_gpu_pipeline.py).  Not the default: it trades one step of latency for throughput" % (nb, nb * K, 2 * nb * K)},
+                             "(tests/test_gpu_pipeline.py).  HBM-resident calls, ALWAYS pairs: it trades one step of latency for throughput" % (nb, nb * K, 2 * nb * K)},
                  "grouped_by_4": None if 4 not in grouped else {
                      "ms_per_%d_frame_step" % nb: round(grouped[4][0], 4), "projected_x_at_8": round(ms32 / grouped[4][0], 3) if nb * 8 == B else None,
                      "calls_served_by_a_shared_pass": round(grouped[4][1], 3),
@@ -924,7 +964,8 @@ def main():
                              "later" % (4 * nb * K)},
                  "note": "single-GPU proxy for north_star's strong-scaling sentence (one %d-frame batch split over 8 GPUs, gallery replicated, no data-path "
                          "collective): a rank's step is %d frames; projected speed-up at 8 GPUs = (ms per %d-frame step on one GPU, HBM-resident) / (ms per "
-                         "%d-frame step, HBM-resident, %d steps back to back with the stages of consecutive calls overlapping)" % (B, nb, B, nb, n_px)}
+                         "%d-frame step in the library's default mode, %d steps back to back with the stages of consecutive calls overlapping).  NOT a "
+                         "measured scaling curve: no multi-GPU node was available to this run; the driver's SCALE file is the measurement when there is one" % (B, nb, B, nb, n_px)}
     if roofline is not None and rank == 0 and not args.no_extras:
         # what THIS device sustains on the dominant kernel's K-loop instruction mix (back-to-back fp16 MFMAs on random operands + one ds_read_b128 per MFMA
         # + the weight-fragment global loads) under its power limit: the denominator the 2.5 PFLOP/s nominal peak is not on this part (DESIGN A.1, A.15)

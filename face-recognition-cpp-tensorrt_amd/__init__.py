@@ -87,6 +87,7 @@ ABI = {
     "frt_merge_topk_dev": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "frt_embeds_to_half_dev": (_i, [_vp, _sz, _vp, _vp]),
     "frt_comm_get_unique_id": (_i, [_vp]),
+    "frt_comm_set_bootstrap_timeout": (ctypes.c_double, [ctypes.c_double]),
     "frt_comm_create": (_i, [_vp, _i, _i, _i, ctypes.POINTER(_vp)]),
     "frt_comm_create_all": (_i, [_i, _vp, _vp]),
     "frt_comm_destroy": (None, [_vp]),
@@ -121,6 +122,7 @@ ABI = {
     "frt_pipeline_set_graph": (_i, [_vp, _i]),
     "frt_pipeline_set_pairing": (_i, [_vp, _i]),
     "frt_pipeline_pairing_stats": (_i, [_vp, _vp, _vp]),
+    "frt_pipeline_graph_stats": (_i, [_vp, _vp, _vp]),
     "frt_detector_has_landmarks": (_i, [_vp]),
     "frt_detector_find_faces_landmarks": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _vp]),
     "frt_detector_infer_landmarks": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -717,9 +719,16 @@ class Pipeline:
         _check(lib.frt_pipeline_set_graph(self._h, 1 if enable else 0))
 
     def set_pairing(self, enable):
-        """Crop + recogniser + match of 2 (True / 2), 3 or 4 consecutive calls as one pass (frt_pipeline_set_pairing: results complete when
-        the group is, or at a flush); False / 0: off."""
+        """frt_pipeline_set_pairing: -1 (the default) adaptive - submit() calls share a recogniser pass with the next call's only while the
+        recogniser is busy anyway; -2 the same for run_dev calls too; 0 / False off; True / 2, 3, 4: always groups of that many consecutive
+        calls (results complete when the group is, or at a flush)."""
         _check(lib.frt_pipeline_set_pairing(self._h, int(enable)))
+
+    def graph_stats(self):
+        """-> (stage graphs captured, stage graphs replayed) since the pipeline was created (set_graph)."""
+        a, b = ctypes.c_long(0), ctypes.c_long(0)
+        _check(lib.frt_pipeline_graph_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def pairing_stats(self):
         """-> (recogniser passes that served two calls, passes that served one)."""

@@ -1584,6 +1584,7 @@ struct frt_pipeline {
         uint8_t *d_crops = nullptr;  // u8 BGR 112x112 crops of the batch's faces (frt_pipeline_submit_crops)
         hipEvent_t ev_h2d = nullptr, ev_out = nullptr;
         long ticket = -1;  // ticket whose results ev_out guards; -1: never used
+        bool failed = false;  // the deferred later stages of this ticket could not be queued (flush_pending): frt_pipeline_wait reports it
     };
     AsyncBuf abuf[NBUF];
     hipStream_t copy_stream = nullptr;
@@ -1620,9 +1621,23 @@ struct frt_pipeline {
     CallRec pend[MAXG];  // the calls whose later stages are still to be queued (fewer than `group` of them)
     int npend = 0;
     CallRec host_req;  // set by submit for the next run(): staging set + host destinations
-    int group = 0;       // 0: off; 2 .. MAXG: calls per recogniser pass (frt_pipeline_set_pairing)
+    // group: 0 off; 2 .. MAXG: ALWAYS wait for that many calls per recogniser pass (results up to group - 1 calls late);
+    //        -1 (default, round 6) ADAPTIVE: a call's later stages are held back only while the recogniser is still busy with earlier calls -
+    //        the pass could not start now anyway, so waiting for the next call costs a lone caller nothing - and go out together with the
+    //        next call's (up to MAXG calls per pass while the backlog lasts).  A call that finds the recogniser idle is queued at once,
+    //        exactly like group == 0.  frt_pipeline_wait on ANY ticket releases held calls once the recogniser has gone idle.
+    //        Only calls that came through frt_pipeline_submit are held (their contract is the ticket); frt_pipeline_run_dev promises that
+    //        the pipeline stream joins the results AT the call, so device-resident calls are held only on request (adaptive_dev).
+    int group = -1;
+    bool adaptive_dev = false;
     unsigned epass = 0;  // recogniser passes queued so far (activation set / stream of the next one)
     long paired_passes = 0, single_passes = 0;
+    // is a recogniser pass queued earlier still running (or waiting to run)?  Two event queries, ~ 1 us each
+    bool recogniser_busy() const {
+        for (int k = 0; k < 2; ++k)
+            if (emb->busy[k] && hipEventQuery(emb->ev_busy[k]) == hipErrorNotReady) return true;
+        return false;
+    }
     void ensure_async() {
         if (copy_stream) return;
         // The upload stream sits in the stage streams' priority class (its own hardware-queue pool): as a normal-priority stream it is
@@ -1663,9 +1678,15 @@ struct frt_pipeline {
         GraphKey key;
         int seen = 0;
         hipGraphExec_t exec = nullptr;
+        unsigned long used = 0;  // tick of the last sighting (least-recently-used eviction)
     };
     std::vector<GraphEntry> graphs;
     bool use_graphs = false;
+    // a steady pipelined workload cycles through NSLOT keys of stage 0, up to 2 * NSLOT (slot, activation set) pairs of stage 1 and NSLOT of
+    // stage 2: the cache holds them all (a smaller one evicted every key before it recurred - nothing was ever replayed)
+    static constexpr size_t GRAPH_CAP = 4 * NSLOT + 8;
+    unsigned long graph_tick = 0;
+    long graphs_captured = 0, graphs_replayed = 0;
     void drop_graphs() {
         for (GraphEntry &e : graphs)
             if (e.exec) (void)hipGraphExecDestroy(e.exec);
@@ -1678,12 +1699,20 @@ struct frt_pipeline {
         for (GraphEntry &g : graphs)
             if (g.key == key) e = &g;
         if (!e) {
-            if (graphs.size() >= 16) drop_graphs();  // callers that never repeat their buffers: stay eager, bounded memory
-            graphs.push_back(GraphEntry{key, 0, nullptr});
+            if (graphs.size() >= GRAPH_CAP) {  // callers that never repeat their buffers: bounded memory - the least recently seen key goes
+                size_t lru = 0;
+                for (size_t i = 1; i < graphs.size(); ++i)
+                    if (graphs[i].used < graphs[lru].used) lru = i;
+                if (graphs[lru].exec) (void)hipGraphExecDestroy(graphs[lru].exec);
+                graphs.erase(graphs.begin() + (long)lru);
+            }
+            graphs.push_back(GraphEntry{key, 0, nullptr, 0});
             e = &graphs.back();
         }
+        e->used = ++graph_tick;
         if (e->exec) {
             HIPCHK(hipGraphLaunch(e->exec, st));
+            ++graphs_replayed;
             return;
         }
         if (e->seen++ == 0) return body(st);
@@ -1703,6 +1732,7 @@ struct frt_pipeline {
             e->exec = nullptr;
             HIPCHK(ie);
         }
+        ++graphs_captured;
         HIPCHK(hipGraphLaunch(e->exec, st));
     }
 
@@ -1859,7 +1889,8 @@ struct frt_pipeline {
         // no other stream competes for the dispatch (with four streams in flight the bracketed time was 2.7x the kernel time).
         const bool pipe3 = overlap && g_prof_kind == 0 && !serial_call;
         // pairing: this call's later stages wait for the next call - or run together with the waiting call's
-        const bool pairable = group >= 2 && pipe3 && group * F <= F_cap && group * F <= emb->max_batch;
+        const int gcap = std::min({group < 0 ? (int)MAXG : group, F_cap / F, emb->max_batch / F});  // calls of this size one pass can take
+        const bool pairable = pipe3 && gcap >= 2 && (group > 0 || (group < 0 && (host_req.ab || adaptive_dev)));
         if (npend && !(pairable && pend[0].n == n)) flush_pending();
         const unsigned call = seq++;
         const int slot = (int)(call % NSLOT);
@@ -1913,9 +1944,13 @@ struct frt_pipeline {
         det->busy = true;
         if (pipe3) HIPCHK(hipEventRecord(ev_det[slot], ds));
         if (pairable) {
-            pend[npend++] = cur;  // wait for partners: nothing else is queued for this call now (the caller's stream joins with the last partner's call)
-            if (npend == group) flush_pending();
-            return;
+            // adaptive: hold this call back only while earlier recogniser passes are still in flight; fixed groups: always
+            const bool hold = group > 0 || npend > 0 || recogniser_busy();
+            if (hold) {
+                pend[npend++] = cur;  // nothing else is queued for this call now (the caller's stream joins with the last partner's call)
+                if (npend == gcap || (group < 0 && npend >= 2 && !recogniser_busy())) flush_pending();
+                return;
+            }
         }
         later_stages(&cur, 1, pipe3);
     }
@@ -1927,7 +1962,18 @@ struct frt_pipeline {
         const int n = npend;
         for (int i = 0; i < n; ++i) grp[i] = pend[i];
         npend = 0;
-        later_stages(grp, n, true);  // (a call is only ever deferred in the three-stream mode: its detector stage sits on det_stream)
+        try {
+            later_stages(grp, n, true);  // (a call is only ever deferred in the three-stream mode: its detector stage sits on det_stream)
+        } catch (...) {
+            // the held calls are lost; their tickets must not be answered from a staging set's STALE "results have left" event: mark them
+            // failed and re-arm the event behind whatever did get queued, so that frt_pipeline_wait returns - with the error
+            for (int i = 0; i < n; ++i)
+                if (grp[i].ab) {
+                    grp[i].ab->failed = true;
+                    (void)hipEventRecord(grp[i].ab->ev_out, stream);
+                }
+            throw;
+        }
     }
     bool is_pending(long ticket) const {
         for (int i = 0; i < npend; ++i)
@@ -1986,7 +2032,9 @@ struct frt_pipeline {
                 emb->forward_set(eset, chw + (size_t)f0 * 3 * 112 * 112, nf, valid + f0, emb_slot + (size_t)f0 * 512, st);
             }
         };
-        if (nc == 1) run_part(GraphKey{1, c[0].frames, nullptr, nullptr, c[0].n, c[0].slot, akey, (unsigned)eset}, es, stage_e);
+        // (the fp32 pass is never captured: its single activation set is handed from pass to pass through the host-tracked event f32.done,
+        //  which must be a real record on every pass - and a graph captured in one precision must not be replayed in the other)
+        if (nc == 1 && !emb->fp32_mode) run_part(GraphKey{1, c[0].frames, nullptr, nullptr, c[0].n, c[0].slot, akey, (unsigned)eset}, es, stage_e);
         else stage_e(es);
         HIPCHK(hipEventRecord(emb->ev_busy[eset], es));
         emb->busy[eset] = true;
@@ -3189,7 +3237,17 @@ int frt_pipeline_set_pairing(frt_pipeline *p, int enable) {
         std::lock_guard<std::mutex> lk(p->run_mu);
         use_device(p->det->device);
         pipeline_flush_locked(p);
-        p->group = enable <= 0 ? 0 : std::min(std::max(enable, 2), (int)frt_pipeline::MAXG);
+        p->group = enable < 0 ? -1 : (enable == 0 ? 0 : std::min(std::max(enable, 2), (int)frt_pipeline::MAXG));
+        p->adaptive_dev = enable <= -2;
+    });
+}
+
+int frt_pipeline_graph_stats(frt_pipeline *p, long *captured, long *replayed) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(p->run_mu);
+        if (captured) *captured = p->graphs_captured;
+        if (replayed) *replayed = p->graphs_replayed;
     });
 }
 
@@ -3214,6 +3272,7 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     const long ticket = p->next_ticket;
     frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
     if (b.ticket >= 0) wait_event_spinning(b.ev_out);  // the staging set is free once its previous batch has left
+    b.failed = false;
     hipStream_t s = p->stream;
     const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
     // A synchronous call that finds nothing else in flight (the reference's request / reply shape: one frame, one caller) has nothing to
@@ -3274,11 +3333,18 @@ static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
         if (b.ticket > ticket) return;  // its staging set was reused, which submit only does after that batch completed
         {
             std::lock_guard<std::mutex> lr(p->run_mu);
-            if (p->is_pending(ticket)) pipeline_flush_locked(p);  // pairing: the partners that would share its recogniser pass have not come
+            // pairing: the partners that would share its recogniser pass have not come; adaptive pairing: calls held back behind a busy
+            // recogniser go out as soon as a waiting caller finds it idle (they would be running by now had they not been held)
+            if (p->is_pending(ticket) || (p->npend && p->group < 0 && !p->recogniser_busy())) pipeline_flush_locked(p);
         }
         ev = b.ev_out;
     }
     wait_event_spinning(ev);
+    {
+        std::lock_guard<std::mutex> lk(p->async_mu);
+        frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
+        if (b.ticket == ticket && b.failed) raise(FRT_ERR_DEVICE, "pipeline: the later stages of this call could not be queued (see the error of the call that flushed it)");
+    }
     p->emb->check_se_error();
 }
 

@@ -11,10 +11,17 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "frt_host.hpp"
@@ -31,6 +38,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -61,6 +69,7 @@ Rccl &rccl() {
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
@@ -72,6 +81,62 @@ Rccl &rccl() {
 
 void ncclchk(ncclResult_t e, const char *what) {
     if (e != ncclSuccess) raise(FRT_ERR_DEVICE, std::string("RCCL: ") + what + ": " + rccl().GetErrorString(e));
+}
+
+// ---- bounded bootstrap.  ncclGetUniqueId (opens the bootstrap's listening socket), ncclCommInitRank (every rank connects to it and to
+// its ring neighbours) and ncclCommInitAll are BLOCKING calls with no timeout of their own: a rank that never arrives, an interface RCCL
+// picked that the peers cannot reach, or a socket stall leaves the caller hung - on an 8-GPU node that is a hung job, not an error.  Each
+// of them runs on a helper thread here; the caller waits for it up to frt_comm_set_bootstrap_timeout seconds (default 180; env
+// FRT_COMM_BOOTSTRAP_TIMEOUT_S; <= 0: forever) and gets FRT_ERR_DEVICE with a message when the time is up.  Everything the helper touches
+// lives in a shared heap record, so a helper that comes back late finds valid memory, sees that it was given up on and tears down what it
+// made (ncclCommAbort).  (RCCL's own non-blocking initialisation - ncclCommInitRankConfig with blocking = 0 - would make every later
+// collective on the communicator non-blocking too; the exchange step wants ordinary stream-ordered calls.)
+std::atomic<long> g_bootstrap_timeout_ms{-1};
+long bootstrap_timeout_ms() {
+    long v = g_bootstrap_timeout_ms.load(std::memory_order_relaxed);
+    if (v != -1) return v;
+    const char *e = getenv("FRT_COMM_BOOTSTRAP_TIMEOUT_S");
+    v = e ? (long)(atof(e) * 1000.0) : 180000L;
+    g_bootstrap_timeout_ms.store(v, std::memory_order_relaxed);
+    return v;
+}
+struct Bootstrap {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    ncclResult_t res = ncclSuccess;
+    ncclUniqueId uid;
+    std::vector<ncclComm_t> comms;
+    std::vector<int> devices;
+};
+// runs body(record) on a helper thread; true = finished in time (result in record->res)
+bool bounded(const std::shared_ptr<Bootstrap> &b, std::function<ncclResult_t(Bootstrap &)> body, std::function<void(Bootstrap &)> undo) {
+    std::thread([b, body, undo] {
+        const ncclResult_t r = body(*b);
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->res = r;
+        b->done = true;
+        if (b->abandoned) {
+            lk.unlock();
+            if (r == ncclSuccess && undo) undo(*b);  // nobody is waiting for what this call made any more
+            return;
+        }
+        b->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(b->mu);
+    const long ms = bootstrap_timeout_ms();
+    if (ms <= 0) b->cv.wait(lk, [&] { return b->done; });
+    else if (!b->cv.wait_for(lk, std::chrono::milliseconds(ms), [&] { return b->done; })) b->abandoned = true;
+    return b->done;
+}
+[[noreturn]] void stalled(const char *what) {
+    char buf[640];
+    snprintf(buf, sizeof(buf),
+             "RCCL: %s did not return within %.0f s (frt_comm_set_bootstrap_timeout / FRT_COMM_BOOTSTRAP_TIMEOUT_S): the bootstrap is stalled - a rank "
+             "of the communicator never called in, or RCCL chose a network interface its peers cannot reach (single node: NCCL_SOCKET_IFNAME=lo; "
+             "NCCL_DEBUG=INFO shows the interface).  The call was given up on; its helper thread tears the communicator down if it ever returns",
+             what, bootstrap_timeout_ms() / 1000.0);
+    raise(FRT_ERR_DEVICE, buf);
 }
 
 }  // namespace
@@ -88,13 +153,21 @@ struct frt_comm {
 
 extern "C" {
 
+double frt_comm_set_bootstrap_timeout(double seconds) {
+    const double prev = bootstrap_timeout_ms() / 1000.0;
+    g_bootstrap_timeout_ms.store(seconds > 0 ? (long)(seconds * 1000.0 + 0.5) : 0L, std::memory_order_relaxed);
+    return prev;
+}
+
 int frt_comm_get_unique_id(uint8_t *id_out) {
     return guarded([&] {
         if (!id_out) raise(FRT_ERR_INVALID, "null argument");
         static_assert(sizeof(ncclUniqueId) == FRT_COMM_ID_BYTES, "FRT_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
-        ncclUniqueId id;
-        ncclchk(rccl().GetUniqueId(&id), "ncclGetUniqueId");
-        std::memcpy(id_out, &id, sizeof(id));
+        Rccl &r = rccl();
+        auto b = std::make_shared<Bootstrap>();
+        if (!bounded(b, [&r](Bootstrap &x) { return r.GetUniqueId(&x.uid); }, nullptr)) stalled("ncclGetUniqueId");
+        ncclchk(b->res, "ncclGetUniqueId");
+        std::memcpy(id_out, &b->uid, sizeof(b->uid));
     });
 }
 
@@ -108,9 +181,20 @@ int frt_comm_create(const uint8_t *id, int rank, int world, int device, frt_comm
         c->device = device;
         c->rank = rank;
         c->world = world;
-        ncclUniqueId uid;
-        std::memcpy(&uid, id, sizeof(uid));
-        ncclchk(rccl().CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
+        Rccl &r = rccl();
+        auto b = std::make_shared<Bootstrap>();
+        std::memcpy(&b->uid, id, sizeof(b->uid));
+        b->comms.assign(1, nullptr);
+        if (!bounded(
+                b,
+                [&r, world, rank, device](Bootstrap &x) {
+                    if (hipSetDevice(device) != hipSuccess) return ncclUnhandledCudaError;  // (the helper thread has no current device yet)
+                    return r.CommInitRank(&x.comms[0], world, x.uid, rank);
+                },
+                [&r](Bootstrap &x) { (void)r.CommAbort(x.comms[0]); }))
+            stalled("ncclCommInitRank");
+        ncclchk(b->res, "ncclCommInitRank");
+        c->comm = b->comms[0];
         HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         *out = c.release();
     });
@@ -120,8 +204,19 @@ int frt_comm_create_all(int n_devices, const int *devices, frt_comm **out) {
     return guarded([&] {
         if (!devices || !out || n_devices < 1) raise(FRT_ERR_INVALID, "comm: bad argument");
         for (int i = 0; i < n_devices; ++i) out[i] = nullptr;
-        std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
-        ncclchk(rccl().CommInitAll(comms.data(), n_devices, devices), "ncclCommInitAll");
+        Rccl &r = rccl();
+        auto b = std::make_shared<Bootstrap>();
+        b->comms.assign((size_t)n_devices, nullptr);
+        b->devices.assign(devices, devices + n_devices);
+        if (!bounded(
+                b, [&r](Bootstrap &x) { return r.CommInitAll(x.comms.data(), (int)x.devices.size(), x.devices.data()); },
+                [&r](Bootstrap &x) {
+                    for (ncclComm_t cm : x.comms)
+                        if (cm) (void)r.CommAbort(cm);
+                }))
+            stalled("ncclCommInitAll");
+        ncclchk(b->res, "ncclCommInitAll");
+        const std::vector<ncclComm_t> &comms = b->comms;
         for (int i = 0; i < n_devices; ++i) {
             frt_comm *c = new frt_comm;
             c->device = devices[i];

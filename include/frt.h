@@ -237,6 +237,11 @@ int frt_embeds_to_half_dev(const void *embeds_dev, size_t n_values, void *half_o
 #define FRT_COMM_ID_BYTES 128
 typedef struct frt_comm frt_comm;
 int frt_comm_get_unique_id(uint8_t *id_out /* [FRT_COMM_ID_BYTES] */);
+/* RCCL's bootstrap calls (ncclGetUniqueId, ncclCommInitRank, ncclCommInitAll) block without a timeout of their own; frt_comm_get_unique_id,
+ * frt_comm_create and frt_comm_create_all give up after this many seconds and return FRT_ERR_DEVICE with a message that says what to look at
+ * (a rank that never called in, the interface RCCL chose).  Default 180 s (env FRT_COMM_BOOTSTRAP_TIMEOUT_S); <= 0: wait for ever.  Process-wide;
+ * returns the previous value. */
+double frt_comm_set_bootstrap_timeout(double seconds);
 int frt_comm_create(const uint8_t *id, int rank, int world, int device, frt_comm **out);
 int frt_comm_create_all(int n_devices, const int *devices, frt_comm **out /* [n_devices] */);
 void frt_comm_destroy(frt_comm *c);
@@ -319,24 +324,32 @@ int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
  * and mode repeat is captured on its second occurrence and replayed afterwards; callers that never repeat their buffers stay
  * on eager launches.  Automatically off while frt_profile_enable() records events. */
 int frt_pipeline_set_graph(frt_pipeline *p, int enable);
-/* Pairing of consecutive calls (default OFF; no reference counterpart - the reference answers one request at a time, src/app.cpp:243-287).
+/* Pairing of consecutive calls (no reference counterpart - the reference answers one request at a time, src/app.cpp:243-287).
  * Below ~ 64 faces a recogniser pass is a chain of launch latencies, not work: 16 faces cost 0.59 ms, 32 faces 0.92 ms, and one match call
- * scans the gallery once whatever the number of queries.  With pairing on, the crop + recogniser + match stages of TWO consecutive calls run
- * as ONE pass: a call's detector stage is queued at the call as always; its later stages are queued with the next call - or alone at a
- * flush: frt_pipeline_wait on its ticket, frt_pipeline_sync, any frt_pipeline_set_*.  What changes for the caller:
- *   - the results of a call are complete one call later: on the frt_pipeline_run_dev path the pipeline stream joins them at the NEXT call (or
- *     at frt_pipeline_sync), not at the call itself; frt_pipeline_submit / frt_pipeline_wait keep their contract (wait flushes when needed);
- *   - frames handed to frt_pipeline_run_dev must stay valid until that later join;
- *   - the embeddings come from the recogniser kernels chosen for BOTH calls' faces together (tile shapes follow the number of faces per pass):
- *     boxes, validity and matched rows are the unpaired pipeline's, embeddings agree with it to fp16 rounding (cosine >= 1 - 1e-5; the same
- *     relation as between any two batch sizes, tests/test_gpu_embedder.py, tests/test_gpu_pipeline.py).
- * A call is only deferred when it can be paired: twice its face slots must fit max_frames * max_faces of the pipeline and the recogniser's
- * max_batch (create the pipeline for twice the frames a call carries); other calls run as without pairing.  frt_pipeline_pairing_stats counts
- * the recogniser passes that served several calls and those that served one.
- * enable: 0 = off; 1 or 2 = pairs; 3, 4 = groups of three / four consecutive calls per pass (results complete when the group is - up to three
- * calls later - or at a flush; capacity for that many calls' face slots; 64 faces per pass is where a pass stops being a latency chain). */
+ * scans the gallery once whatever the number of queries.  The crop + recogniser + match stages of up to four CONSECUTIVE calls can run as
+ * ONE pass: a call's detector stage is queued at the call as always; its later stages are queued together with a later call's.
+ *
+ * enable = -1 (DEFAULT since round 6): ADAPTIVE, frt_pipeline_submit calls only.  A call's later stages are held back only while the
+ *   recogniser is still busy with earlier calls - the pass could not start now anyway - and go out with the next call's (up to four calls
+ *   per pass while the backlog lasts).  A call that finds the recogniser idle is queued at once: a lone caller sees exactly the unpaired
+ *   pipeline and its latency.  Held calls are released by the next submit, by frt_pipeline_wait on their ticket, by frt_pipeline_wait on
+ *   any ticket once the recogniser has gone idle, by frt_pipeline_sync and by any frt_pipeline_set_*; the submit / wait contract is unchanged.
+ *   frt_pipeline_run_dev calls are never held in this mode (their contract is the join on the pipeline stream AT the call).
+ * enable = -2: adaptive for frt_pipeline_run_dev calls too.  What changes for such a caller: the pipeline stream joins a held call's results
+ *   at a LATER call (or at frt_pipeline_sync), not at the call itself, and the frames must stay valid until then.
+ * enable = 0: off.  enable = 1 or 2: ALWAYS pairs; 3, 4: always groups of three / four (both boundaries; results complete when the group
+ *   is - up to three calls later - or at a flush; 64 faces per pass is where a pass stops being a latency chain).
+ *
+ * In every mode: boxes, validity and matched rows are the unpaired pipeline's; the embeddings come from the recogniser kernels chosen for
+ * the faces of ALL the calls of a pass together (tile shapes follow the number of faces per pass) and agree with the unpaired ones to fp16
+ * rounding (cosine >= 1 - 1e-5; the same relation as between any two batch sizes, tests/test_gpu_embedder.py, tests/test_gpu_pipeline.py).
+ * A call is only held when it can be grouped: at least twice its face slots must fit max_frames * max_faces of the pipeline and the
+ * recogniser's max_batch (a pipeline created for exactly the frames a call carries - the benchmark's 32-frame step - never groups).
+ * frt_pipeline_pairing_stats counts the recogniser passes that served several calls and those that served one. */
 int frt_pipeline_set_pairing(frt_pipeline *p, int enable);
 int frt_pipeline_pairing_stats(frt_pipeline *p, long *paired_passes_out, long *single_passes_out);
+/* hipGraph replay (frt_pipeline_set_graph): stage graphs captured / replayed so far (a key is captured on its second sighting). */
+int frt_pipeline_graph_stats(frt_pipeline *p, long *captured_out, long *replayed_out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Request coalescing (opt-in).  The reference answers ONE frame per request (src/app.cpp:293-352) from a Crow server that runs

@@ -2,8 +2,13 @@
 // Runs on however many devices are visible: one communicator per device created in ONE process (frt_comm_create_all), an all-gather of
 // per-device byte blocks issued from one thread (frt_comm_all_gather_multi) and, on device 0, a 1-rank communicator made from a unique id
 // (frt_comm_get_unique_id + frt_comm_create) - the one-process-per-GPU form.  Prints "comm ok <ndev>".
+// `comm_test stall`: the bound on RCCL's bootstrap - rank 0 of a TWO-rank communicator whose other rank never calls in must come back from
+// frt_comm_create with an error after frt_comm_set_bootstrap_timeout seconds instead of hanging.  Prints "stall ok <seconds waited>".
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -18,9 +23,25 @@
         }                                                                    \
     } while (0)
 
-int main() {
+int main(int argc, char **argv) {
     const int ndev = frt_device_count();
     if (ndev < 1) return 2;
+    if (argc > 1 && !std::strcmp(argv[1], "stall")) {
+        frt_comm_set_bootstrap_timeout(4.0);
+        uint8_t id[FRT_COMM_ID_BYTES];
+        CK(frt_comm_get_unique_id(id));
+        frt_comm *c = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = frt_comm_create(id, 0, 2, 0, &c);  // rank 1 never comes
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc == 0 || c || dt < 3.5 || dt > 60.0 || !std::strstr(frt_last_error(), "did not return within")) {
+            std::printf("FAILED stall: rc %d after %.1f s: %s\n", rc, dt, frt_last_error());
+            return 6;
+        }
+        std::printf("stall ok %.1f\n", dt);
+        std::fflush(stdout);
+        _exit(0);  // (the abandoned helper thread still sits in RCCL's bootstrap: no destructors, no atexit handlers)
+    }
     const size_t B = 4096;
     // ---- one process per GPU form (here: world 1 on device 0)
     {

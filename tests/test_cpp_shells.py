@@ -133,17 +133,14 @@ def test_rccl_communicator_from_plain_cpp(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
                            os.path.join(ROOT, "tests", "cpp", "comm_test.cpp"), "-o", exe, os.path.join(PKG, "libfrt.so"), "-L/opt/rocm/lib", "-lamdhip64",
                            "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
-    # RCCL's bootstrap (ncclGetUniqueId opens a listening socket, ncclCommInitRank connects to it) has been seen to stall once in about
-    # ten boxes with nothing of libfrt on the stack yet; a fresh process gets a second chance before the test calls it a failure
-    out = None
-    for attempt, (limit, extra) in enumerate(((120, {}), (300, {"NCCL_SOCKET_IFNAME": "lo", "NCCL_DEBUG": "WARN"}))):
-        try:
-            out = subprocess.run([exe], capture_output=True, text=True, timeout=limit, env=dict(os.environ, **extra))
-            break
-        except subprocess.TimeoutExpired as e:
-            if attempt == 1:
-                raise AssertionError("comm_test did not finish twice (120 s, 300 s): " + str(e.stdout)[-1000:] + str(e.stderr)[-1000:])
+    # RCCL's bootstrap blocks without a timeout of its own; libfrt bounds it (frt_comm_set_bootstrap_timeout, default 180 s) and reports a
+    # stall as FRT_ERR_DEVICE with a message - one attempt, the interface pinned to loopback (everything here is one node), no retry
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", FRT_COMM_BOOTSTRAP_TIMEOUT_S="150")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=400, env=env)
     assert out.returncode == 0 and "comm ok" in out.stdout, out.stdout + out.stderr
+    # the bound itself: a two-rank communicator whose second rank never calls in
+    out = subprocess.run([exe, "stall"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0 and "stall ok" in out.stdout, out.stdout + out.stderr
 
 
 def build_multi_device(outdir):

@@ -205,6 +205,34 @@ def test_graph_replay_matches_eager(frt, synth, blobs):
         r, _ = pipe.run(fa)
         assert np.array_equal(r, rc), i
     assert not np.array_equal(rc["match_idx"], ra["match_idx"])
+    # the pipelined paths (run_dev / submit: stage streams, ten box slots, two activation sets): a key recurs every ten calls - first round eager,
+    # second captured, later ones replayed; the cache must hold all 30 keys of the three stages (it used to drop everything at 16)
+    import torch
+    d_f = [torch.from_numpy(fa).cuda(), torch.from_numpy(fb).cuda()]
+    d_r = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    st = torch.cuda.Stream()
+    pipe.set_stream(st.cuda_stream)
+    pipe.set_graph(False)
+    want = []
+    for k in range(2):
+        pipe.run_dev(d_f[k].data_ptr(), B, d_r[k].data_ptr(), None)
+        pipe.sync()
+        st.synchronize()
+        want.append(d_r[k].cpu().numpy().copy())
+    assert np.array_equal(want[0].view(frt.RESULT_DTYPE), rc)
+    pipe.set_graph(True)
+    c0, r0 = pipe.graph_stats()
+    for i in range(50):
+        d_r[i & 1].zero_()
+        torch.cuda.synchronize()
+        pipe.run_dev(d_f[i & 1].data_ptr(), B, d_r[i & 1].data_ptr(), None)
+        if i % 10 == 9 or i >= 40:
+            pipe.sync()
+            st.synchronize()
+            assert np.array_equal(d_r[i & 1].cpu().numpy(), want[i & 1]), i
+    pipe.sync()
+    c1, r1 = pipe.graph_stats()
+    assert c1 - c0 >= 30 and r1 - r0 >= 60, (c1 - c0, r1 - r0)   # 3 stages x 10 slots captured in calls 10-19, replayed from call 20 on
     pipe.close()
     det.close()
     rec.close()
@@ -495,6 +523,7 @@ def test_pairing_of_consecutive_calls_changes_nothing_but_the_pass_count(frt, sy
     rec.setGallery(synth.make_gallery(3000))
     rec.initMatMul()
     pipe = frt.Pipeline(det, rec, 4 * B)                       # room for four calls' face slots: the condition for groups of up to four
+    pipe.set_pairing(0)                                        # (the default is the adaptive mode, tested below on its own)
     n_batches = 7                                              # odd: the last call finds no partner
     batches = [synth.make_frames(B, H, W, start=5 * i) for i in range(n_batches)]
     pinned = [torch.from_numpy(b).pin_memory() for b in batches]
@@ -579,6 +608,104 @@ def test_pairing_of_consecutive_calls_changes_nothing_but_the_pass_count(frt, sy
     assert (pb - pa, sb - sa) == (n_batches // 2, 1)
     pipe.set_pairing(False)
     pipe.set_stream(None)
+    pipe.close()
+    det.close()
+    rec.close()
+
+
+def test_adaptive_pairing_holds_calls_only_behind_a_busy_recogniser(frt, synth, blobs):
+    """The default mode (frt_pipeline_set_pairing(p, -1)): a submit() call's crop + recogniser + match stages wait for the next call only while the
+    recogniser is still busy with earlier calls.  (a) a lone caller - submit, wait, submit, wait - never shares a pass; (b) calls submitted back
+    to back do, with the unpaired pipeline's boxes / rows and embeddings to fp16 rounding; (c) run_dev calls are never held in this mode: their
+    results are joined on the pipeline stream AT the call, no frt_pipeline_sync needed; (d) -2 extends the mode to run_dev (results at sync)."""
+    import torch
+    dpath, _ = blobs("det")
+    rpath, _ = blobs("ir")
+    B, K, H, W = 4, 4, 320, 320
+
+    def same(got, want):
+        got, want = np.asarray(got).view(frt.RESULT_DTYPE), np.asarray(want).view(frt.RESULT_DTYPE)
+        return all(np.array_equal(got[k], want[k]) for k in ("x1", "y1", "x2", "y2", "frame", "match_idx", "valid")) and \
+            float(np.abs(got["match_sim"] - want["match_sim"]).max()) < 2e-4
+
+    def same_emb(got, want):
+        n = np.linalg.norm(want, axis=1) > 0.5
+        return np.array_equal(got[~n], want[~n]) and float((got[n] * want[n]).sum(1).min(initial=1.0)) > 1 - 1e-5
+    det = frt.RetinaFace(dpath, W, H, (3, H, W), 4 * B, K, 0.4, 0.6)
+    rec = frt.ArcFaceIR50(rpath, W, H, maxBatchSize=4 * B * K, maxFacesPerScene=K)
+    n_batches = 9
+    batches = [synth.make_frames(B, H, W, start=11 * i) for i in range(n_batches)]
+    pinned = [torch.from_numpy(b).pin_memory() for b in batches]
+    rec.setGallery(synth.make_gallery(3000))
+    rec.initMatMul()
+    pipe = frt.Pipeline(det, rec, 4 * B)
+
+    def new_out():
+        return ([torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in batches], [torch.zeros(B * K, 512).pin_memory() for _ in batches])
+    # reference: pairing off, one call at a time; every face then gets its own gallery row (see the fixed-group test above)
+    pipe.set_pairing(0)
+    res, emb = new_out()
+    for i in range(n_batches):
+        pipe.wait(pipe.submit(pinned[i].numpy(), res[i].numpy().view(frt.RESULT_DTYPE), emb[i].numpy()))
+    gal = synth.make_gallery(3000)
+    all_emb = np.concatenate([e.numpy() for e in emb])
+    ok = np.linalg.norm(all_emb, axis=1) > 0.5
+    gal[(np.arange(len(all_emb)) * 19 + 3)[ok]] = all_emb[ok]
+    rec.setGallery(gal)
+    rec.initMatMul()
+    res, emb = new_out()
+    for i in range(n_batches):
+        pipe.wait(pipe.submit(pinned[i].numpy(), res[i].numpy().view(frt.RESULT_DTYPE), emb[i].numpy()))
+    want_res, want_emb = [r.numpy().view(frt.RESULT_DTYPE).copy() for r in res], [e.numpy().copy() for e in emb]
+    assert sum(int(w["valid"].sum()) for w in want_res) > 0
+    pipe.set_pairing(-1)                                       # the default
+    # (a) lone caller: the recogniser is idle at every call
+    p0, s0 = pipe.pairing_stats()
+    res, emb = new_out()
+    for i in range(n_batches):
+        pipe.wait(pipe.submit(pinned[i].numpy(), res[i].numpy().view(frt.RESULT_DTYPE), emb[i].numpy()))
+        assert np.array_equal(res[i].numpy().view(frt.RESULT_DTYPE), want_res[i]) and np.array_equal(emb[i].numpy(), want_emb[i]), i   # the very same pass
+    p1, s1 = pipe.pairing_stats()
+    assert p1 == p0 and s1 - s0 == n_batches, (p1 - p0, s1 - s0)
+    # (b) back to back: later calls find the recogniser busy and share passes; waiting in submit order and in reverse
+    for order in (list(range(n_batches)), list(reversed(range(n_batches)))):
+        res, emb = new_out()
+        tickets = [pipe.submit(pinned[i].numpy(), res[i].numpy().view(frt.RESULT_DTYPE), emb[i].numpy()) for i in range(n_batches)]
+        for i in order:
+            pipe.wait(tickets[i])
+        for i in range(n_batches):
+            assert same(res[i].numpy(), want_res[i]), i
+            assert same_emb(emb[i].numpy(), want_emb[i]), i
+    p2, s2 = pipe.pairing_stats()
+    assert p2 - p1 >= 2, (p2 - p1, s2 - s1)                      # at least one shared pass per round (in practice: groups of up to four)
+    assert 4 * (p2 - p1) + (s2 - s1) >= 2 * n_batches              # every call was served
+    # (c) run_dev is not held: complete after a synchronisation of the pipeline's stream alone
+    d_frames = [torch.from_numpy(b).cuda() for b in batches]
+    d_res = [torch.zeros(B * K * frt.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda") for _ in batches]
+    st = torch.cuda.Stream()
+    pipe.set_stream(st.cuda_stream)
+    torch.cuda.synchronize()
+    pc, sc = pipe.pairing_stats()
+    for f, rr in zip(d_frames, d_res):
+        pipe.run_dev(f.data_ptr(), B, rr.data_ptr(), None)
+    st.synchronize()
+    assert pipe.pairing_stats() == (pc, sc + n_batches)
+    for i in range(n_batches):
+        assert same(d_res[i].cpu().numpy(), want_res[i]), i
+    # (d) -2: device-resident calls are held too; complete after frt_pipeline_sync
+    pipe.set_pairing(-2)
+    for rr in d_res:
+        rr.zero_()
+    torch.cuda.synchronize()
+    pd, sd = pipe.pairing_stats()
+    for f, rr in zip(d_frames, d_res):
+        pipe.run_dev(f.data_ptr(), B, rr.data_ptr(), None)
+    pipe.sync()
+    st.synchronize()
+    pe, se = pipe.pairing_stats()
+    assert pe - pd >= 1, (pe - pd, se - sd)
+    for i in range(n_batches):
+        assert same(d_res[i].cpu().numpy(), want_res[i]), i
     pipe.close()
     det.close()
     rec.close()
