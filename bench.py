@@ -883,9 +883,7 @@ def main():
         # the next call's only while the recogniser is busy anyway) and the same loop with pairing switched off
         host_legs = {}
         if not args.pair and 2 * nb <= B:
-            depth_p = 8
-
-            def host_leg(n):
+            def host_leg(n, depth_p=11):
                 tk = []
                 for i in range(n):
                     if len(tk) >= depth_p:
@@ -903,6 +901,12 @@ def main():
                     ms_h = 1e3 * (time.perf_counter() - tp) / n_px
                     pb, sb = pipe.pairing_stats()
                     host_legs[name_p] = (ms_h, n_px / float(max(pb - pa + sb - sa, 1)))
+                pipe.set_pairing(-1)
+                for dq in (8, 6):
+                    host_leg(24, dq)
+                    tp = time.perf_counter()
+                    host_leg(n_px, dq)
+                    host_legs["adaptive_%d" % dq] = (1e3 * (time.perf_counter() - tp) / n_px, 0.0)
             finally:
                 pipe.set_pairing(-1)
         # the same with consecutive calls GROUPED (frt_pipeline_set_pairing): one recogniser pass + one match call per two / four 4-frame calls, results
@@ -940,11 +944,14 @@ def main():
                  "measured_on_hardware": False,
                  "default_mode": None if "adaptive" not in host_legs else {
                      "ms_per_%d_frame_step" % nb: round(host_legs["adaptive"][0], 4), "calls_per_recogniser_pass": round(host_legs["adaptive"][1], 3),
-                     "boundary": "frt_pipeline_submit / frt_pipeline_wait (pinned host frames in, host records out), 8 calls in flight",
-                     "what": "the library as shipped (frt_pipeline_set_pairing(p, -1), adaptive): a call's crop + recogniser + match stages are held back only "
-                             "while the recogniser is still busy with earlier calls and then share ONE pass with the next call's (up to four calls per pass); "
-                             "a call that finds the recogniser idle is queued at once - a lone caller sees the unpaired pipeline and its latency "
-                             "(tests/test_gpu_pipeline.py::test_adaptive_pairing_*)"},
+                     "boundary": "frt_pipeline_submit / frt_pipeline_wait (pinned host frames in, host records out), 11 calls in flight (what the staging ring takes)",
+                     "ms_per_%d_frame_step_by_calls_in_flight" % nb: {"11": round(host_legs["adaptive"][0], 4), "8": round(host_legs["adaptive_8"][0], 4),
+                                                                    "6": round(host_legs["adaptive_6"][0], 4), "<=5": "as pairing_off (nothing is ever held)"},
+                     "what": "the library as shipped (frt_pipeline_set_pairing(p, -1), adaptive): a submit is held back only while at least five earlier "
+                             "tickets are still running; held submits are merged into ONE call (one detector pass, one recogniser pass, one match call, "
+                             "up to four tickets) and released as soon as fewer than five tickets are running; a caller with up to five calls in flight "
+                             "sees the unpaired pipeline and its latency (profiles/r06_adaptive_hold_sweep.txt, "
+                             "tests/test_gpu_pipeline.py::test_adaptive_pairing_*)"},
                  "pairing_off": None if "off" not in host_legs else {
                      "ms_per_%d_frame_step" % nb: round(host_legs["off"][0], 4), "projected_x_at_8": round(ms32 / host_legs["off"][0], 3) if nb * 8 == B else None,
                      "calls_per_recogniser_pass": round(host_legs["off"][1], 3), "what": "same loop, frt_pipeline_set_pairing(p, 0): every call its own pass"},

@@ -123,6 +123,7 @@ ABI = {
     "frt_pipeline_set_pairing": (_i, [_vp, _i]),
     "frt_pipeline_pairing_stats": (_i, [_vp, _vp, _vp]),
     "frt_pipeline_graph_stats": (_i, [_vp, _vp, _vp]),
+    "frt_pipeline_merge_stats": (_i, [_vp, _vp, _vp]),
     "frt_detector_has_landmarks": (_i, [_vp]),
     "frt_detector_find_faces_landmarks": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _vp]),
     "frt_detector_infer_landmarks": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -723,6 +724,12 @@ class Pipeline:
         recogniser is busy anyway; -2 the same for run_dev calls too; 0 / False off; True / 2, 3, 4: always groups of that many consecutive
         calls (results complete when the group is, or at a flush)."""
         _check(lib.frt_pipeline_set_pairing(self._h, int(enable)))
+
+    def merge_stats(self):
+        """-> (calls that carried several submit tickets, tickets they carried): adaptive merging at the host boundary."""
+        a, b = ctypes.c_long(0), ctypes.c_long(0)
+        _check(lib.frt_pipeline_merge_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def graph_stats(self):
         """-> (stage graphs captured, stage graphs replayed) since the pipeline was created (set_graph)."""

@@ -1584,7 +1584,7 @@ struct frt_pipeline {
         uint8_t *d_crops = nullptr;  // u8 BGR 112x112 crops of the batch's faces (frt_pipeline_submit_crops)
         hipEvent_t ev_h2d = nullptr, ev_out = nullptr;
         long ticket = -1;  // ticket whose results ev_out guards; -1: never used
-        bool failed = false;  // the deferred later stages of this ticket could not be queued (flush_pending): frt_pipeline_wait reports it
+        std::atomic<bool> failed{false};  // the held stages of this ticket could not be queued (flush_pending / start_held): frt_pipeline_wait reports it
     };
     AsyncBuf abuf[NBUF];
     hipStream_t copy_stream = nullptr;
@@ -1602,6 +1602,15 @@ struct frt_pipeline {
     //      ready - one call later - and which batch-size class of recogniser kernels produced it (the class of the two calls' faces together).
     //      A call is only ever deferred when it could be paired: both calls' face slots together must fit this pipeline's max_frames *
     //      max_faces and the recogniser's max_batch, i.e. create the pipeline for twice the frames a call carries.
+    struct Sub {  // one frt_pipeline_submit ticket inside a call: `n` frames, where its results go, the staging set that carries its events
+        AsyncBuf *ab = nullptr;
+        frt_face_result *h_results = nullptr;
+        float *h_embeds = nullptr;
+        uint8_t *h_crops = nullptr;
+        int n = 0;
+        long ticket = -1;
+    };
+    static constexpr int MAXSUB = 4;
     struct CallRec {
         bool on = false;
         unsigned call = 0;
@@ -1610,12 +1619,10 @@ struct frt_pipeline {
         frt_face_result *results = nullptr;
         float *embeds = nullptr;
         uint8_t *crops = nullptr;
-        // host side of frt_pipeline_submit: the downloads of this call's results follow its match stage, wherever that is queued
-        AsyncBuf *ab = nullptr;
-        frt_face_result *h_results = nullptr;
-        float *h_embeds = nullptr;
-        uint8_t *h_crops = nullptr;
-        long ticket = -1;
+        // host side of frt_pipeline_submit: the downloads of this call's results follow its match stage, wherever that is queued.  One entry per
+        // ticket: a call is the frames of up to MAXSUB consecutive submits when they were merged at the host boundary (Held, below)
+        int nsub = 0;
+        Sub sub[MAXSUB];
     };
     static constexpr int MAXG = 4;  // calls per recogniser pass at most
     CallRec pend[MAXG];  // the calls whose later stages are still to be queued (fewer than `group` of them)
@@ -1630,6 +1637,45 @@ struct frt_pipeline {
     //        the pipeline stream joins the results AT the call, so device-resident calls are held only on request (adaptive_dev).
     int group = -1;
     bool adaptive_dev = false;
+    bool merge_submits = true;   // adaptive mode: merge held submits at the host boundary (Held, below)
+    // ---- merging of consecutive submits at the host boundary (adaptive mode only, round 6).  A small call's DETECTOR stage is as much a chain of
+    //      launch latencies as its recogniser pass (4 frames: 258 us of kernels, 32 frames: 809 - profiles/r06g_det_tables.txt).  A submit that
+    //      finds the pipeline backed up (detector or recogniser still busy with earlier calls) is not queued at all: its frames are uploaded into its staging set and the call is
+    //      HELD; the next submit's frames go into the same staging set behind them, and the held frames then run as ONE call (one detector pass,
+    //      one recogniser pass, one match call; per-ticket result downloads).  Released by: the submit that fills it (MAXSUB tickets / the
+    //      pipeline's capacity) or finds the detector idle, any submit that cannot join, frt_pipeline_wait on one of its tickets - or on any
+    //      ticket once the detector has gone idle -, run_dev, sync, set_*, destroy.  A call that finds the detector idle is never held.
+    struct Held {
+        bool on = false;
+        AsyncBuf *base = nullptr;  // the staging set that holds the frames / results / embeddings / crops of every ticket of the call
+        int n = 0, nsub = 0;
+        bool want_embeds = false, want_crops = false;
+        Sub sub[MAXSUB];
+    } held;
+    long merged_calls = 0, merged_tickets = 0;
+    std::string held_error;  // why the last held call could not be queued
+    bool detector_busy() const { return det->busy && hipEventQuery(det->ev_busy) == hipErrorNotReady; }
+    // "backed up": a stage of an earlier call is still running or queued.  (The detector alone is the wrong signal: under load the recogniser is
+    // the bottleneck and the detector is often idle at the moment of a submit - single 4-frame calls then slip in between the merged ones:
+    // measured 0.559 ms per 4-frame step against 0.524 without any merging.)
+    bool backed_up() const { return detector_busy() || recogniser_busy(); }
+    // tickets whose stages are queued and whose results have not left yet (held / pending ones are not counted: nothing of theirs is queued)
+    int tickets_running() const {
+        int n = 0;
+        for (const AsyncBuf &b : abuf) {
+            if (b.ticket < 0 || is_pending(b.ticket)) continue;
+            bool h = false;
+            for (int j = 0; held.on && j < held.nsub; ++j) h = h || held.sub[j].ticket == b.ticket;
+            if (!h && hipEventQuery(b.ev_out) == hipErrorNotReady) ++n;
+        }
+        return n;
+    }
+    // Holding is only free while the GPU has enough queued work to stay busy until the held frames are released: a submit is held only when at
+    // least HOLD_MIN tickets are running, and the held ones go out as soon as fewer are.  Measured with 4-frame calls (tools/proxy_only.py, ms
+    // per call; pairing off 0.71 - 0.72 at every depth): without the threshold 2 / 3 / 4 calls in flight cost 0.98 / 0.86 / 0.74 - a caller that
+    // keeps few calls in flight is latency-coupled to each of them; with HOLD_MIN = 5 and the release rule: <= 5 in flight as without pairing,
+    // 6: 0.58, 7: 0.55, 8: 0.52, 11: 0.49 (profiles/r06_adaptive_hold_sweep.txt).
+    static constexpr int HOLD_MIN = 5;
     unsigned epass = 0;  // recogniser passes queued so far (activation set / stream of the next one)
     long paired_passes = 0, single_passes = 0;
     // is a recogniser pass queued earlier still running (or waiting to run)?  Two event queries, ~ 1 us each
@@ -1890,7 +1936,7 @@ struct frt_pipeline {
         const bool pipe3 = overlap && g_prof_kind == 0 && !serial_call;
         // pairing: this call's later stages wait for the next call - or run together with the waiting call's
         const int gcap = std::min({group < 0 ? (int)MAXG : group, F_cap / F, emb->max_batch / F});  // calls of this size one pass can take
-        const bool pairable = pipe3 && gcap >= 2 && (group > 0 || (group < 0 && (host_req.ab || adaptive_dev)));
+        const bool pairable = pipe3 && gcap >= 2 && (group > 0 || (group < 0 && (host_req.nsub || adaptive_dev)));
         if (npend && !(pairable && pend[0].n == n)) flush_pending();
         const unsigned call = seq++;
         const int slot = (int)(call % NSLOT);
@@ -1945,7 +1991,7 @@ struct frt_pipeline {
         if (pipe3) HIPCHK(hipEventRecord(ev_det[slot], ds));
         if (pairable) {
             // adaptive: hold this call back only while earlier recogniser passes are still in flight; fixed groups: always
-            const bool hold = group > 0 || npend > 0 || recogniser_busy();
+            const bool hold = group > 0 || npend > 0 || (recogniser_busy() && (!cur.nsub || tickets_running() >= HOLD_MIN));
             if (hold) {
                 pend[npend++] = cur;  // nothing else is queued for this call now (the caller's stream joins with the last partner's call)
                 if (npend == gcap || (group < 0 && npend >= 2 && !recogniser_busy())) flush_pending();
@@ -1968,16 +2014,17 @@ struct frt_pipeline {
             // the held calls are lost; their tickets must not be answered from a staging set's STALE "results have left" event: mark them
             // failed and re-arm the event behind whatever did get queued, so that frt_pipeline_wait returns - with the error
             for (int i = 0; i < n; ++i)
-                if (grp[i].ab) {
-                    grp[i].ab->failed = true;
-                    (void)hipEventRecord(grp[i].ab->ev_out, stream);
+                for (int j = 0; j < grp[i].nsub; ++j) {
+                    grp[i].sub[j].ab->failed = true;
+                    (void)hipEventRecord(grp[i].sub[j].ab->ev_out, stream);
                 }
             throw;
         }
     }
     bool is_pending(long ticket) const {
         for (int i = 0; i < npend; ++i)
-            if (pend[i].ticket == ticket) return true;
+            for (int j = 0; j < pend[i].nsub; ++j)
+                if (pend[i].sub[j].ticket == ticket) return true;
         return false;
     }
 
@@ -2058,8 +2105,14 @@ struct frt_pipeline {
                 const int sl = c[i].slot;
                 {
                     ProfScope ps(2, "pack_results", (double)Fc[i], st);
-                    launch_pack_results(slot_boxes[sl], slot_nout[sl], valid + f_off, have_gallery ? d_idx + f_off : nullptr, have_gallery ? d_sim + f_off : nullptr,
-                                        max_faces, Fc[i], c[i].results, st);
+                    // one launch per ticket of the call (merged submits): a ticket's records count ITS frames from zero
+                    const int np = c[i].nsub > 1 ? c[i].nsub : 1;
+                    for (int j = 0, fr = 0; j < np; ++j) {
+                        const int nf = c[i].nsub > 1 ? c[i].sub[j].n : c[i].n, o = fr * max_faces;
+                        launch_pack_results(slot_boxes[sl] + o, slot_nout[sl] + fr, valid + f_off + o, have_gallery ? d_idx + f_off + o : nullptr,
+                                            have_gallery ? d_sim + f_off + o : nullptr, max_faces, nf * max_faces, c[i].results + o, st);
+                        fr += nf;
+                    }
                 }
                 if (c[i].embeds)
                     HIPCHK(hipMemcpyAsync(c[i].embeds, emb_slot + (size_t)f_off * 512, sizeof(float) * 512 * Fc[i], hipMemcpyDeviceToDevice, st));
@@ -2081,12 +2134,17 @@ struct frt_pipeline {
         }
         // calls that came through frt_pipeline_submit: their downloads follow the join
         for (int i = 0; i < nc; ++i) {
-            if (!c[i].ab) continue;
-            AsyncBuf &b = *c[i].ab;
-            HIPCHK(hipMemcpyAsync(c[i].h_results, b.d_results, sizeof(frt_face_result) * Fc[i], hipMemcpyDeviceToHost, s));
-            if (c[i].h_embeds) HIPCHK(hipMemcpyAsync(c[i].h_embeds, b.d_embeds, sizeof(float) * 512 * Fc[i], hipMemcpyDeviceToHost, s));
-            if (c[i].h_crops) HIPCHK(hipMemcpyAsync(c[i].h_crops, b.d_crops, (size_t)Fc[i] * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipEventRecord(b.ev_out, s));
+            size_t o = 0;  // face slots in front of this ticket inside the call's device blocks (c[i].results / .embeds / .crops)
+            for (int j = 0; j < c[i].nsub; ++j) {
+                const Sub &t = c[i].sub[j];
+                const size_t nf = (size_t)t.n * max_faces;
+                HIPCHK(hipMemcpyAsync(t.h_results, c[i].results + o, sizeof(frt_face_result) * nf, hipMemcpyDeviceToHost, s));
+                if (t.h_embeds) HIPCHK(hipMemcpyAsync(t.h_embeds, c[i].embeds + o * 512, sizeof(float) * 512 * nf, hipMemcpyDeviceToHost, s));
+                if (t.h_crops) HIPCHK(hipMemcpyAsync(t.h_crops, c[i].crops + o * 112 * 112 * 3, nf * 112 * 112 * 3, hipMemcpyDeviceToHost, s));
+                o += nf;
+            }
+            // "results have left" only behind the LAST download of the call: the first ticket's staging set carries every ticket's data
+            for (int j = 0; j < c[i].nsub; ++j) HIPCHK(hipEventRecord(c[i].sub[j].ab->ev_out, s));
         }
     }
 };
@@ -3050,11 +3108,12 @@ int frt_pipeline_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int ma
 }
 
 static void pipeline_flush_locked(frt_pipeline *p);
+static void pipeline_start_held(frt_pipeline *p);
 
 void frt_pipeline_destroy(frt_pipeline *p) {
     if (!p) return;
     (void)hipSetDevice(p->det->device);
-    if (p->npend) {  // pairing: calls still waiting for partners run now - a submitted batch is never dropped
+    if (p->npend || p->held.on) {  // pairing / merging: calls still waiting for partners run now - a submitted batch is never dropped
         try {
             std::lock_guard<std::mutex> lk(p->run_mu);
             pipeline_flush_locked(p);
@@ -3108,6 +3167,7 @@ int frt_pipeline_run_dev(frt_pipeline *p, const void *frames_dev, int n_frames, 
         if (!p || !frames_dev || !results_dev) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
         std::lock_guard<std::mutex> lk(p->run_mu);
+        pipeline_start_held(p);  // (submits held back at the host boundary go first)
         pipeline_lock_run(p, frames_dev, n_frames, results_dev, embeds_dev);
     });
 }
@@ -3117,6 +3177,7 @@ int frt_pipeline_run_dev_after(frt_pipeline *p, const void *frames_dev, int n_fr
         if (!p || !frames_dev || !results_dev) raise(FRT_ERR_INVALID, "null argument");
         use_device(p->det->device);
         std::lock_guard<std::mutex> lk(p->run_mu);
+        pipeline_start_held(p);
         p->ev_ready = reinterpret_cast<hipEvent_t>(ready_event);
         try {
             pipeline_lock_run(p, frames_dev, n_frames, results_dev, embeds_dev);
@@ -3238,7 +3299,17 @@ int frt_pipeline_set_pairing(frt_pipeline *p, int enable) {
         use_device(p->det->device);
         pipeline_flush_locked(p);
         p->group = enable < 0 ? -1 : (enable == 0 ? 0 : std::min(std::max(enable, 2), (int)frt_pipeline::MAXG));
-        p->adaptive_dev = enable <= -2;
+        p->adaptive_dev = enable == -2;
+        p->merge_submits = enable != -3;
+    });
+}
+
+int frt_pipeline_merge_stats(frt_pipeline *p, long *merged_calls, long *merged_tickets) {
+    return guarded([&] {
+        if (!p) raise(FRT_ERR_INVALID, "null argument");
+        std::lock_guard<std::mutex> lk(p->run_mu);
+        if (merged_calls) *merged_calls = p->merged_calls;
+        if (merged_tickets) *merged_tickets = p->merged_tickets;
     });
 }
 
@@ -3260,6 +3331,36 @@ int frt_pipeline_pairing_stats(frt_pipeline *p, long *paired_passes, long *singl
     });
 }
 
+static void pipeline_lock_run(frt_pipeline *p, const void *frames_dev, int n_frames, void *results_dev, void *embeds_dev);
+
+// Caller holds p->run_mu: the held submits (merged at the host boundary) go out as ONE call.  Never throws: a failure is left on the tickets
+// (AsyncBuf::failed, reported by frt_pipeline_wait) - the caller of the moment may be somebody else's submit or wait.
+static void pipeline_start_held(frt_pipeline *p) {
+    if (!p->held.on) return;
+    frt_pipeline::Held h = p->held;
+    p->held = frt_pipeline::Held{};
+    p->ev_frames = h.base->ev_h2d;  // recorded behind the last ticket's upload
+    p->crops_req = h.want_crops ? h.base->d_crops : nullptr;
+    p->serial_call = false;
+    p->host_req = frt_pipeline::CallRec{};
+    p->host_req.nsub = h.nsub;
+    for (int j = 0; j < h.nsub; ++j) p->host_req.sub[j] = h.sub[j];
+    try {
+        pipeline_lock_run(p, h.base->d_frames, h.n, h.base->d_results, h.want_embeds ? h.base->d_embeds : nullptr);
+        p->merged_calls += h.nsub > 1;
+        p->merged_tickets += h.nsub > 1 ? h.nsub : 0;
+    } catch (const std::exception &e) {
+        p->held_error = e.what();
+        p->ev_frames = nullptr;
+        p->crops_req = nullptr;
+        p->host_req = frt_pipeline::CallRec{};
+        for (int j = 0; j < h.nsub; ++j) {
+            h.sub[j].ab->failed = true;
+            (void)hipEventRecord(h.sub[j].ab->ev_out, p->stream);
+        }
+    }
+}
+
 // queue one batch through a staging set; caller holds neither mutex
 static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_frames, frt_face_result *results, float *embeds_out, bool synchronous = false,
                                  uint8_t *crops_host = nullptr) {
@@ -3271,15 +3372,59 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     p->ensure_async();
     const long ticket = p->next_ticket;
     frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
-    if (b.ticket >= 0) wait_event_spinning(b.ev_out);  // the staging set is free once its previous batch has left
+    if (b.ticket >= 0) {
+        // (a ticket that is still held back has no "results have left" event yet: its set's event is its previous occupant's)
+        for (int j = 0; j < p->held.nsub; ++j)
+            if (p->held.on && p->held.sub[j].ticket == b.ticket) pipeline_start_held(p);
+        if (p->is_pending(b.ticket)) pipeline_flush_locked(p);
+        wait_event_spinning(b.ev_out);  // the staging set is free once its previous batch has left
+    }
     b.failed = false;
     hipStream_t s = p->stream;
     const size_t fbytes = (size_t)p->det->g.frame_h * p->det->g.frame_w * 3;
+    // ---- adaptive merging at the host boundary (frt_pipeline::Held): join the held call, or become one when the detector is busy
+    {
+        const int K = p->max_faces;
+        const bool mergeable = p->group < 0 && p->merge_submits && p->overlap && g_prof_kind == 0;
+        frt_pipeline::Sub me;
+        me.ab = &b;
+        me.h_results = results;
+        me.h_embeds = embeds_out;
+        me.h_crops = crops_host;
+        me.n = n_frames;
+        me.ticket = ticket;
+        auto join = [&](frt_pipeline::Held &h) {  // this ticket's frames behind the held ones, in the FIRST ticket's staging set
+            HIPCHK(hipMemcpyAsync(h.base->d_frames + fbytes * (size_t)h.n, frames, fbytes * n_frames, hipMemcpyHostToDevice, p->copy_stream));
+            HIPCHK(hipEventRecord(h.base->ev_h2d, p->copy_stream));
+            h.sub[h.nsub++] = me;
+            h.n += n_frames;
+            h.want_embeds = h.want_embeds || embeds_out;
+            h.want_crops = h.want_crops || crops_host;
+            b.ticket = ticket;
+            p->next_ticket = ticket + 1;
+        };
+        if (p->held.on) {
+            const int nt = p->held.n + n_frames;
+            if (mergeable && p->held.nsub < frt_pipeline::MAXSUB && nt <= p->max_frames && nt * K <= p->emb->max_batch) {
+                join(p->held);
+                if (p->held.nsub == frt_pipeline::MAXSUB || 2 * p->held.n > p->max_frames || !p->backed_up() || p->tickets_running() < frt_pipeline::HOLD_MIN)
+                    pipeline_start_held(p);
+                return ticket;
+            }
+            pipeline_start_held(p);  // cannot join: first in, first out
+        }
+        if (mergeable && 2 * n_frames <= p->max_frames && 2 * n_frames * K <= p->emb->max_batch && p->backed_up() && p->tickets_running() >= frt_pipeline::HOLD_MIN) {
+            p->held.on = true;
+            p->held.base = &b;
+            join(p->held);
+            return ticket;
+        }
+    }
     // A synchronous call that finds nothing else in flight (the reference's request / reply shape: one frame, one caller) has nothing to
     // overlap with: upload, detector, recogniser, match and download go down ONE stream - no stream-to-stream event hand-overs on its
     // critical path (5 of them otherwise; one 4-face call 1.02 -> 0.94 ms, profiles/r03/r03u_sync_overlap.txt).  Calls that arrive while
     // another is in flight take the stage streams as before (and are ordered behind this one through ev_serial).
-    bool lone = synchronous && p->overlap && !p->npend;
+    bool lone = synchronous && p->overlap && !p->npend && !p->held.on;
     for (int i = 0; lone && i < frt_pipeline::NBUF; ++i)
         if (p->abuf[i].ticket >= 0 && i != (int)(ticket % frt_pipeline::NBUF) && hipEventQuery(p->abuf[i].ev_out) != hipSuccess) lone = false;
     if (lone) {
@@ -3293,11 +3438,13 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
     p->crops_req = crops_host ? b.d_crops : nullptr;
     // the downloads and the "results have left" event are queued by the pipeline behind this call's match stage - now, or (pairing) with the next call
     p->host_req = frt_pipeline::CallRec{};
-    p->host_req.ab = &b;
-    p->host_req.h_results = results;
-    p->host_req.h_embeds = embeds_out;
-    p->host_req.h_crops = crops_host;
-    p->host_req.ticket = ticket;
+    p->host_req.nsub = 1;
+    p->host_req.sub[0].ab = &b;
+    p->host_req.sub[0].h_results = results;
+    p->host_req.sub[0].h_embeds = embeds_out;
+    p->host_req.sub[0].h_crops = crops_host;
+    p->host_req.sub[0].n = n_frames;
+    p->host_req.sub[0].ticket = ticket;
     try {
         pipeline_lock_run(p, b.d_frames, n_frames, b.d_results, embeds_out ? b.d_embeds : nullptr);
     } catch (...) {
@@ -3315,6 +3462,7 @@ static long pipeline_submit_impl(frt_pipeline *p, const uint8_t *frames, int n_f
 
 // Caller holds p->run_mu: queue the later stages of a call that is waiting for a partner (pairing).
 static void pipeline_flush_locked(frt_pipeline *p) {
+    pipeline_start_held(p);  // (takes the object mutexes itself)
     if (!p->npend) return;
     std::lock_guard<std::mutex> l1(p->det->mu);
     std::lock_guard<std::mutex> l2(p->emb->mu);
@@ -3335,6 +3483,11 @@ static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
             std::lock_guard<std::mutex> lr(p->run_mu);
             // pairing: the partners that would share its recogniser pass have not come; adaptive pairing: calls held back behind a busy
             // recogniser go out as soon as a waiting caller finds it idle (they would be running by now had they not been held)
+            if (p->held.on) {  // submits merged at the host boundary: one of its tickets is being waited for, or the detector has gone idle
+                bool mine = false;
+                for (int j = 0; j < p->held.nsub; ++j) mine = mine || p->held.sub[j].ticket == ticket;
+                if (mine || !p->backed_up() || p->tickets_running() < frt_pipeline::HOLD_MIN) pipeline_start_held(p);
+            }
             if (p->is_pending(ticket) || (p->npend && p->group < 0 && !p->recogniser_busy())) pipeline_flush_locked(p);
         }
         ev = b.ev_out;
@@ -3343,7 +3496,8 @@ static void pipeline_wait_impl(frt_pipeline *p, long ticket) {
     {
         std::lock_guard<std::mutex> lk(p->async_mu);
         frt_pipeline::AsyncBuf &b = p->abuf[ticket % frt_pipeline::NBUF];
-        if (b.ticket == ticket && b.failed) raise(FRT_ERR_DEVICE, "pipeline: the later stages of this call could not be queued (see the error of the call that flushed it)");
+        if (b.ticket == ticket && b.failed)
+            raise(FRT_ERR_DEVICE, "pipeline: the held stages of this call could not be queued" + (p->held_error.empty() ? std::string() : ": " + p->held_error));
     }
     p->emb->check_se_error();
 }

@@ -329,12 +329,16 @@ int frt_pipeline_set_graph(frt_pipeline *p, int enable);
  * scans the gallery once whatever the number of queries.  The crop + recogniser + match stages of up to four CONSECUTIVE calls can run as
  * ONE pass: a call's detector stage is queued at the call as always; its later stages are queued together with a later call's.
  *
- * enable = -1 (DEFAULT since round 6): ADAPTIVE, frt_pipeline_submit calls only.  A call's later stages are held back only while the
- *   recogniser is still busy with earlier calls - the pass could not start now anyway - and go out with the next call's (up to four calls
- *   per pass while the backlog lasts).  A call that finds the recogniser idle is queued at once: a lone caller sees exactly the unpaired
- *   pipeline and its latency.  Held calls are released by the next submit, by frt_pipeline_wait on their ticket, by frt_pipeline_wait on
- *   any ticket once the recogniser has gone idle, by frt_pipeline_sync and by any frt_pipeline_set_*; the submit / wait contract is unchanged.
- *   frt_pipeline_run_dev calls are never held in this mode (their contract is the join on the pipeline stream AT the call).
+ * enable = -1 (DEFAULT since round 6): ADAPTIVE, frt_pipeline_submit calls only.  A call is held back only while the pipeline is backed up
+ *   AND at least five earlier tickets are still running - the GPU then has work queued for longer than the held call waits (a caller that
+ *   keeps two to four calls in flight is latency-coupled to each of them: any holding measured 3 - 20 % slower there, so it gets none).  Held
+ *   submits are MERGED: the next submits' frames join the held ones in one staging set (up to four tickets / the pipeline's capacity) and run
+ *   as ONE call - one detector pass, one recogniser pass, one match call, per-ticket result downloads (frt_pipeline_merge_stats); beyond that
+ *   a call's recogniser pass may still wait for the next call's.  A call that finds the pipeline idle is queued at once: a lone caller sees
+ *   exactly the unpaired pipeline and its latency.  Held calls are released by the submit that fills them or finds fewer than five tickets
+ *   running, by frt_pipeline_wait on one of their tickets (or on any ticket once the backlog is gone), by frt_pipeline_run_dev,
+ *   frt_pipeline_sync and any frt_pipeline_set_*; the submit / wait contract is unchanged.  frt_pipeline_run_dev calls are never held in
+ *   this mode (their contract is the join on the pipeline stream AT the call).  -3: the same without the merging of submits.
  * enable = -2: adaptive for frt_pipeline_run_dev calls too.  What changes for such a caller: the pipeline stream joins a held call's results
  *   at a LATER call (or at frt_pipeline_sync), not at the call itself, and the frames must stay valid until then.
  * enable = 0: off.  enable = 1 or 2: ALWAYS pairs; 3, 4: always groups of three / four (both boundaries; results complete when the group
@@ -348,6 +352,12 @@ int frt_pipeline_set_graph(frt_pipeline *p, int enable);
  * frt_pipeline_pairing_stats counts the recogniser passes that served several calls and those that served one. */
 int frt_pipeline_set_pairing(frt_pipeline *p, int enable);
 int frt_pipeline_pairing_stats(frt_pipeline *p, long *paired_passes_out, long *single_passes_out);
+/* Adaptive mode, host boundary: a frt_pipeline_submit that finds the DETECTOR still busy with earlier calls is not queued at once - its frames are
+ * uploaded and held, the next submit's frames join them (up to 4 tickets / the pipeline's capacity), and the held frames run as ONE call: one
+ * detector pass, one recogniser pass, one match call, per-ticket downloads (a 4-frame detector pass costs 258 us of kernels, a 32-frame one
+ * 809).  Released like a held pass (above); a submit that finds the detector idle is never held.  Counts the calls that carried several
+ * tickets and the tickets they carried. */
+int frt_pipeline_merge_stats(frt_pipeline *p, long *merged_calls_out, long *merged_tickets_out);
 /* hipGraph replay (frt_pipeline_set_graph): stage graphs captured / replayed so far (a key is captured on its second sighting). */
 int frt_pipeline_graph_stats(frt_pipeline *p, long *captured_out, long *replayed_out);
 
