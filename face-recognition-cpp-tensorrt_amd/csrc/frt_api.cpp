@@ -732,7 +732,7 @@ struct frt_embedder {
     // ---- fp32 end-to-end mode (frt_embedder_set_precision(e, 1); kernels_arc_f32.hip): its own weights and activation buffers, built on
     //      first use from the blob the object was created from
     struct F32Unit {
-        float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // [Cout][tap][Cin] fp32
+        float *w1 = nullptr, *w2 = nullptr, *wsc = nullptr;  // [Cout][tap][Cin] fp32 in conv32_kernel's fragment order
     };
     struct F32 {
         std::vector<void *> owned;   // device allocations of this mode
@@ -1043,7 +1043,15 @@ void frt_embedder::build_f32() {
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t) w[((size_t)co * 9 + t) * cin + ci] = src[((size_t)co * cin + ci) * 9 + t];
-        return up(w);
+        std::vector<float> wf(w.size());
+        pack_conv32_weights(w.data(), cout, 9, cin, wf.data());
+        return up(wf);
+    };
+    auto w1x1 = [&](const std::string &name, int cout, int cin) {
+        const std::vector<float> w = vec_of(b, name, (size_t)cout * cin);
+        std::vector<float> wf(w.size());
+        pack_conv32_weights(w.data(), cout, 1, cin, wf.data());
+        return up(wf);
     };
     int idx = 0;
     for (const ArcUnit &u : units) {
@@ -1051,7 +1059,7 @@ void frt_embedder::build_f32() {
         F32Unit fu;
         fu.w1 = w3(p + ".res_layer.1.weight", u.depth, u.cin);
         fu.w2 = w3(p + ".res_layer.3.weight", u.depth, u.depth);
-        if (u.wsc) fu.wsc = up(vec_of(b, p + ".shortcut_layer.0.weight", (size_t)u.depth * u.cin));
+        if (u.wsc) fu.wsc = w1x1(p + ".shortcut_layer.0.weight", u.depth, u.cin);
         f32.units.push_back(fu);
     }
     {

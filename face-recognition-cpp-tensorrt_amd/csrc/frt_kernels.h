@@ -251,7 +251,7 @@ void launch_fc_slices(const half_t *z, const half_t *wfrag, int F, float *partia
 // partial [splits][F][512] -> +bias -> BN1d -> L2 normalise -> out [F][512] fp32; rows with valid[f]==0 become zeros.
 // fp32 end-to-end recogniser path (kernels_arc_f32.hip; frt_embedder_set_precision)
 struct Conv32Args {
-    const float *x, *w, *ps, *pb;
+    const float *x, *w, *ps, *pb;  // w: fragment-ordered (pack_conv32_weights)
     float *out;
     int F, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, mode;  // mode 0: PReLU(p0)  1: BN(p0, p1)  2: BN(p0, p1) + shortcut
     const float *p0, *p1, *sc;
@@ -259,6 +259,7 @@ struct Conv32Args {
 };
 void launch_arc32_input(const float *x, const float *w, const float *s0, const float *b0, const float *slope, float *y, int F, hipStream_t s);
 void launch_conv32(const Conv32Args &c, hipStream_t s);
+void pack_conv32_weights(const float *w, int cout, int taps, int cin, float *out);  // host: [Cout][taps][Cin] -> the kernel's fragment order
 void launch_fc32(const float *y, const float *sn, const float *bn, const float *w, float *out, int F, hipStream_t s);
 void launch_se32(const float *res, const float *w1, const float *w2, float *gate, const float *sc, float *out, int F, int Ho, int Wo, int C, int sc_h, int sc_w, int sc_stride,
                  hipStream_t s);

@@ -16,6 +16,8 @@ tmp = tempfile.mkdtemp()
 MODE = os.environ.get("FRT_PROF_MODE", "ir")
 path = frt.write_weights(os.path.join(tmp, "rec.frtw"), s.arcface_state(2, MODE, calib=s.load_calibration(MODE)), 2 if MODE == "ir" else 3)
 rec = frt.ArcFaceIR50(path, maxBatchSize=F)
+if os.environ.get("FRT_PROF_FP32"):
+    rec.setPrecision(True)
 x = np.random.default_rng(0).standard_normal((F, 3, 112, 112)).astype(np.float32) * 0.5
 for _ in range(reps):
     e = rec.doInference(x)
