@@ -294,6 +294,8 @@ def main():
     ap.add_argument("--stage-profile", default=None, help="write a per-stage HIP-event breakdown (extra untimed steps) to this file")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (no side measurements)")
+    ap.add_argument("--ab-old-lib", default=None, help="measurement only: run the timed region on an OLDER build of libfrt.so (path) for a same-box A/B "
+                                                       "(tools/ab_lib.sh); symbols it lacks are skipped with a warning.  Never a reported number")
     ap.add_argument("--smi-trace", default=None, help="write the rocm-smi power/clock samples taken during the timed region to this file")
     ap.add_argument("--wait-spin-us", type=int, default=50000,
                     help="how long libfrt's host waits busy-poll before they back off (frt_set_wait_spin_us).  The library's default is 200 us "
@@ -325,6 +327,10 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.ab_old_lib:
+        import types
+        os.environ["FRT_LIB"] = os.path.abspath(args.ab_old_lib)
+        sys.modules["frt_amd_ab_old_library"] = types.ModuleType("frt_amd_ab_old_library")  # (the binding's import is strict otherwise)
     import __graft_entry__ as entry
     frt = entry.load_pkg()
     fd = frt.dist
@@ -377,10 +383,7 @@ def main():
     gallery_load_s = time.perf_counter() - t_load
     if args.exact_match:
         rec.matmul.setScreening(False)
-    try:
-        _sb = rec.matmul.scanBytes()
-    except AttributeError:  # (FRT_LIB_OLD=1: an older library in a same-box A/B)
-        _sb = 512 * args.gallery if args.gallery >= 32768 else 2048 * args.gallery
+    _sb = rec.matmul.scanBytes()
     _rows = max(int(frt.lib.frt_matcher_num_rows(rec.matmul._h)), 1)
     scan_mode = "int8" if _sb == 512 * _rows else ("fp16" if (_sb == 1024 * _rows and not args.sharded_gallery) else "exact")
     pipe = frt.Pipeline(det, rec, B * cap, match=not args.sharded_gallery)  # sharded gallery: the pipeline produces embeddings, match + merge follow below

@@ -178,7 +178,9 @@ int frt_coalescer_create(frt_detector *d, frt_embedder *e, frt_matcher *m, int m
         c->max_faces = mf;
         c->fbytes = (size_t)fw * fh * 3;
         c->window_us = window_us;
+#ifdef FRT_TUNING  // (measurement builds only: batches in flight behind the coalescer)
         if (const char *e = getenv("FRT_COALESCE_INFLIGHT")) c->kInflight = std::max(1, std::min(3, atoi(e)));
+#endif
         auto cleanup = [&] {
             for (auto &b : c->batch) {
                 frt_pinned_free(b.h_frames);

@@ -307,20 +307,20 @@ int frt_pipeline_set_input_sync(frt_pipeline *p, int enable);
  * runs in order).  This call MEASURES it: one 150 us single-wave probe kernel per stream, started together; *ratio_out = elapsed /
  * 150 us, about 1 when they run side by side, about n when n of them share a queue.  Above 1.5 the call still returns FRT_OK but
  * frt_last_error() holds a warning (also printed to stderr once unless FRT_QUIET is set) naming the remedy.  The same check runs over
- * the stage streams alone inside frt_pipeline_create (about 1 ms; env FRT_PIPELINE_SELFCHECK=0 skips it); call this one after
+ * the stage streams alone inside frt_pipeline_create (about 1 ms); call this one after
  * frt_pipeline_set_stream and after every other stream of the process (RCCL, copy streams) exists.  Waits for work in flight. */
 int frt_pipeline_check_overlap(frt_pipeline *p, float *ratio_out);
 int frt_pipeline_sync(frt_pipeline *p);
 /* Run on a caller-owned HIP stream (a hipStream_t passed as void*, e.g. PyTorch's current stream, so that RCCL collectives
  * issued by the caller are ordered after the pipeline without a host synchronisation).  NULL restores the private stream. */
 int frt_pipeline_set_stream(frt_pipeline *p, void *hip_stream);
-/* Software pipelining across calls (default on; env FRT_PIPELINE_OVERLAP=0 disables): detector of call b+1, crop + recogniser of
+/* Software pipelining across calls (default on): detector of call b+1, crop + recogniser of
  * call b and match + pack of call b-1 run on three internal streams; the pipeline stream joins at the end of every call, so
  * results stay ordered on it exactly as if the call had run there.  With overlap on, the frames passed to
  * frt_pipeline_run_dev must already be valid when the call is made (the internal streams do not wait for earlier work on
  * the pipeline stream) and must stay unchanged until that call's results are complete on the pipeline stream. */
 int frt_pipeline_set_overlap(frt_pipeline *p, int enable);
-/* hipGraph replay of a call's ~150 launches (opt-in: env FRT_PIPELINE_GRAPH=1 or this call; measured neutral on one GPU).  A call whose buffers, batch size
+/* hipGraph replay of a call's ~150 launches (opt-in through this call; measured neutral on one GPU).  A call whose buffers, batch size
  * and mode repeat is captured on its second occurrence and replayed afterwards; callers that never repeat their buffers stay
  * on eager launches.  Automatically off while frt_profile_enable() records events. */
 int frt_pipeline_set_graph(frt_pipeline *p, int enable);

@@ -10,16 +10,16 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-OLD="FRT_LIB=$ROOT/face-recognition-cpp-tensorrt_amd/$OLDLIB"
-leg() {  # label, env...
+OLD="--ab-old-lib $ROOT/face-recognition-cpp-tensorrt_amd/$OLDLIB"
+leg() {  # label, extra bench arguments...
   local label=$1; shift
-  env "$@" python bench.py $ARGS --no-cpu-baseline --no-extras --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$label', d['value'], d['ms_per_step'])"
+  python bench.py $ARGS "$@" --no-cpu-baseline --no-extras --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$label', d['value'], d['ms_per_step'])"
 }
 {
 echo "# bench.py $ARGS  (old = $OLDLIB)"
 for i in $(seq $LEGS); do
   leg old $OLD
-  leg new FRT_AB=new
+  leg new
 done
 } > "$OUT/ab.txt" 2>&1
 cat "$OUT/ab.txt"
