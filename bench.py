@@ -643,7 +643,7 @@ def main():
                                 "time includes other streams' dispatches)" % (args.steps, args.steps)}
             try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_profiles.sh)
                 import glob
-                for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
+                for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "*_pmc_hbm.json"), recursive=True), reverse=True):  # newest round first
                     with open(path) as f:
                         pmc = json.load(f)
                     per = pmc.get("per_kernel", {})

@@ -62,7 +62,7 @@ struct frt_pipeline {
     std::mutex async_mu;
 
     // ---- pairing (frt_pipeline_set_pairing; off by default).  A recogniser pass over 16 faces costs 0.59 ms, one over 32 faces 0.92 ms
-    //      (profiles/r05p_small_batch_layers.txt: below ~ 64 faces a pass is a chain of launch latencies, not work), and one match call scans
+    //      (profiles/r05z_small_batch_layers.txt: below ~ 64 faces a pass is a chain of launch latencies, not work), and one match call scans
     //      the gallery once whatever the number of queries.  With pairing on, the crop + recogniser + match stages of TWO consecutive calls
     //      run as one pass: a call's detector stage is queued at the call as always, its later stages wait for the next call (or for a
     //      flush: frt_pipeline_wait on its ticket, frt_pipeline_sync, any mode switch).  Nothing about a result changes except when it is

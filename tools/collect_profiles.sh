@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the per-round measurement artefacts on the GPU box (run via gpurun from the repo root):
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
-# then copy gpurun_out/profiles_<tag>/* into profiles/.  PMC passes run separately from the kernel trace (see the pool rule).
+# then copy gpurun_out/profiles_<tag>/* into profiles/<round>/ (profiles/r06/ for tag r06z).  PMC passes run separately from the kernel trace (see the pool rule).
 set -u
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -54,7 +54,7 @@ json.dump({"per_kernel": mo, "note": "rocprofv3 --pmc (one pass) over tools/prof
            "SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD with the matrix pipe busy (1024 SIMDs), GRBM_GUI_ACTIVE is per-XCD busy cycles (8 XCDs)"},
           open(sys.argv[2], "w"), indent=1)
 PYEOF
-cp "$OUT/${TAG}_pmc_hbm.json" "$ROOT/profiles/" 2>/dev/null   # bench.py reads the newest profiles/*_pmc_hbm.json for roofline.traffic
+mkdir -p "$ROOT/profiles/${TAG:0:3}" && cp "$OUT/${TAG}_pmc_hbm.json" "$ROOT/profiles/${TAG:0:3}/" 2>/dev/null   # bench.py reads the newest profiles/*/*_pmc_hbm.json for roofline.traffic
 cd "$ROOT"
 # 3. the benchmark: driver-style line, default line (+ stage breakdown), power/clock trace over a long region
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver.json" 2> "$OUT/${TAG}_bench_driver.stderr"
