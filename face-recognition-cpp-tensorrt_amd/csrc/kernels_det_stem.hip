@@ -62,11 +62,32 @@ __device__ __forceinline__ void ld_pairs(const P w, int chunk, floatx2 (&dst)[NP
     for (int c = 0; c < NP; ++c) dst[c] = floatx2{w[chunk * 2 * NP + 2 * c], w[chunk * 2 * NP + 2 * c + 1]};
 }
 
+// Round 6: the two long FMA chains - the first conv's 27 x 8 and block 1's pointwise 8 x 16 - run on the MATRIX pipe, which idled until P3.
+// v_mfma_f32_4x4x1_16B_f32 is 16 independent 4x4 outer products D[i][j] += A[i] B[j]; with CBSZ = 4 the four A values of ONE block (ABID) are
+// broadcast to all 16 blocks, and with the lane's own value as B lane l's four accumulator registers become acc[i] += w[i] * x: four fused
+// multiply-adds of the lane's value with four weights - bit for bit the fmaf chain (tools/ubench/mfma_4x4_fma.hip: 0 of 256 values differ after
+// 27 steps; 4.3 ns per instruction and SIMD).  One VECTOR register carries 16 weight quads (lane l: quad l / 4, element l & 3), the quad is
+// picked by the ABID immediate: the first conv's 54 quads are 4 registers, the pointwise conv's 32 are 2 - no scalar weight stream in P1 at all
+// (it was 27 s_load_dwordx8 per position pass with an lgkmcnt(0) in front of every second one), a third of the kernel's vector instructions
+// gone.  The chains keep their order ((ci, tap) ascending; cin ascending), so the output is unchanged bit for bit (FRT_DET_STEM_CHECK, tests).
+struct StemW {
+    float w1[4];  // first conv: quad Q = (ci * 9 + tap) * 2 + (cout quad) lives in w1[Q / 16], block Q % 16
+    float wp[2];  // block 1 pointwise: quad Q = cin * 4 + (cout quad)
+};
+template <int Q>
+__device__ __forceinline__ floatx4 fma4(const float (&w)[4], float x, floatx4 acc) {  // acc[i] += W[quad Q][i] * x
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(w[Q / 16], x, acc, 4, Q % 16, 0);
+}
+template <int Q>
+__device__ __forceinline__ floatx4 fma4p(const float (&w)[2], float x, floatx4 acc) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(w[Q / 16], x, acc, 4, Q % 16, 0);
+}
+
 // INTERIOR: the tile's regions lie inside the 320x320 map and every tap of the first conv inside the frame (81 % of the tiles at 640x640):
 // no validity masks anywhere.  LDS is position-major ([position][channel]): a tap's 8 / 16 channels are two / four ds_read_b128, and the
 // channel pairs they deliver are the operands of v_pk_fma_f32 (weights: scalar pairs, host-packed [pair][tap][2] for the depthwise parts).
 template <bool INTERIOR>
-__device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], float (*b1s)[16], int b, int Y0, int X0) {
+__device__ __forceinline__ void stem_body(const StemArgs &a, const StemW &W, float (*c1)[8], float (*b1s)[16], int b, int Y0, int X0) {
     constexpr int NT = 192;  // three waves per tile split the positions of P1 and P2 (measured at 32 frames, interior + ring: one wave 134 + 68 us, two 106 + 50, four 97 + 45, three 94 + 43: more waves per LDS byte against emptier passes); wave 0 alone runs P3
     const int lane = threadIdx.x;  // (position index in P1 / P2; < 64: the P3 lane)
     const int r2y0 = 2 * Y0 - 1, r2x0 = 2 * X0 - 1;  // block 1 region origin (H1 x W1 map)
@@ -93,10 +114,7 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
             ldraw(lane, raw);
 #pragma unroll 1
             for (int idx = lane; idx < R1 * R1; idx += NT) {
-                int z;
-                asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-                const auto w = uni(a.w1) + z;
-                const auto bias = uni(a.b1) + z;
+                const auto bias = uni(a.b1);
                 ldraw(idx + NT, nxt);
                 float v[3][9];
 #pragma unroll
@@ -108,26 +126,17 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
 #pragma unroll
                         for (int ci = 0; ci < 3; ++ci) v[ci][kh * 3 + kw] = (float)by[kw * 3 + ci] - mean[ci];
                 }
-                floatx2 acc[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = floatx2{0.f, 0.f};
-                constexpr int D = 2;
-                floatx2 wc[D + 1][4];
-                static_for<0, D>([&](auto jc) { ld_pairs<4>(w, decltype(jc)::value, wc[decltype(jc)::value]); });
+                floatx4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;  // couts 0-3 / 4-7; chunk i = (ci, tap): the chain order of det_conv1_u8_kernel
                 static_for<0, 27>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    if constexpr (i + D < 27) ld_pairs<4>(w, i + D, wc[(i + D) % (D + 1)]);
-                    const float x = v[i / 9][i % 9];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_elementwise_fma(floatx2{x, x}, wc[i % (D + 1)][c], acc[c]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    q0 = fma4<2 * i>(W.w1, v[i / 9][i % 9], q0);
+                    q1 = fma4<2 * i + 1>(W.w1, v[i / 9][i % 9], q1);
                 });
                 floatx4 o0, o1;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float ov = fmaxf(acc[c >> 1][c & 1] + bias[c], 0.f);
-                    if (c < 4) o0[c] = ov;
-                    else o1[c - 4] = ov;
+                for (int c = 0; c < 4; ++c) {
+                    o0[c] = fmaxf(q0[c] + bias[c], 0.f);
+                    o1[c] = fmaxf(q1[c] + bias[4 + c], 0.f);
                 }
                 *reinterpret_cast<floatx4 *>(&c1[idx][0]) = o0;
                 *reinterpret_cast<floatx4 *>(&c1[idx][4]) = o1;
@@ -138,16 +147,11 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
 #pragma unroll 1
         for (int idx = lane; idx < R1 * R1; idx += NT) {
             // (an opaque zero: without it the 224 scalar weight loads are hoisted out of the loop and spilled - 569 SGPR spills)
-            int z;
-            asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-            const auto w = uni(a.w1) + z;
-            const auto bias = uni(a.b1) + z;
+            const auto bias = uni(a.b1);
             const int cy = idx / R1, cx = idx - cy * R1;
             const int oh = r1y0 + cy, ow = r1x0 + cx;
             const bool inside = INTERIOR || (oh >= 0 && oh < a.H1 && ow >= 0 && ow < a.W1);
-            floatx2 acc[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = floatx2{0.f, 0.f};
+            floatx4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
             if (inside) {
                 float v[3][9];
                 if (INTERIOR || ow * 2 + 1 < a.W) {
@@ -184,24 +188,17 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
                             }
                         }
                 }
-                constexpr int D = INTERIOR ? 3 : 1;  // chunks of scalar weights in flight ahead of the one in use (scalar registers permitting)
-                floatx2 wc[D + 1][4];
-                static_for<0, D>([&](auto jc) { ld_pairs<4>(w, decltype(jc)::value, wc[decltype(jc)::value]); });
                 static_for<0, 27>([&](auto ic) {  // chunk i = (ci, tap): the eight output channels' weights of one input value
                     constexpr int i = decltype(ic)::value;
-                    if constexpr (i + D < 27) ld_pairs<4>(w, i + D, wc[(i + D) % (D + 1)]);
-                    const float x = v[i / 9][i % 9];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_elementwise_fma(floatx2{x, x}, wc[i % (D + 1)][c], acc[c]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    q0 = fma4<2 * i>(W.w1, v[i / 9][i % 9], q0);
+                    q1 = fma4<2 * i + 1>(W.w1, v[i / 9][i % 9], q1);
                 });
             }
             floatx4 o0, o1;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float v = inside ? fmaxf(acc[c >> 1][c & 1] + bias[c], 0.f) : 0.f;
-                if (c < 4) o0[c] = v;
-                else o1[c - 4] = v;
+            for (int c = 0; c < 4; ++c) {
+                o0[c] = inside ? fmaxf(q0[c] + bias[c], 0.f) : 0.f;
+                o1[c] = inside ? fmaxf(q1[c] + bias[4 + c], 0.f) : 0.f;
             }
             *reinterpret_cast<floatx4 *>(&c1[idx][0]) = o0;
             *reinterpret_cast<floatx4 *>(&c1[idx][4]) = o1;
@@ -215,7 +212,7 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
         for (int idx = lane; idx < R2 * R2; idx += NT) {
             int z;
             asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-            const auto wdt = uni(a.wdt1) + z, wp = uni(a.wp1) + z, bp = uni(a.bp1) + z;
+            const auto wdt = uni(a.wdt1) + z, bp = uni(a.bp1) + z;
             const int by = idx / R2, bx = idx - by * R2;
             const bool inside = INTERIOR || (r2y0 + by >= 0 && r2y0 + by < a.H1 && r2x0 + bx >= 0 && r2x0 + bx < a.W1);
             floatx2 dd[4];  // depthwise outputs, channel pairs; weights tap-major [tap | bias][pair][2]
@@ -236,29 +233,22 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
-            floatx2 acc[8];
+            floatx4 accq[4];  // cout quads; cin ascending: the chain order of dwpw_row4_kernel<16>
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = floatx2{0.f, 0.f};
-            {
-                floatx2 wc[2][8];
-                ld_pairs<8>(wp, 0, wc[0]);
-                static_for<0, 8>([&](auto cc) {
-                    constexpr int ci = decltype(cc)::value;
-                    if constexpr (ci + 1 < 8) ld_pairs<8>(wp, ci + 1, wc[(ci + 1) & 1]);
-                    const float d = fmaxf(dd[ci >> 1][ci & 1], 0.f);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[c] = __builtin_elementwise_fma(floatx2{d, d}, wc[ci & 1][c], acc[c]);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
+            for (int q = 0; q < 4; ++q) accq[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+            static_for<0, 8>([&](auto cc) {
+                constexpr int ci = decltype(cc)::value;
+                const float d = fmaxf(dd[ci >> 1][ci & 1], 0.f);
+                accq[0] = fma4p<4 * ci>(W.wp, d, accq[0]);
+                accq[1] = fma4p<4 * ci + 1>(W.wp, d, accq[1]);
+                accq[2] = fma4p<4 * ci + 2>(W.wp, d, accq[2]);
+                accq[3] = fma4p<4 * ci + 3>(W.wp, d, accq[3]);
+            });
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 floatx4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = 4 * q + e;
-                    o[e] = inside ? fmaxf(acc[c >> 1][c & 1] + bp[c], 0.f) : 0.f;
-                }
+                for (int e = 0; e < 4; ++e) o[e] = inside ? fmaxf(accq[q][e] + bp[4 * q + e], 0.f) : 0.f;
                 *reinterpret_cast<floatx4 *>(&b1s[idx][4 * q]) = o;
             }
         }
@@ -332,6 +322,18 @@ __device__ __forceinline__ void stem_body(const StemArgs &a, float (*c1)[8], flo
 __global__ __launch_bounds__(192) void det_stem_kernel(StemArgs a, int n_interior) {
     __shared__ __attribute__((aligned(16))) float c1[R1 * R1][8];
     __shared__ __attribute__((aligned(16))) float b1s[R2 * R2][16];
+    StemW W;  // lane l: quad (16 k + l / 4), element l & 3 of the first conv's [27][8] = 54 quads (k < 4; the last 10 quads unused) and of
+              // the pointwise conv's [8][16] = 32 quads (k < 2)
+    {
+        const int l = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = 16 * k + (l >> 2);
+            W.w1[k] = q < 54 ? a.w1[q * 4 + (l & 3)] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) W.wp[k] = a.wp1[(16 * k + (l >> 2)) * 4 + (l & 3)];
+    }
     const int tiles_x = a.W2 >> 3, tiles_y = a.H2 >> 3;
     int t = blockIdx.x, b, ty, tx;
     if (t < n_interior) {
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(192) void det_stem_kernel(StemArgs a, int n_interio
         ty = t / ix;
         tx = t - ty * ix + 1;
         ty += 1;
-        stem_body<true>(a, c1, b1s, b, ty * 8, tx * 8);
+        stem_body<true>(a, W, c1, b1s, b, ty * 8, tx * 8);
     } else {  // the ring: top row, bottom row, then the left / right columns of the rows in between
         t -= n_interior;
         const int per = 2 * tiles_x + 2 * (tiles_y - 2);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(192) void det_stem_kernel(StemArgs a, int n_interio
         if (t < tiles_x) { ty = 0; tx = t; }
         else if (t < 2 * tiles_x) { ty = tiles_y - 1; tx = t - tiles_x; }
         else { t -= 2 * tiles_x; ty = 1 + (t >> 1); tx = (t & 1) ? tiles_x - 1 : 0; }
-        stem_body<false>(a, c1, b1s, b, ty * 8, tx * 8);
+        stem_body<false>(a, W, c1, b1s, b, ty * 8, tx * 8);
     }
 }
 
