@@ -20,6 +20,8 @@
 //     are pure latency on their own and hide inside the 80x80 level's launch.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "frt_kernels.h"
 
 namespace {
@@ -160,8 +162,20 @@ __global__ __launch_bounds__(256) void dwpw_kernel(DwPwArgs a) {
 // NS = slots of the input prefetch ring (NS - 1 channels in flight ahead of the one being consumed): at 176-240 registers only two
 // waves fit a SIMD, so the bytes in flight per CU come from the ring depth (one channel ahead = 37 KB per CU: 2.3 TB/s on the 8 -> 16
 // block at 320x320).
-template <int CT, int NS = 2>
-__global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
+// MF (round 6, CT = 32 with two channels per ring step): the pointwise chain - 128 of the ~ 190 vector instructions per input channel - runs on the
+// matrix pipe: v_mfma_f32_4x4x1_16B_f32 with CBSZ = 4 is acc[i] += w[ABID][i] * x per lane (kernels_det_stem.hip), one vector register holds the
+// 16 weight quads of two input channels (read from LDS once per ring round), pixel q's accumulators are 8 quads.  Same chain order (cin
+// ascending) = same bits as the fmaf chain.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_dw(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_dw<I + 1, N>(f);
+    }
+}
+template <int CT, int NS = 2, bool MF = false>
+__global__ __launch_bounds__(256, MF ? 2 : 1) void dwpw_row4_kernel(DwPwArgs a) {
+    static_assert(!MF || (CT == 32 && NS == 2), "matrix-pipe pointwise: 8 cout quads x 2 channels = the 16 blocks of one A register");
     constexpr int REC = 12 + CT;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int co0 = blockIdx.y * CT;  // (grid.y > 1: a frame or two, narrower channel tiles = more waves; the depthwise part is recomputed per tile)
@@ -172,6 +186,13 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
         else if (r == 9) v = a.bd[ci];
         else if (r >= 12) v = a.wp[(long)ci * a.Cout + co0 + (r - 12)];
         wsm[i] = v;
+    }
+    if constexpr (MF) {  // A registers: [channel pair][lane]: lane l = block l / 4 = (channel l / 32, cout quad (l / 4) % 8), element l & 3
+        float *wa = wsm + a.Cin * REC;
+        for (int i = threadIdx.x; i < a.Cin * 32; i += 256) {
+            const int pr = i >> 6, l = i & 63;
+            wa[i] = a.wp[(long)(2 * pr + (l >> 5)) * a.Cout + co0 + ((l >> 2) & 7) * 4 + (l & 3)];
+        }
     }
     __syncthreads();
     const int W4 = a.W >> 2, HW = a.H * a.W;
@@ -193,11 +214,16 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
     const bool lok = ow0 > 0, rok = ow0 + 4 < a.W;
     const int loff = lok ? -1 : 0, roff_r = rok ? 4 : 3;
 
-    float acc[4][CT];
+    float acc[MF ? 1 : 4][MF ? 1 : CT];
+    floatx4 acc4[MF ? 4 : 1][MF ? CT / 4 : 1];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < (MF ? 1 : 4); ++q)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[q][c] = 0.f;
+        for (int c = 0; c < (MF ? 1 : CT); ++c) acc[q][c] = 0.f;
+#pragma unroll
+    for (int q = 0; q < (MF ? 4 : 1); ++q)
+#pragma unroll
+        for (int c = 0; c < (MF ? CT / 4 : 1); ++c) acc4[q][c] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     floatx4 mid[NS][3];
     float lft[NS][3], rgt[NS][3];
@@ -214,6 +240,8 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
     for (int sl = 0; sl < NS - 1; ++sl)
         if (sl < a.Cin) fetch(sl, sl);
     for (int ci = 0; ci < a.Cin; ci += NS) {
+        float wA = 0.f;
+        if constexpr (MF) wA = wsm[a.Cin * REC + (ci >> 1) * 64 + (threadIdx.x & 63)];
 #pragma unroll
         for (int half = 0; half < NS; ++half) {  // (compile-time ring slot)
             const int c_ = ci + half;
@@ -242,16 +270,27 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
                 for (int t = 0; t < 9; ++t) sacc = fmaf(v[t / 3][q + t % 3], wt[t], sacc);
                 d[q] = fmaxf(sacc, 0.f);
             }
-            const float *wp = rec + 12;
+            if constexpr (MF) {
+                static_for_dw<0, 8>([&](auto cc) {
+                    constexpr int cq = decltype(cc)::value;
 #pragma unroll
-            for (int c4 = 0; c4 < CT; c4 += 4) {
-                const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + c4);
+                    for (int q = 0; q < 4; ++q) {
+                        if (half == 0) acc4[q][cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA, d[q], acc4[q][cq], 4, cq, 0);
+                        else acc4[q][cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA, d[q], acc4[q][cq], 4, 8 + cq, 0);
+                    }
+                });
+            } else {
+                const float *wp = rec + 12;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[q][c4] = fmaf(d[q], w[0], acc[q][c4]);
-                    acc[q][c4 + 1] = fmaf(d[q], w[1], acc[q][c4 + 1]);
-                    acc[q][c4 + 2] = fmaf(d[q], w[2], acc[q][c4 + 2]);
-                    acc[q][c4 + 3] = fmaf(d[q], w[3], acc[q][c4 + 3]);
+                for (int c4 = 0; c4 < CT; c4 += 4) {
+                    const floatx4 w = *reinterpret_cast<const floatx4 *>(wp + c4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[q][c4] = fmaf(d[q], w[0], acc[q][c4]);
+                        acc[q][c4 + 1] = fmaf(d[q], w[1], acc[q][c4 + 1]);
+                        acc[q][c4 + 2] = fmaf(d[q], w[2], acc[q][c4 + 2]);
+                        acc[q][c4 + 3] = fmaf(d[q], w[3], acc[q][c4 + 3]);
+                    }
                 }
             }
         }
@@ -267,7 +306,7 @@ __global__ __launch_bounds__(256) void dwpw_row4_kernel(DwPwArgs a) {
         floatx4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float v = acc[q][c] + bq[c];
+            float v = (MF ? acc4[MF ? q : 0][MF ? c >> 2 : 0][c & 3] : acc[MF ? 0 : q][MF ? 0 : c]) + bq[c];
             if (a.relu) v = fmaxf(v, 0.f);
             o[q] = v;
         }
@@ -705,13 +744,16 @@ void launch_dwpw(const DwPwArgs &a, hipStream_t s) {
     if (row4 && a.stride == 1 && !a.add && a.H == a.Ho && a.W == a.Wo && a.W % 4 == 0 && (a.Cout == 16 || a.Cout == 32) && a.Cin <= 64) {
         const long threads = (long)a.B * a.H * (a.W / 4);
         const dim3 grid((unsigned)((threads + 255) / 256));
-        const size_t lds = (size_t)a.Cin * (12 + a.Cout) * sizeof(float);
+        static const bool mf = !(frt_tuning_env("FRT_ROW4_MFMA") && frt_tuning_env("FRT_ROW4_MFMA")[0] == '0');
+        const bool use_mf = mf && a.Cout == 32 && a.Cin % 2 == 0;
+        const size_t lds = (size_t)a.Cin * (12 + a.Cout + (use_mf ? 32 : 0)) * sizeof(float);
         // (ring depth measured on the 8 -> 16 block: 98 / 97 / 99 us with 1 / 2 / 3 channels in flight - the kernel waits on memory 60 % of
         //  its wave cycles but not for lack of bytes in flight; default = the shallow ring, 176 registers)
         static const int ns16 = frt_tuning_env("FRT_ROW4_NS") ? atoi(frt_tuning_env("FRT_ROW4_NS")) : 2;
         if (a.Cout == 16 && ns16 == 4) hipLaunchKernelGGL((dwpw_row4_kernel<16, 4>), grid, dim3(256), lds, s, a);
         else if (a.Cout == 16 && ns16 == 3) hipLaunchKernelGGL((dwpw_row4_kernel<16, 3>), grid, dim3(256), lds, s, a);
         else if (a.Cout == 16) hipLaunchKernelGGL((dwpw_row4_kernel<16, 2>), grid, dim3(256), lds, s, a);
+        else if (use_mf) hipLaunchKernelGGL((dwpw_row4_kernel<32, 2, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((dwpw_row4_kernel<32, 2>), grid, dim3(256), lds, s, a);
         return;
     }
