@@ -203,7 +203,7 @@ def test_dynamic_range_of_the_fp16_activation_storage(frt, synth, tmp_path, whic
 def test_branch_conditioning_at_load_removes_the_silent_range_failure(frt, synth, tmp_path, scale):
     """Round-4 review item 6.  The one SILENT failure of the sweep above was a conv1 -> PReLU -> conv2 branch 1e-4 times smaller than the
     synthetic weights keep it (1 - cos 4.8e-4, five times north_star's tolerance): T and conv1's fp16 weights in the subnormals, conv2's near
-    overflow.  libfrt now conditions every unit at load (frt_api.cpp: conv1 rows, conv2 columns / rows and the closing BatchNorm's scale by
+    overflow.  libfrt now conditions every unit at load (frt_embedder.cpp: conv1 rows, conv2 columns / rows and the closing BatchNorm's scale by
     powers of two - the same function, exactly); the embeddings of a branch rescaled by 1e-6 ... 1e5 match the fp32 oracle as well as the
     well-scaled network does (1 - cos <= 1e-5)."""
     import importlib.util

@@ -126,5 +126,11 @@ FRT_LIB=$ROOT/face-recognition-cpp-tensorrt_amd/libfrt_tuning.so FRT_DET_STEM_CH
   done
 } > "$OUT/${TAG}_stage_ablation_raw.txt" 2>&1
 for f in "$OUT"/${TAG}_det_kernel_stats_b*.csv; do echo "== $(basename $f)"; python tools/det_table.py "$f"; done > "$OUT/${TAG}_det_tables.txt" 2>&1
+# 8. round 6: the adaptive mode at 2 - 11 calls in flight (4-frame calls), the fp32 recogniser pass per layer, the two fp32-MFMA microbenchmarks
+python tools/proxy_only.py 2 3 4 5 6 8 11 2>&1 | grep depth > "$OUT/${TAG}_adaptive_depth_sweep.txt"
+{ FRT_PROF_FP32=1 bash tools/trace_layers.sh 4 4; FRT_PROF_FP32=1 bash tools/trace_layers.sh 8 4 | tail -1; } > "$OUT/${TAG}_fp32_layers.txt" 2>&1
+for P in mfma_f32_chain mfma_4x4_fma; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -w -o /tmp/$P "$ROOT/tools/ubench/$P.hip" 2>/dev/null && timeout 120 /tmp/$P > "$OUT/${TAG}_$P.txt" 2>&1
+done
 python -c "import __graft_entry__ as e; e.smoke()" > "$OUT/${TAG}_smoke.txt" 2>&1
 ls -la "$OUT"

@@ -13,7 +13,7 @@ network computes (so the fp32 oracle's embedding is the same up to rounding and 
                    conv2 weights / t (both are fp16 in the product: the weights leave their trained range too, as they would in such a net).
 
 Round 5: libfrt conditions every unit's branch at load (powers of two on conv1 rows / conv2 columns + rows / the closing BatchNorm's scale, the same
-function exactly - csrc/frt_api.cpp), so the branch sweep is flat now (5.5e-6 from 1e-4 to 1e4, profiles/r05e_dynamic_range.json; round 3:
+function exactly - csrc/frt_embedder.cpp), so the branch sweep is flat now (5.5e-6 from 1e-4 to 1e4, profiles/r05e_dynamic_range.json; round 3:
 4.8e-4 at 1e-4, non-finite at 1e4).  The tuning build's FRT_ARC_CONDITION=0 restores the unconditioned load for an A/B.
 
     python tools/dynamic_range_sweep.py --out gpurun_out/r03_dynamic_range.json        (GPU box)
