@@ -270,3 +270,31 @@ def test_fp16_overflow_is_not_silent(frt, synth, tmp_path):
     got = rec.doInference(face_input(synth.make_faces(2)))
     rec.close()
     assert not np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("mode", ["ir", "ir_se"])
+def test_compact_strips_at_ragged_batches(frt, synth, blobs, mode):
+    """Round 6: from 112 faces per pass the 14x14 and 7x7 body convs run on compact strips (conv_patchc_kernel: 8 images of 14x14 per 7 strips,
+    128 images of 7x7 per 49 strips; a strip crosses image boundaries, and the LAST strips of a pass whose face count is not a multiple of 8
+    hold pixels of images that do not exist).  Batches of 112, 113, 119, 121 and 127 faces must embed every face like the 128-face pass does -
+    bit for bit: a face's outputs depend on nothing but its own pixels and the kernel class - and like the fp32 oracle to north_star's 1e-4
+    (the first, a middle and the last face of each batch).  IR-SE takes the compact kernel for conv1 and the padded one, SE tail fused, for conv2."""
+    from oracle import nets
+    path, sd = blobs(mode)
+    x = np.random.default_rng(23).standard_normal((128, 3, 112, 112)).astype(np.float32) * 0.5
+    full = frt.ArcFaceIR50(path, maxBatchSize=128)
+    want = full.doInference(x)
+    again = full.doInference(x)
+    full.close()
+    assert np.array_equal(want, again)
+    probe = [0, 63, 111, 112, 118, 126, 127]
+    ref = nets.arcface_forward(sd, x[probe])
+    assert ((want[probe].astype(np.float64) * ref).sum(1) > 1 - 1e-4).all()
+    for F in (112, 113, 119, 121, 127):
+        rec = frt.ArcFaceIR50(path, maxBatchSize=F)
+        e = rec.doInference(x[:F])
+        shifted = rec.doInference(np.concatenate([x[1:F], x[:1]]))  # the same faces one slot earlier: other strips, other image boundaries
+        rec.close()
+        assert np.isfinite(e).all(), F
+        assert np.array_equal(e, want[:F]), (mode, F, int((e != want[:F]).any(1).sum()))
+        assert np.array_equal(shifted[:F - 1], e[1:]) and np.array_equal(shifted[F - 1], e[0]), (mode, F)

@@ -678,6 +678,17 @@ def test_adaptive_pairing_holds_calls_only_behind_a_busy_recogniser(frt, synth, 
         for i in range(n_batches):
             assert same(res[i].numpy(), want_res[i]), i
             assert same_emb(emb[i].numpy(), want_emb[i]), i
+    # tickets of one merged call that want different things: every other submit without embeddings
+    res, emb = new_out()
+    tickets = [pipe.submit(pinned[i].numpy(), res[i].numpy().view(frt.RESULT_DTYPE), emb[i].numpy() if i % 2 == 0 else None) for i in range(n_batches)]
+    for t in tickets:
+        pipe.wait(t)
+    for i in range(n_batches):
+        assert same(res[i].numpy(), want_res[i]), i
+        if i % 2 == 0:
+            assert same_emb(emb[i].numpy(), want_emb[i]), i
+        else:
+            assert not emb[i].numpy().any(), i                       # nobody wrote where nothing was asked for
     p2, s2 = pipe.pairing_stats()
     mc, mt = pipe.merge_stats()
     # calls shared passes - as whole calls merged at the host boundary (detector busy at the submit) and / or at the recogniser stage
