@@ -2,7 +2,7 @@
 # Same-box A/B of two builds of libfrt.so: alternating legs of the benchmark's timed region (no side measurements).
 #   tools/ab_lib.sh TAG OLD_LIB [legs] [-- bench args]      (OLD_LIB relative to the package directory, e.g. libfrt_r05.so)
 # The old library is not in the repository (*.so is ignored): build it from the commit to compare against, e.g. round 5's final tree:
-#   git worktree add /tmp/r05 a3fcd79 && make -j16 -C /tmp/r05/face-recognition-cpp-tensorrt_amd/csrc && cp /tmp/r05/face-recognition-cpp-tensorrt_amd/libfrt.so face-recognition-cpp-tensorrt_amd/libfrt_r05.so
+#   git worktree add /tmp/r05 17e97a2 && make -j16 -C /tmp/r05/face-recognition-cpp-tensorrt_amd/csrc && cp /tmp/r05/face-recognition-cpp-tensorrt_amd/libfrt.so face-recognition-cpp-tensorrt_amd/libfrt_r05.so
 # bench.py --ab-old-lib loads it with the symbols it lacks skipped (warned on stderr); the product import of the binding is strict.
 set -u
 TAG=${1:-ab}; OLDLIB=${2:-libfrt_r05.so}; LEGS=${3:-3}
