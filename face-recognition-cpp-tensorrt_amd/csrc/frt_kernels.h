@@ -47,6 +47,7 @@ void launch_match_top1(const float *gallery, int N, int D, const float *queries,
                        int32_t *idx_out, float *sim_out, int row_offset, hipStream_t s);
 int match_top1_blocks(int N, int F);
 // screened top-1: fp16 shadow gallery + coarse MFMA pass + exact re-rank of the few tiles that can hold the maximum
+constexpr int FRT_MATCH_CTL_WORDS = 32 + 64 * 32;
 struct ScreenScratch {
     half_t *q16;       // [F][D]
     float *tilemax;    // [F][tiles][sub], sub = 1 or 4 coarse maxima per 128-row tile
@@ -58,7 +59,7 @@ struct ScreenScratch {
     float *wgmax;                 // [coarse workgroups][F] maxima of a workgroup's coarse entries
     void *pairs;                  // (query, tile) candidate pairs
     int pair_cap;
-    int *ctl;                     // [32] control words: overflow flag, per-sub-list pair counts (kernels_match.hip)
+    int *ctl;                     // [FRT_MATCH_CTL_WORDS] control words: overflow flag, per-sub-list pair counts, one 128-byte line each (kernels_match.hip)
     unsigned long long *qkey;     // [F] packed (similarity, ~row) winners of the scalar re-rank
     // int8 shadow gallery (round 4; fast path, D = 512, fp32-stored galleries): null -> the fp16 shadow is scanned
     const uint8_t *g8;            // fragment-ordered biased bytes (value + 128), gallery8_bytes(N, D)

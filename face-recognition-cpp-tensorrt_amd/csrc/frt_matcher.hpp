@@ -246,11 +246,11 @@ struct frt_matcher {
             HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.segmax), (size_t)cap * 16 * sizeof(float)));
             const char *fe = frt_tuning_env("FRT_MATCH_FAST");  // "0": the round-2 tile-list re-rank (diagnostics, tuning build)
             if (!(fe && fe[0] == '0')) {
-                scr.pair_cap = std::max(cap * 64, 8192);  // (a multiple of the 16 sub-lists)
+                scr.pair_cap = std::max(cap * 64, 8192);  // (a multiple of the 64 sub-lists)
                 HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.wgmax), (size_t)256 * cap * sizeof(float)));
                 HIPCHK(hipMalloc(&scr.pairs, (size_t)scr.pair_cap * 8));
-                HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.ctl), 32 * sizeof(int)));  // CTL_WORDS (kernels_match.hip)
-                HIPCHK(hipMemset(scr.ctl, 0, 32 * sizeof(int)));
+                HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.ctl), FRT_MATCH_CTL_WORDS * sizeof(int)));
+                HIPCHK(hipMemset(scr.ctl, 0, FRT_MATCH_CTL_WORDS * sizeof(int)));
                 HIPCHK(hipMalloc(reinterpret_cast<void **>(&scr.qkey), (size_t)cap * sizeof(unsigned long long)));
             }
         }

@@ -17,7 +17,7 @@
 
 #include "frt_kernels.h"
 
-constexpr int CTL_WORDS = 32;  // control words of the fast screened path (cleared by the coarse scan; layout at CTL_OVERFLOW below)
+constexpr int CTL_WORDS = FRT_MATCH_CTL_WORDS;  // control words of the fast screened path (cleared by the coarse scan; layout at CTL_OVERFLOW below; frt_matcher.hpp allocates them)
 
 #include <limits.h>
 
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void match_coarse_kernel(const half_t *__restr
     const int r = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.y * 128;
     if (ctl && blockIdx.x == 0 && blockIdx.y == 0) {
-        if (tid < CTL_WORDS) ctl[tid] = 0;
+        for (int i = tid; i < CTL_WORDS; i += 256) ctl[i] = 0;
         for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
     }
     for (int i = tid; i < 128 * (D / 8); i += 256) {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void match_coarse_i8_kernel(const uint8_t *__r
     const int r = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.y * (32 * NQB);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (tid < CTL_WORDS) ctl[tid] = 0;
+        for (int i = tid; i < CTL_WORDS; i += 256) ctl[i] = 0;
         for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
     }
     for (int i = tid; i < 32 * NQB * (D / 8); i += 256) {
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void match_coarse_i8x4_kernel(const uint8_t *_
     const int rb = wave >> 1, qh = wave & 1;
     const int q0 = blockIdx.y * 128;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (tid < CTL_WORDS) ctl[tid] = 0;
+        for (int i = tid; i < CTL_WORDS; i += 256) ctl[i] = 0;
         for (int i = tid; i < F; i += 256) qkey[i] = 0ull;
     }
     for (int i = tid; i < 128 * (D / 8); i += 256) {
@@ -958,10 +958,12 @@ struct MatchPair {
     int q, tile;  // tile: bits 0 - 27 the 128-row tile, bits 28 - 31 which of its four 32-row blocks are inside the band
 };
 constexpr int PAIR_TILE_MASK = (1 << 28) - 1;
-// ctl words: [1] overflow flag, [CTL_SEG0 + s] number of pairs in sub-list s.  The pair list is SEL_SEG sub-lists of pair_cap / SEL_SEG
-// entries, one per tile segment (= blockIdx.x of the selection): 1 400 increments of ONE counter cost 35 us of atomics (queries that match
-// nothing, int8 band), sixteen counters share them out
-constexpr int CTL_OVERFLOW = 1, CTL_SEG0 = 4;
+// ctl words: [1] overflow flag, [CTL_SEG0 + s * CTL_STRIDE] number of pairs in sub-list s.  The pair list is SEL_SUB sub-lists of pair_cap / SEL_SUB
+// entries, one per (tile segment = blockIdx.x of the selection, query & 3): 1 400 increments of ONE counter cost 35 us of atomics (queries that match
+// nothing, int8 band).  Round 4 shared them out over sixteen counters in ONE cache line - the selection still took 27 us with ~ 2 000 pairs against
+// 7 us with 128 (returning atomics on one line queue in one L2 channel whatever the address); round 6: 64 counters, each in its own 128-byte line.
+constexpr int CTL_OVERFLOW = 1, CTL_SEG0 = 32, CTL_STRIDE = 32, SEL_QSUB = 4, SEL_SUB = SEL_SEG * SEL_QSUB;
+static_assert(CTL_SEG0 + SEL_SUB * CTL_STRIDE <= CTL_WORDS, "control words");
 constexpr int FB_BLOCKS = 128;  // workgroups of the gated fallback scan (it returns at once in the normal case: keep the empty launch small)
 
 __device__ __forceinline__ unsigned mono_bits(float f) {
@@ -1025,13 +1027,13 @@ __global__ __launch_bounds__(256) void match_select_pairs_kernel(const float *__
         const unsigned long long bal = __ballot(mask != 0u);
         if (bal) {
             const int first = __ffsll((long long)bal) - 1;
-            const int sub_cap = pair_cap / SEL_SEG;
+            const int sub_cap = pair_cap / SEL_SUB, sub = seg + SEL_SEG * (q & (SEL_QSUB - 1));
             int base = 0;
-            if (lane == first) base = atomicAdd(&ctl[CTL_SEG0 + seg], __popcll(bal));
+            if (lane == first) base = atomicAdd(&ctl[CTL_SEG0 + sub * CTL_STRIDE], __popcll(bal));
             base = __shfl(base, first);
             if (mask) {
                 const int i = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (i < sub_cap) pairs[seg * sub_cap + i] = MatchPair{q, (int)((unsigned)t | (mask << 28))};
+                if (i < sub_cap) pairs[sub * sub_cap + i] = MatchPair{q, (int)((unsigned)t | (mask << 28))};
                 else ctl[CTL_OVERFLOW] = 1;
             }
         }
@@ -1052,12 +1054,12 @@ __global__ __launch_bounds__(128) void match_rerank_pairs_kernel(const GT *__res
     __shared__ int ri[2];
     const int tid = threadIdx.x;
     if (ctl[CTL_OVERFLOW]) return;  // the exact full scan answers this call
-    const int sub_cap = pair_cap / SEL_SEG;
+    const int sub_cap = pair_cap / SEL_SUB;
     int maxc = 0;
-    for (int sgi = 0; sgi < SEL_SEG; ++sgi) maxc = max(maxc, min(ctl[CTL_SEG0 + sgi], sub_cap));
-    for (int p = blockIdx.x; p < maxc * SEL_SEG; p += gridDim.x) {  // virtual index over the sub-lists, interleaved
-        const int sgi = p % SEL_SEG, pi_ = p / SEL_SEG;
-        if (pi_ >= ctl[CTL_SEG0 + sgi]) continue;  // (block-uniform)
+    for (int sgi = 0; sgi < SEL_SUB; ++sgi) maxc = max(maxc, min(ctl[CTL_SEG0 + sgi * CTL_STRIDE], sub_cap));
+    for (int p = blockIdx.x; p < maxc * SEL_SUB; p += gridDim.x) {  // virtual index over the sub-lists, interleaved
+        const int sgi = p % SEL_SUB, pi_ = p / SEL_SUB;
+        if (pi_ >= ctl[CTL_SEG0 + sgi * CTL_STRIDE]) continue;  // (block-uniform)
         const MatchPair pr = pairs[sgi * sub_cap + pi_];
         __syncthreads();  // the previous pair's readers of qs / rv are done
         for (int k = tid * 4; k < D; k += 512) *reinterpret_cast<floatx4 *>(qs + k) = *reinterpret_cast<const floatx4 *>(E + (long)pr.q * D + k);
