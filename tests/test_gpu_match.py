@@ -298,6 +298,32 @@ def test_screened_top1_pair_list_overflow_falls_back_to_the_exact_scan(frt, synt
     m.close()
 
 
+def test_screened_top1_one_overflowing_pair_sub_list_falls_back_to_the_exact_scan(frt, synth):
+    """Round 6: the pair list is 64 sub-lists (tile segment x query & 3), each with its own counter on its own cache line.  ONE sub-list
+    overflowing - six queries of the same class that each match a planted row in all 32 tiles of segment 0: 192 pairs for 128 slots, with the
+    list as a whole almost empty - must send the call through the exact scan like a full list does: same answers as the materialised matrix,
+    first index among the identical planted rows."""
+    N = 65536                                                       # 512 tiles: 32 per segment
+    g = synth.make_gallery(N)
+    d = synth.make_gallery(1, seed=11)[0]
+    planted = np.arange(32) * 128 + 5                               # one row in every tile of segment 0
+    g[planted] = d
+    q = synth.make_gallery(24, seed=7)
+    same_class = [0, 4, 8, 12, 16, 20]                              # query & 3 == 0
+    q[same_class] = d
+    m = frt.MatMul(0)
+    m.init(g)
+    i, s = m.top1(q)
+    full = m.calculate(q)
+    assert np.array_equal(i, full.argmax(1).astype(np.int32)) and np.array_equal(s, full.max(1))
+    assert all(int(i[k]) == 5 for k in same_class)                  # the first of the identical rows
+    # and the same object answers an ordinary call afterwards (flag and counters are cleared per call)
+    q2 = synth.make_queries(g, [9, 40000, 777, 65535])
+    i2, _ = m.top1(q2)
+    assert i2.tolist() == [9, 40000, 777, 65535]
+    m.close()
+
+
 def test_calculate_top1_is_the_matrix_and_its_row_maxima_in_one_call(frt, synth):
     """frt_matcher_calculate_top1 (what the drop-in ArcFaceIR50::featureMatching + getOutputs use): the materialised [F, N] matrix equals
     calculate(), the (idx, sim) pairs equal top1() AND std::max_element over the rows, bit for bit; without the matrix the pairs are the same."""
